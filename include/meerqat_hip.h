@@ -1,0 +1,97 @@
+/*
+ * meerqat_hip.h -- C ABI of libmeerqat_hip.so, the MI355X (gfx950) implementation of the
+ * arithmetic that PaulLerner/ViQuAE's dense-retrieval path delegates to FAISS and Hugging Face.
+ *
+ * The reference has no FFI of its own (it is pure Python); every entry point below names the
+ * reference call site whose arithmetic it replaces.  Conventions:
+ *   - plain pointers and sizes only, no C++/torch types; `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream);
+ *   - every `*_dev` / device pointer is HBM memory owned by the CALLER (the Python host allocates
+ *     through torch); nothing is allocated, freed or retained across calls;
+ *   - return value: MQ_OK (0) or a negative MQ_E* code; no exceptions cross the boundary;
+ *     kernels are enqueued on `stream` and NOT synchronised (results are valid after the caller
+ *     synchronises the stream);
+ *   - re-entrant per stream: no global mutable state.
+ */
+#ifndef MEERQAT_HIP_H
+#define MEERQAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MQ_OK 0
+#define MQ_EINVAL (-1)     /* bad argument (NULL pointer, non-positive size, unsupported k, ...) */
+#define MQ_EWORKSPACE (-2) /* workspace too small */
+#define MQ_EHIP (-3)       /* a HIP runtime call failed; see mq_last_hip_error() */
+#define MQ_EUNSUPPORTED (-4)
+
+#define MQ_METRIC_IP 0 /* faiss.METRIC_INNER_PRODUCT, "metric_type": 0 in experiments/ir/..../search/config.json */
+#define MQ_METRIC_L2 1 /* faiss.METRIC_L2 (FAISS default when metric_type is None) */
+
+#define MQ_KNN_MAX_K 128 /* largest k of the fused scan; the reference uses k=100 (ir/search.py:12) */
+
+const char *mq_version(void);
+const char *mq_strerror(int code);
+int mq_last_hip_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * KB matrix in HBM: the "panel" layout.  Replaces faiss IndexFlat's row-major storage filled by
+ * FaissIndex.add_vectors (datasets/search.py:255-313, reached from meerqat/ir/search.py:245).
+ * Row i, component k lives at   packed[((i / 64) * dpad + k) * 64 + (i % 64)],
+ * dpad = d rounded up to 16, rows padded (zero) to a multiple of 256.
+ * ------------------------------------------------------------------------------------------- */
+int64_t mq_padded_rows(int64_t n_rows);
+int mq_padded_dim(int d);
+size_t mq_packed_bytes(int64_t n_rows, int d);
+
+/* Pack `n` row-major fp32 rows (device) into the panel buffer at rows [row_offset, row_offset+n).
+ * l2norm != 0 applies FAISS's "L2norm," NormalizationTransform (string_factory "L2norm,Flat",
+ * meerqat/ir/search.py:230-233) to each row first.  sqnorm_dev[row] receives ||x||^2 of the stored
+ * row (used by the L2 metric).  capacity_rows = mq_padded_rows(total rows) of the destination;
+ * the caller zero-fills the panel buffer once before the first call. */
+int mq_pack_rows_f32(const float *rows_dev, int64_t n, int d, int64_t row_offset, int l2norm, float *packed_dev,
+                     int64_t capacity_rows, float *sqnorm_dev, void *stream);
+
+/* Inverse of mq_pack_rows_f32 (FaissIndex.save / reconstruct, datasets/search.py:387-397). */
+int mq_unpack_rows_f32(const float *packed_dev, int64_t capacity_rows, int d, int64_t row_offset, int64_t n,
+                       float *rows_dev, void *stream);
+
+/* In-place row L2 normalisation of a row-major [n,d] device matrix: L2norm(), meerqat/ir/search.py:43-46. */
+int mq_l2norm_rows_f32(float *rows_dev, int64_t n, int d, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Exact brute-force top-k: replaces faiss IndexFlat.search behind FaissIndex.search_batch
+ * (datasets/search.py:369-385), called by KnowledgeBase.search_batch (meerqat/ir/search.py:146).
+ *   packed_dev/sqnorm_dev : the KB shard (N rows) as written by mq_pack_rows_f32
+ *   queries_dev           : [nq, d] row-major fp32
+ *   metric                : MQ_METRIC_IP or MQ_METRIC_L2
+ *   l2norm_queries        : apply the index's "L2norm," transform to the queries first
+ *   id_offset             : added to every returned row id (global id of the shard's row 0)
+ *   D_dev [nq,k] fp32, I_dev [nq,k] int64: best first; equal scores by ascending id; unfilled
+ *                           slots are (-inf | +inf, -1) as FAISS leaves them
+ *   ws_dev/ws_bytes       : scratch of at least mq_knn_workspace_bytes(N, d, nq, k)
+ * Scores are the k-ordered fp32 fma chain (see oracle/knn_oracle.c); selection is exact.
+ * ------------------------------------------------------------------------------------------- */
+size_t mq_knn_workspace_bytes(int64_t N, int d, int nq, int k);
+int mq_knn_search_f32(const float *packed_dev, const float *sqnorm_dev, int64_t N, int d, const float *queries_dev,
+                      int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float *D_dev,
+                      int64_t *I_dev, void *ws_dev, size_t ws_bytes, void *stream);
+
+/* Name and launch geometry of the scan kernel for the given problem (for bench.py / profiles):
+ * out[0]=workgroups, out[1]=threads per workgroup, out[2]=LDS bytes, out[3]=query tiles,
+ * out[4]=KB slabs, out[5]=KB chunks (256 rows each). */
+int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[6]);
+
+/* Merge per-shard results after the all-gather (new step; no reference
+ * counterpart): Ds/Is [nshards, nq, k] with GLOBAL ids -> the k best per query. */
+int mq_topk_merge_f32(const float *Ds_dev, const int64_t *Is_dev, int nshards, int nq, int k, int metric,
+                      float *D_dev, int64_t *I_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEERQAT_HIP_H */

@@ -1,0 +1,142 @@
+"""ctypes front-end of oracle/knn_oracle.c (TEST INFRASTRUCTURE, see oracle/__init__.py).
+
+Also holds ``knn_numpy_f64``: an independent float64 brute force used (a) to validate the C
+restatement and (b) to judge free-form fp32 results by re-scoring ("hard
+parts": two correct fp32 implementations may swap near-tied neighbours).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libknn_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile knn_oracle.c with gcc (a few seconds)."""
+    src = os.path.join(_HERE, "knn_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = ctypes.CDLL(_SO)
+        fp = ctypes.c_void_p
+        L.oracle_knn_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int64, fp, fp]
+        L.oracle_knn_f32.restype = ctypes.c_int
+        L.oracle_l2norm_rows_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int]
+        L.oracle_l2norm_rows_f32.restype = None
+        L.oracle_sqnorm_rows_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int, fp]
+        L.oracle_sqnorm_rows_f32.restype = None
+        L.oracle_topk_merge.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp]
+        L.oracle_topk_merge.restype = ctypes.c_int
+        L.oracle_num_threads.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def num_threads():
+    return int(lib().oracle_num_threads())
+
+
+def l2norm_rows(x):
+    """Row L2-normalisation with the oracle's fixed arithmetic (returns a new array)."""
+    x = _f32(x).copy()
+    if x.ndim != 2:
+        raise ValueError("expected a 2-D array")
+    lib().oracle_l2norm_rows_f32(x.ctypes.data, x.shape[0], x.shape[1])
+    return x
+
+
+def sqnorm_rows(x):
+    x = _f32(x)
+    out = np.empty(x.shape[0], dtype=np.float32)
+    lib().oracle_sqnorm_rows_f32(x.ctypes.data, x.shape[0], x.shape[1], out.ctypes.data)
+    return out
+
+
+def knn(X, Q, k, metric=0, id_offset=0, l2norm=False):
+    """Brute-force top-k of Q against X; returns (D f32 [nq,k], I i64 [nq,k]).
+
+    ``l2norm=True`` applies the "L2norm," transform to both sides first (FAISS
+    NormalizationTransform on add and on search)."""
+    X, Q = _f32(X), _f32(Q)
+    if Q.ndim != 2 or X.ndim != 2 or Q.shape[1] != X.shape[1]:
+        raise ValueError("shape mismatch")
+    if l2norm:
+        X, Q = l2norm_rows(X), l2norm_rows(Q)
+    nq, d = Q.shape
+    D = np.empty((nq, k), dtype=np.float32)
+    I = np.empty((nq, k), dtype=np.int64)
+    rc = lib().oracle_knn_f32(X.ctypes.data, X.shape[0], d, Q.ctypes.data, nq, k, int(metric), int(id_offset),
+                              D.ctypes.data, I.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"oracle_knn_f32 failed: {rc}")
+    return D, I
+
+
+def topk_merge(Ds, Is, metric=0):
+    """Merge [nshards,nq,k] per-shard lists (global ids) into the k best per query."""
+    Ds = _f32(Ds)
+    Is = np.ascontiguousarray(Is, dtype=np.int64)
+    ns, nq, k = Ds.shape
+    D = np.empty((nq, k), dtype=np.float32)
+    I = np.empty((nq, k), dtype=np.int64)
+    rc = lib().oracle_topk_merge(Ds.ctypes.data, Is.ctypes.data, ns, nq, k, int(metric), D.ctypes.data, I.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"oracle_topk_merge failed: {rc}")
+    return D, I
+
+
+# ----------------------------------------------------------------------------------------------
+# independent cross-checks (slow; small cases only)
+# ----------------------------------------------------------------------------------------------
+def knn_numpy_f64(X, Q, k, metric=0):
+    """float64 scores + (score, id) lexicographic order. Independent of knn_oracle.c."""
+    X64, Q64 = np.asarray(X, np.float64), np.asarray(Q, np.float64)
+    S = Q64 @ X64.T
+    if metric == 1:
+        S = (Q64 ** 2).sum(1)[:, None] + (X64 ** 2).sum(1)[None, :] - 2 * S
+        S = np.maximum(S, 0)
+        order = np.lexsort((np.broadcast_to(np.arange(S.shape[1]), S.shape), S), axis=1)
+    else:
+        order = np.lexsort((np.broadcast_to(np.arange(S.shape[1]), S.shape), -S), axis=1)
+    I = order[:, :k]
+    D = np.take_along_axis(S, I, axis=1)
+    if I.shape[1] < k:
+        pad = k - I.shape[1]
+        I = np.concatenate([I, -np.ones((I.shape[0], pad), np.int64)], 1)
+        D = np.concatenate([D, np.full((D.shape[0], pad), np.inf if metric == 1 else -np.inf)], 1)
+    return D, I.astype(np.int64)
+
+
+def chain_scores_python(X, Q):
+    """Pure-Python/numpy-scalar statement of the fmaf chain for TINY inputs: validates that the C
+    file's vectorised loops really are the k-ordered fp32 fma chain. fma is emulated exactly in
+    float64 (a*b of two fp32 is exact in fp64; one fp64 add then one rounding to fp32 is a correctly
+    rounded fp32 fma unless the fp64 add itself is inexact AND lands on an fp32 rounding boundary --
+    double rounding; inputs for this check are kept to small-exponent-range values where that cannot
+    change the result measurably, and any mismatch is reported by the caller)."""
+    X = np.asarray(X, np.float32)
+    Q = np.asarray(Q, np.float32)
+    out = np.zeros((Q.shape[0], X.shape[0]), np.float32)
+    for i in range(Q.shape[0]):
+        for j in range(X.shape[0]):
+            acc = np.float32(0)
+            for kk in range(X.shape[1]):
+                acc = np.float32(np.float64(Q[i, kk]) * np.float64(X[j, kk]) + np.float64(acc))
+            out[i, j] = acc
+    return out

@@ -1,0 +1,213 @@
+/*
+ * oracle/knn_oracle.c -- CPU restatement of the brute-force kNN the reference
+ * delegates to FAISS IndexFlat.  TEST INFRASTRUCTURE ONLY: imported by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product
+ * path (viquae_amd/ fails loudly when the HIP library is missing).
+ *
+ * PARITY STATUS: "parity unpinned" against FAISS itself.  The arithmetic lives
+ * in the third-party module `faiss` (faiss-gpu>=1.7.1, /root/reference/
+ * requirements.txt:14), which is neither vendored in /root/reference nor
+ * installable here, and the reference's only test (tests/search.py:1-20) is
+ * stale and pins nothing on this path.  What IS pinned: (i) the plumbing, by
+ * running the reference's own KnowledgeBase.search_batch /
+ * search_batch_if_not_None (meerqat/ir/search.py:135-171) over this restatement
+ * (tools/make_golden.py); (ii) the result on integer-lattice data, where every
+ * fp32 summation order gives the same scores, against an independent
+ * torch.mm + stable argsort computation (tests/golden/knn_*.npz).
+ *
+ * Algorithm restated (call sites: meerqat/ir/search.py:146 ->
+ * datasets/search.py:384 FaissIndex.search_batch -> faiss IndexFlat.search):
+ *   - METRIC_INNER_PRODUCT (metric_type 0, experiments/ir/viquae/dpr/search/
+ *     config.json:18): score = <q, x>, larger is better, rows sorted descending.
+ *   - METRIC_L2 (metric_type 1 / FAISS default): squared distance, smaller is
+ *     better, ascending.  FAISS's BLAS path (nq >= 20; the reference searches
+ *     256 queries per batch, dpr/search/config.json:25) evaluates
+ *     ||q||^2 + ||x||^2 - 2<q,x>, clamped at 0.
+ *   - a result-heap per query, initialised with (-inf | +inf, id -1), scanned
+ *     over ascending database ids with a STRICT comparison: an equal score never
+ *     displaces an earlier id, so the lower id wins membership at the k-th
+ *     boundary; unfilled slots keep id -1.  NaN scores never enter.
+ *   - output order: best first; equal scores by ascending id (documented
+ *     choice; FAISS's order inside an equal-score run is version dependent).
+ *
+ * Summation order (the one thing FAISS leaves to BLAS): every inner product and
+ * squared norm here is the k-ordered fp32 chain acc = fmaf(a[k], b[k], acc),
+ * k = 0..d-1, acc0 = +0.  This is bit-for-bit what the gfx950
+ * v_mfma_f32_32x32x2_f32 instruction computes when K is walked in order
+ * (cdna_hip_programming.md section 3), so the HIP path is compared BIT-EXACTLY
+ * (scores and ids) with this file on arbitrary fp32 data.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define QB 32 /* queries per register block */
+
+typedef struct {
+    float g; /* goodness: ip, or -dist for L2 */
+    int64_t id;
+} ent_t;
+
+/* k-ordered fmaf chain: sum_k a[k]*b[k] */
+static float chain_dot(const float *a, const float *b, int d) {
+    float acc = 0.0f;
+    for (int k = 0; k < d; ++k) acc = fmaf(a[k], b[k], acc);
+    return acc;
+}
+
+/* rows[i] /= sqrt(sum_k rows[i][k]^2): the "L2norm," prefix of the reference's
+ * string_factory (meerqat/ir/search.py:230-233; FAISS NormalizationTransform) and
+ * L2norm() (meerqat/ir/search.py:43-46).  Norm^2 is the fmaf chain, sqrtf and the
+ * division are IEEE correctly rounded.  Like the reference there is no epsilon: a
+ * zero row becomes NaN. */
+void oracle_l2norm_rows_f32(float *rows, int64_t n, int d) {
+    for (int64_t i = 0; i < n; ++i) {
+        float *r = rows + i * (int64_t)d;
+        float nr = sqrtf(chain_dot(r, r, d));
+        for (int k = 0; k < d; ++k) r[k] = r[k] / nr;
+    }
+}
+
+void oracle_sqnorm_rows_f32(const float *rows, int64_t n, int d, float *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = chain_dot(rows + i * (int64_t)d, rows + i * (int64_t)d, d);
+}
+
+/* insert (g,id) into a best-first sorted list of length k (strict: caller checked
+ * g > list[k-1].g, or the slot is empty) */
+static inline void list_insert(ent_t *list, int k, float g, int64_t id) {
+    int p = k - 1;
+    /* ids arrive ascending, so on equal g the newcomer goes after existing ones */
+    while (p > 0 && (list[p - 1].id < 0 || list[p - 1].g < g)) {
+        list[p] = list[p - 1];
+        --p;
+    }
+    list[p].g = g;
+    list[p].id = id;
+}
+
+/*
+ * metric: 0 = inner product, 1 = squared L2.
+ * X [N,d] row-major, Q [nq,d] row-major, D [nq,k] fp32, I [nq,k] int64.
+ * ids are reported as row + id_offset.  Returns 0, or -1 on bad arguments.
+ */
+int oracle_knn_f32(const float *X, int64_t N, int d, const float *Q, int nq, int k, int metric,
+                   int64_t id_offset, float *D, int64_t *I) {
+    if (N < 0 || d <= 0 || nq < 0 || k <= 0 || (metric != 0 && metric != 1)) return -1;
+    int nblk = (nq + QB - 1) / QB;
+    float *xn = NULL;
+    if (metric == 1) {
+        xn = (float *)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1));
+        oracle_sqnorm_rows_f32(X, N, d, xn);
+    }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < nblk; ++b) {
+        int q0 = b * QB, nb = nq - q0 < QB ? nq - q0 : QB;
+        /* Qt[k][j]: the block's queries, k-major, so the j loop vectorises while every
+         * lane keeps its own k-ordered chain */
+        float *Qt = (float *)calloc((size_t)d * QB, sizeof(float));
+        ent_t *lists = (ent_t *)malloc(sizeof(ent_t) * (size_t)k * QB);
+        float qn[QB], thr[QB];
+        for (int j = 0; j < nb; ++j) {
+            for (int kk = 0; kk < d; ++kk) Qt[(size_t)kk * QB + j] = Q[(size_t)(q0 + j) * d + kk];
+            qn[j] = metric == 1 ? chain_dot(Q + (size_t)(q0 + j) * d, Q + (size_t)(q0 + j) * d, d) : 0.0f;
+        }
+        for (int j = 0; j < QB; ++j) {
+            thr[j] = -INFINITY;
+            for (int s = 0; s < k; ++s) {
+                lists[(size_t)j * k + s].g = -INFINITY;
+                lists[(size_t)j * k + s].id = -1;
+            }
+        }
+        for (int64_t i = 0; i < N; ++i) {
+            const float *x = X + i * (int64_t)d;
+            float acc[QB];
+            for (int j = 0; j < QB; ++j) acc[j] = 0.0f;
+            for (int kk = 0; kk < d; ++kk) {
+                const float xv = x[kk];
+                const float *qr = Qt + (size_t)kk * QB;
+                for (int j = 0; j < QB; ++j) acc[j] = fmaf(xv, qr[j], acc[j]);
+            }
+            if (metric == 1) {
+                for (int j = 0; j < QB; ++j) {
+                    float dis = (qn[j] + xn[i]) - 2.0f * acc[j];
+                    if (dis < 0.0f) dis = 0.0f;
+                    acc[j] = -dis;
+                }
+            }
+            for (int j = 0; j < nb; ++j) {
+                if (acc[j] > thr[j]) { /* strict; false for NaN */
+                    ent_t *l = lists + (size_t)j * k;
+                    list_insert(l, k, acc[j], i);
+                    thr[j] = l[k - 1].id < 0 ? -INFINITY : l[k - 1].g;
+                }
+            }
+        }
+        for (int j = 0; j < nb; ++j) {
+            for (int s = 0; s < k; ++s) {
+                const ent_t e = lists[(size_t)j * k + s];
+                float out;
+                if (e.id < 0)
+                    out = metric == 1 ? INFINITY : -INFINITY;
+                else
+                    out = metric == 1 ? -e.g : e.g;
+                D[(size_t)(q0 + j) * k + s] = out + 0.0f; /* -0 -> +0 */
+                I[(size_t)(q0 + j) * k + s] = e.id < 0 ? -1 : e.id + id_offset;
+            }
+        }
+        free(Qt);
+        free(lists);
+    }
+    free(xn);
+    return 0;
+}
+
+/*
+ * Merge per-shard results (the new multi-GPU step): Ds/Is are
+ * [nshards, nq, k] best-first lists with global ids; output the k best per query,
+ * ordered by (score better first, id ascending); id -1 entries are empty.
+ */
+int oracle_topk_merge(const float *Ds, const int64_t *Is, int nshards, int nq, int k, int metric, float *D,
+                      int64_t *I) {
+    if (nshards <= 0 || nq < 0 || k <= 0) return -1;
+    for (int q = 0; q < nq; ++q) {
+        int *pos = (int *)calloc((size_t)nshards, sizeof(int));
+        for (int s = 0; s < k; ++s) {
+            int best = -1;
+            float bg = 0;
+            int64_t bid = 0;
+            for (int h = 0; h < nshards; ++h) {
+                if (pos[h] >= k) continue;
+                size_t o = ((size_t)h * nq + q) * k + pos[h];
+                if (Is[o] < 0) continue;
+                float g = metric == 1 ? -Ds[o] : Ds[o];
+                if (best < 0 || g > bg || (g == bg && Is[o] < bid)) {
+                    best = h;
+                    bg = g;
+                    bid = Is[o];
+                }
+            }
+            if (best < 0) {
+                D[(size_t)q * k + s] = metric == 1 ? INFINITY : -INFINITY;
+                I[(size_t)q * k + s] = -1;
+            } else {
+                D[(size_t)q * k + s] = (metric == 1 ? -bg : bg) + 0.0f;
+                I[(size_t)q * k + s] = bid;
+                pos[best]++;
+            }
+        }
+        free(pos);
+    }
+    return 0;
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,149 @@
+"""GPU parity tests of the fused kNN scan (csrc/knn.hip) through the C ABI, against the CPU oracle
+(oracle/knn_oracle.c).  Bar: BIT-EXACT scores and indices (integer/index work; scores are the same
+k-ordered fp32 fma chain on both sides)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(n, d, nq, seed, kind="normal"):
+    rng = np.random.default_rng(seed)
+    if kind == "normal":
+        return rng.standard_normal((n, d), dtype=np.float32), rng.standard_normal((nq, d), dtype=np.float32)
+    if kind == "lattice":
+        return (rng.integers(-128, 129, (n, d)).astype(np.float32), rng.integers(-128, 129, (nq, d)).astype(np.float32))
+    if kind == "ties":
+        return (rng.integers(-2, 3, (n, d)).astype(np.float32), rng.integers(-2, 3, (nq, d)).astype(np.float32))
+    raise ValueError(kind)
+
+
+def _index(X, metric, factory="Flat"):
+    from viquae_amd.index import MI355XFlatIndex
+    idx = MI355XFlatIndex(string_factory=factory, metric_type=metric)
+    idx.add_vectors(X)
+    return idx
+
+
+def _check(X, Q, k, metric, factory="Flat"):
+    from oracle import knn as ok
+    idx = _index(X, metric, factory)
+    D, I = idx.search_batch(Q, k)
+    Do, Io = ok.knn(X, Q, k, metric=metric, l2norm=("L2norm" in factory))
+    assert I.shape == Io.shape and D.dtype == np.float32
+    bad = np.nonzero((I != Io).any(axis=1))[0]
+    assert bad.size == 0, f"index mismatch in {bad.size} queries, first {bad[:5]}: {I[bad[0]][:10]} vs {Io[bad[0]][:10]}"
+    assert np.array_equal(D, Do), f"score mismatch: max abs diff {np.nanmax(np.abs(D - Do))}"
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("n,d,nq,k", [
+    (2048, 64, 37, 10),      # SURVEY 8c fixture shape
+    (2048, 64, 37, 100),
+    (1000, 768, 5, 100),     # nq < 20 (FAISS's non-BLAS path in the reference)
+    (10000, 768, 256, 100),  # BASELINE configs[0]
+    (777, 100, 3, 1),        # ragged everything, k=1, d not a multiple of 16
+    (300, 48, 260, 128),     # two query tiles, k = max
+])
+def test_random_exact(n, d, nq, k, metric):
+    X, Q = _mk(n, d, nq, seed=n + d + nq)
+    _check(X, Q, k, metric)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_integer_lattice(metric):
+    X, Q = _mk(4096, 768, 37, seed=7, kind="lattice")
+    _check(X, Q, 100, metric)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_tie_heavy(metric):
+    # many exactly equal scores: membership at the k-th boundary must go to the lower id
+    X, Q = _mk(3000, 16, 21, seed=11, kind="ties")
+    _check(X, Q, 100, metric)
+
+
+def test_sorted_ascending_worst_case():
+    # every new row beats everything seen so far: the threshold never prunes
+    d = 32
+    X = np.zeros((5000, d), np.float32)
+    X[:, 0] = np.arange(5000, dtype=np.float32)
+    Q = np.zeros((9, d), np.float32)
+    Q[:, 0] = 1.0
+    _check(X, Q, 100, 0)
+
+
+def test_fewer_rows_than_k():
+    X, Q = _mk(7, 16, 4, seed=3, kind="ties")
+    idx = _index(X, 0)
+    D, I = idx.search_batch(Q, 10)
+    assert (I[:, 7:] == -1).all() and np.isneginf(D[:, 7:]).all()
+    assert (np.sort(I[:, :7], axis=1) == np.arange(7)).all()
+    idx = _index(X, 1)
+    D, I = idx.search_batch(Q, 10)
+    assert (I[:, 7:] == -1).all() and np.isposinf(D[:, 7:]).all()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_l2norm_factory(metric):
+    X, Q = _mk(3000, 96, 33, seed=5)
+    _check(X, Q, 50, metric, factory="L2norm,Flat")
+
+
+def test_nan_and_inf_rows_never_enter():
+    X, Q = _mk(600, 32, 6, seed=9)
+    X[17, 3] = np.nan
+    X[100, 0] = np.inf
+    _check(X, Q, 20, 0)
+
+
+def test_incremental_add_matches_single_add():
+    from viquae_amd.index import MI355XFlatIndex
+    X, Q = _mk(1000, 40, 11, seed=21)
+    a = _index(X, 0)
+    b = MI355XFlatIndex(string_factory="Flat", metric_type=0)
+    b.add(X[:640])
+    b.add(X[640:])
+    Da, Ia = a.search_batch(Q, 30)
+    Db, Ib = b.search_batch(Q, 30)
+    assert np.array_equal(Ia, Ib) and np.array_equal(Da, Db)
+    assert np.array_equal(b.reconstruct_n(), X)
+
+
+def test_save_load_roundtrip(tmp_path):
+    from viquae_amd.index import MI355XFlatIndex
+    X, Q = _mk(500, 24, 7, seed=31)
+    a = _index(X, 0, "L2norm,Flat")
+    p = tmp_path / "idx.mq"
+    a.save(p)
+    b = MI355XFlatIndex.load(p)
+    Da, Ia = a.search_batch(Q, 10)
+    Db, Ib = b.search_batch(Q, 10)
+    assert np.array_equal(Ia, Ib) and np.array_equal(Da, Db)
+
+
+def test_shard_merge_kernel():
+    import torch
+    from oracle import knn as ok
+    from viquae_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    ns, nq, k = 5, 19, 100
+    X = rng.integers(-3, 4, (ns * 400, 8)).astype(np.float32)
+    Q = rng.integers(-3, 4, (nq, 8)).astype(np.float32)
+    for metric in (0, 1):
+        Ds, Is = [], []
+        for s in range(ns):
+            D, I = ok.knn(X[s * 400:(s + 1) * 400], Q, k, metric=metric, id_offset=s * 400)
+            Ds.append(D), Is.append(I)
+        Ds, Is = np.stack(Ds), np.stack(Is)
+        Dm, Im = ok.topk_merge(Ds, Is, metric)
+        Dref, Iref = ok.knn(X, Q, k, metric=metric)
+        assert np.array_equal(Im, Iref) and np.array_equal(Dm, Dref)
+        dDs, dIs = torch.from_numpy(Ds).cuda(), torch.from_numpy(Is).cuda()
+        D = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        I = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        _lib.check(lib.mq_topk_merge_f32(dDs.data_ptr(), dIs.data_ptr(), ns, nq, k, metric, D.data_ptr(), I.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert np.array_equal(I.cpu().numpy(), Iref) and np.array_equal(D.cpu().numpy(), Dref)

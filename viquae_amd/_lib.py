@@ -1,0 +1,75 @@
+"""ctypes binding of libmeerqat_hip.so (C ABI: include/meerqat_hip.h).
+
+The library is the product; if it is missing this module raises -- nothing falls back to a CPU
+path.  Loading it and resolving its symbols needs no GPU; calling a compute entry does.
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+_LIB = None
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_sz = ctypes.c_size_t
+c_ptr = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol declared in include/meerqat_hip.h
+SIGNATURES = {
+    "mq_version": (ctypes.c_char_p, []),
+    "mq_strerror": (ctypes.c_char_p, [c_int]),
+    "mq_last_hip_error": (c_int, []),
+    "mq_padded_rows": (c_i64, [c_i64]),
+    "mq_padded_dim": (c_int, [c_int]),
+    "mq_packed_bytes": (c_sz, [c_i64, c_int]),
+    "mq_pack_rows_f32": (c_int, [c_ptr, c_i64, c_int, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr]),
+    "mq_unpack_rows_f32": (c_int, [c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr, c_ptr]),
+    "mq_l2norm_rows_f32": (c_int, [c_ptr, c_i64, c_int, c_ptr]),
+    "mq_knn_workspace_bytes": (c_sz, [c_i64, c_int, c_int, c_int]),
+    "mq_knn_search_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_int, c_int, c_i64,
+                                  c_ptr, c_ptr, c_ptr, c_sz, c_ptr]),
+    "mq_knn_launch_info": (c_int, [c_i64, c_int, c_int, c_int, ctypes.POINTER(c_i64)]),
+    "mq_topk_merge_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+}
+
+
+class MeerqatHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.SO
+
+
+def load():
+    """Load the HIP library (raises if it has not been built; never builds implicitly on import)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise MeerqatHipError(
+            f"{path} is missing: build it with `python -m viquae_amd.build` (hipcc, gfx950). "
+            "viquae_amd has no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        lib = load()
+        msg = lib.mq_strerror(code).decode()
+        extra = f" (hipError {lib.mq_last_hip_error()})" if code == -3 else ""
+        raise MeerqatHipError(f"{what or 'libmeerqat_hip'}: {msg}{extra}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise MeerqatHipError("no GPU visible: viquae_amd runs its arithmetic on MI355X only (no CPU fallback)")

@@ -1,0 +1,332 @@
+"""MI355XFlatIndex -- exact (brute-force) dense index resident in HBM.
+
+Drop-in for ``datasets.search.FaissIndex`` (site-packages/datasets/search.py:225-425) restricted to
+what the reference uses: ``string_factory`` in {None, "Flat", "L2norm,Flat"}, ``metric_type`` in
+{None, 0 (inner product), 1 (L2)} (meerqat/ir/search.py:207-249, experiments/ir/**/config.json).
+It subclasses ``datasets.search.BaseIndex`` so that ``Dataset.search_batch`` /
+``get_nearest_examples_batch`` (datasets/search.py:713-784) work once the object is registered in
+``dataset._indexes``.
+
+All arithmetic happens in libmeerqat_hip.so (csrc/knn.hip) through the C ABI; torch only owns the
+device buffers and the stream.  No CPU fallback.
+"""
+import os
+import struct
+from pathlib import PurePath
+from typing import Optional, Union
+
+import numpy as np
+
+try:  # datasets is the reference's host framework; BaseIndex is the seam
+    from datasets.search import BaseIndex, BatchedSearchResults, SearchResults
+except Exception:  # pragma: no cover - datasets is installed in the target image
+    from typing import NamedTuple
+
+    class BaseIndex:  # type: ignore
+        pass
+
+    class SearchResults(NamedTuple):  # type: ignore
+        scores: list
+        indices: list
+
+    class BatchedSearchResults(NamedTuple):  # type: ignore
+        total_scores: list
+        total_indices: list
+
+from . import _lib
+
+METRIC_INNER_PRODUCT = 0  # faiss.METRIC_INNER_PRODUCT
+METRIC_L2 = 1  # faiss.METRIC_L2
+MAX_K = 128
+_MAGIC = b"MQFLAT01"
+_UPLOAD_ROWS = 1 << 16  # rows per host->device staging copy (multiple of 64)
+_QUERY_CHUNK = 1 << 14
+
+
+def parse_string_factory(string_factory):
+    """Returns do_l2norm for the factories the reference ships; raises for anything else.
+
+    "Flat" -> IndexFlat; "L2norm,Flat" -> IndexPreTransform(NormalizationTransform(d, 2), IndexFlat)
+    (FAISS index_factory grammar).  Approximate indexes (IVF/PQ/HNSW ...) are not exact search and
+    are not provided."""
+    if string_factory is None:
+        return False
+    parts = [p.strip() for p in string_factory.split(",") if p.strip()]
+    l2norm = False
+    for p in parts[:-1]:
+        if p == "L2norm":
+            l2norm = True
+        else:
+            raise ValueError(f"Unsupported FAISS factory component '{p}' in '{string_factory}' "
+                             "(MI355XFlatIndex provides exact 'Flat' and 'L2norm,Flat')")
+    if not parts or parts[-1] != "Flat":
+        raise ValueError(f"Unsupported FAISS factory '{string_factory}' "
+                         "(MI355XFlatIndex provides exact 'Flat' and 'L2norm,Flat')")
+    return l2norm
+
+
+def _resolve_device(device):
+    """HF convention (datasets/search.py:315-347): None -> default device, int >= 0 -> that GPU.
+    The reference's shipped configs all say ``"device": null`` (CPU FAISS); here that means "the
+    GPU of this process" (LOCAL_RANK-aware) because there is no CPU path."""
+    import torch
+    _lib.require_gpu()
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    if isinstance(device, int):
+        if device < 0:
+            raise TypeError("device=-1 (all GPUs) is served by viquae_amd.sharded.ShardedFlatIndex "
+                            "(one process per GPU); MI355XFlatIndex is a single-GPU shard")
+        return torch.device("cuda", device)
+    if isinstance(device, (list, tuple)):
+        if len(device) == 1:
+            return torch.device("cuda", int(device[0]))
+        raise TypeError("a device list is served by viquae_amd.sharded.ShardedFlatIndex (one process per GPU)")
+    if isinstance(device, torch.device):
+        return device
+    raise TypeError(f"The argument type: {type(device)} is not expected. "
+                    "Please pass in either nothing, a positive int, a negative int, or a list of positive ints.")
+
+
+class MI355XFlatIndex(BaseIndex):
+    """Exact IP / L2 index over an fp32 matrix held in HBM in the kernel's panel layout."""
+
+    def __init__(self, device: Optional[Union[int, list]] = None, string_factory: Optional[str] = None,
+                 metric_type: Optional[int] = None, custom_index=None, id_offset: int = 0):
+        if custom_index is not None:
+            raise ValueError("custom_index is a FAISS object; MI355XFlatIndex builds its own index")
+        self.device = device
+        self.string_factory = string_factory
+        # FAISS: IndexFlat(d) and index_factory(d, "Flat") default to METRIC_L2 when no metric is given
+        self.metric_type = METRIC_L2 if metric_type is None else int(metric_type)
+        if self.metric_type not in (METRIC_INNER_PRODUCT, METRIC_L2):
+            raise ValueError(f"Unsupported metric_type {metric_type} (0 = inner product, 1 = L2)")
+        self.do_l2norm = parse_string_factory(string_factory)
+        self.id_offset = int(id_offset)
+        self.ntotal = 0
+        self.d = None
+        self._packed = None  # torch.float32 [padded_rows * padded_dim]
+        self._sqnorm = None  # torch.float32 [padded_rows]
+        self._capacity = 0
+        self._ws = None
+        self._torch_device = None
+
+    # ------------------------------------------------------------------ construction
+    def _ensure_capacity(self, n_total, d):
+        import torch
+        lib = _lib.load()
+        if self._torch_device is None:
+            self._torch_device = _resolve_device(self.device)
+        if self.d is None:
+            self.d = int(d)
+        elif self.d != int(d):
+            raise ValueError(f"dimension mismatch: index has d={self.d}, got {d}")
+        cap = int(lib.mq_padded_rows(n_total))
+        if cap <= self._capacity:
+            return
+        # grow geometrically when appending repeatedly; exact when the total is known up front
+        dpad = int(lib.mq_padded_dim(self.d))
+        new_packed = torch.zeros(cap * dpad, dtype=torch.float32, device=self._torch_device)
+        new_sqnorm = torch.zeros(cap, dtype=torch.float32, device=self._torch_device)
+        if self._packed is not None and self.ntotal > 0:
+            # panels are contiguous: the old buffer is a prefix of the new one
+            new_packed[: self._packed.numel()].copy_(self._packed)
+            new_sqnorm[: self._sqnorm.numel()].copy_(self._sqnorm)
+        self._packed, self._sqnorm, self._capacity = new_packed, new_sqnorm, cap
+
+    def add(self, vecs, total_hint: Optional[int] = None):
+        """Append rows (numpy [n,d] or a CUDA torch tensor). Rows already appended must be a
+        multiple of 64 unless this is the first call after them (the C ABI packs whole panels)."""
+        import torch
+        lib = _lib.load()
+        if isinstance(vecs, torch.Tensor):
+            if vecs.dim() != 2:
+                raise ValueError("expected a 2-D matrix of vectors")
+            n, d = vecs.shape
+        else:
+            vecs = np.asarray(vecs, dtype=np.float32)
+            if vecs.ndim != 2:
+                raise ValueError("expected a 2-D matrix of vectors")
+            n, d = vecs.shape
+        if n == 0:
+            return
+        if self.ntotal % 64 != 0:
+            raise ValueError("MI355XFlatIndex.add: previous adds must total a multiple of 64 rows "
+                             "(add_vectors batches accordingly)")
+        self._ensure_capacity(max(self.ntotal + n, total_hint or 0), d)
+        stream = torch.cuda.current_stream(self._torch_device).cuda_stream
+        with torch.cuda.device(self._torch_device):
+            for i in range(0, n, _UPLOAD_ROWS):
+                part = vecs[i:i + _UPLOAD_ROWS]
+                if isinstance(part, torch.Tensor):
+                    dev = part.to(device=self._torch_device, dtype=torch.float32).contiguous()
+                else:
+                    dev = torch.from_numpy(np.ascontiguousarray(part)).to(self._torch_device, non_blocking=False)
+                _lib.check(lib.mq_pack_rows_f32(dev.data_ptr(), dev.shape[0], self.d, self.ntotal, int(self.do_l2norm),
+                                                self._packed.data_ptr(), self._capacity, self._sqnorm.data_ptr(),
+                                                stream), "mq_pack_rows_f32")
+                self.ntotal += dev.shape[0]
+                # `dev` must outlive the kernel: synchronise before it is released
+                torch.cuda.current_stream(self._torch_device).synchronize()
+
+    def add_vectors(self, vectors, column: Optional[str] = None, batch_size: int = 1000,
+                    train_size: Optional[int] = None, faiss_verbose: Optional[bool] = None):
+        """Same signature as FaissIndex.add_vectors (datasets/search.py:255-313).
+
+        ``vectors`` is a numpy matrix or a ``datasets.Dataset`` (then ``column`` names a
+        ``list<float>`` column).  The reference walks the dataset 1000 rows at a time through
+        Python lists; here the Arrow column is viewed as one contiguous fp32 buffer per chunk.
+        ``batch_size`` / ``train_size`` / ``faiss_verbose`` are accepted for compatibility (a Flat
+        index needs no training)."""
+        if column is None:
+            mat = np.asarray(vectors, dtype=np.float32)
+            if mat.ndim != 2:
+                raise ValueError("expected a 2-D matrix of vectors")
+            self.add(mat, total_hint=self.ntotal + mat.shape[0])
+            return
+        n_total = len(vectors)
+        added = 0
+        for block in iter_arrow_column(vectors, column):
+            # keep every add but the last a multiple of 64 rows
+            self._pending = block if getattr(self, "_pending", None) is None else np.concatenate([self._pending, block])
+            full = (self._pending.shape[0] // 64) * 64
+            if full:
+                self.add(self._pending[:full], total_hint=self.ntotal - added + n_total)
+                added += full
+                self._pending = self._pending[full:]
+        if getattr(self, "_pending", None) is not None and self._pending.shape[0]:
+            self.add(self._pending, total_hint=self.ntotal - added + n_total)
+        self._pending = None
+
+    # ------------------------------------------------------------------ search
+    def _workspace(self, nbytes):
+        import torch
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self._torch_device)
+        return self._ws
+
+    def search_device(self, queries, k):
+        """queries: CUDA float32 [nq,d] tensor on this index's device -> (D [nq,k] f32, I [nq,k] i64)
+        CUDA tensors.  This is the raw hot path: one mq_knn_search_f32 call per <=16384 queries."""
+        import torch
+        lib = _lib.load()
+        if self._packed is None:
+            raise ValueError("the index is empty: call add_vectors first")
+        if queries.dim() != 2 or queries.shape[1] != self.d:
+            raise ValueError(f"Shape of query must be 2D with {self.d} columns, got {tuple(queries.shape)}")
+        if k < 1:
+            raise ValueError("k must be >= 1")
+        if k > MAX_K:
+            raise NotImplementedError(f"k={k} > {MAX_K}: the fused MI355X scan keeps at most {MAX_K} neighbours "
+                                      "(the reference uses k=100)")
+        nq = queries.shape[0]
+        queries = queries.to(dtype=torch.float32).contiguous()
+        D = torch.empty((nq, k), dtype=torch.float32, device=self._torch_device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=self._torch_device)
+        stream = torch.cuda.current_stream(self._torch_device).cuda_stream
+        with torch.cuda.device(self._torch_device):
+            for s in range(0, nq, _QUERY_CHUNK):
+                q = queries[s:s + _QUERY_CHUNK]
+                nb = int(lib.mq_knn_workspace_bytes(self.ntotal, self.d, q.shape[0], k))
+                ws = self._workspace(nb)
+                _lib.check(lib.mq_knn_search_f32(self._packed.data_ptr(), self._sqnorm.data_ptr(), self.ntotal, self.d,
+                                                 q.data_ptr(), q.shape[0], k, self.metric_type, int(self.do_l2norm),
+                                                 self.id_offset, D[s:s + _QUERY_CHUNK].data_ptr(),
+                                                 I[s:s + _QUERY_CHUNK].data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                           "mq_knn_search_f32")
+        return D, I
+
+    def search_batch(self, queries, k: int = 10, **kwargs) -> BatchedSearchResults:
+        """FaissIndex.search_batch (datasets/search.py:369-385): numpy [nq,d] -> (scores f32 [nq,k],
+        indices int [nq,k]), best first, -1 for unfilled slots."""
+        import torch
+        queries = np.asarray(queries)
+        if len(queries.shape) != 2:
+            raise ValueError("Shape of query must be 2D")
+        if self._torch_device is None:
+            self._torch_device = _resolve_device(self.device)
+        q = torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32)).to(self._torch_device)
+        D, I = self.search_device(q, k)
+        torch.cuda.current_stream(self._torch_device).synchronize()
+        return BatchedSearchResults(D.cpu().numpy(), I.cpu().numpy().astype(int))
+
+    def search(self, query, k: int = 10, **kwargs) -> SearchResults:
+        """FaissIndex.search (datasets/search.py:349-367)."""
+        query = np.asarray(query)
+        if len(query.shape) != 1 and (len(query.shape) != 2 or query.shape[0] != 1):
+            raise ValueError("Shape of query is incorrect, it has to be either a 1D array or 2D (1, N)")
+        scores, indices = self.search_batch(query.reshape(1, -1), k)
+        return SearchResults(scores[0], indices[0].astype(int))
+
+    # ------------------------------------------------------------------ persistence
+    def reconstruct_n(self, start=0, n=None):
+        """Stored rows (after any L2norm transform) as numpy [n,d]."""
+        import torch
+        lib = _lib.load()
+        n = self.ntotal - start if n is None else n
+        out = torch.empty((n, self.d), dtype=torch.float32, device=self._torch_device)
+        stream = torch.cuda.current_stream(self._torch_device).cuda_stream
+        with torch.cuda.device(self._torch_device):
+            _lib.check(lib.mq_unpack_rows_f32(self._packed.data_ptr(), self._capacity, self.d, start, n, out.data_ptr(),
+                                              stream), "mq_unpack_rows_f32")
+        torch.cuda.current_stream(self._torch_device).synchronize()
+        return out.cpu().numpy()
+
+    def save(self, file: Union[str, PurePath], storage_options: Optional[dict] = None):
+        """FaissIndex.save (datasets/search.py:387-397).  Format: 8-byte magic, int64 N, int32 d,
+        int32 metric, int32 l2norm, int32 reserved, then N*d fp32 row-major (rows as stored)."""
+        rows = self.reconstruct_n() if self.ntotal else np.zeros((0, self.d or 0), np.float32)
+        with open(os.fspath(file), "wb") as f:
+            f.write(_MAGIC)
+            f.write(struct.pack("<qiiii", self.ntotal, self.d or 0, self.metric_type, int(self.do_l2norm), 0))
+            f.write(rows.tobytes())
+
+    @classmethod
+    def load(cls, file: Union[str, PurePath], device=None, storage_options: Optional[dict] = None):
+        """FaissIndex.load (datasets/search.py:399-416)."""
+        with open(os.fspath(file), "rb") as f:
+            if f.read(8) != _MAGIC:
+                raise ValueError(f"{file} is not an MI355XFlatIndex file")
+            n, d, metric, l2norm, _ = struct.unpack("<qiiii", f.read(24))
+            rows = np.frombuffer(f.read(n * d * 4), dtype=np.float32).reshape(n, d)
+        idx = cls(device=device, string_factory="L2norm,Flat" if l2norm else "Flat", metric_type=metric)
+        if n:
+            # rows were stored after normalisation: do not normalise twice on load
+            idx.do_l2norm = False
+            idx.add(rows, total_hint=n)
+            idx.do_l2norm = bool(l2norm)
+        else:
+            idx.d = d or None
+        return idx
+
+
+def iter_arrow_column(dataset, column):
+    """Yields numpy [rows,d] fp32 blocks of a ``list<float>`` column without going through Python
+    lists (the reference's add loop: datasets/search.py:311-313 -> list -> ndarray)."""
+    import pyarrow as pa
+    table = getattr(dataset, "data", None)
+    indices = getattr(dataset, "_indices", None)
+    if table is None or indices is not None:
+        # selected/shuffled dataset: fall back to formatted access, still batched
+        ds = dataset.with_format("numpy", columns=[column])
+        for i in range(0, len(ds), 1 << 15):
+            block = ds[i:i + (1 << 15)][column]
+            yield np.ascontiguousarray(np.stack(block) if isinstance(block, list) else block, dtype=np.float32)
+        return
+    col = table.column(column)
+    for chunk in col.chunks:
+        if len(chunk) == 0:
+            continue
+        if pa.types.is_fixed_size_list(chunk.type):
+            d = chunk.type.list_size
+            flat = chunk.flatten()
+        else:
+            offsets = chunk.offsets.to_numpy()
+            d = int(offsets[1] - offsets[0])
+            if not np.all(np.diff(offsets) == d):
+                raise ValueError(f"column '{column}' holds vectors of different lengths")
+            flat = chunk.flatten()
+        if chunk.null_count:
+            raise ValueError(f"column '{column}' holds null vectors: cannot be indexed")
+        arr = flat.to_numpy(zero_copy_only=False)
+        yield np.ascontiguousarray(arr.reshape(len(chunk), d), dtype=np.float32)
