@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): exact inner-product top-100 of 4096 fp32 queries against a
+synthetic 1.5M x 768 fp32 KB resident in HBM (panel layout), on ONE MI355X.  A "step" is one
+mq_knn_search_f32 call (query pack + fused scan/top-k + slab merge) over the whole batch; inputs
+are already in HBM when the timed region starts, D/I are written to HBM inside it.
+
+N > 1 (BASELINE configs[4] shape): the KB is row-sharded, one 1.5M-row
+shard per rank (weak scaling: per-GPU work fixed), queries replicated; each step = local scan +
+one RCCL all-gather of the per-shard [nq,100] lists + merge on every rank.  `value` counts the
+units all ranks processed: one unit = one query's exact top-100 over one 1.5M x 768 shard (the
+BASELINE metric's unit), so value = N * nq * K / t; the end-to-end rate of finished queries over
+the N x 1.5M KB is reported next to it as `global_queries_per_s`.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+KB_ROWS = 1_500_000
+DIM = 768
+NQ = 4096
+TOPK = 100
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=KB_ROWS, help="KB rows per GPU (default: BASELINE size)")
+    ap.add_argument("--nq", type=int, default=NQ)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
+    return ap.parse_args()
+
+
+def build_shard(idx, rows, seed, device):
+    """Synthetic shard generated ON DEVICE (Philox, per-shard seed) and packed batch by batch."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    step = 1 << 16
+    for s in range(0, rows, step):
+        n = min(step, rows - s)
+        idx.add(torch.randn((n, DIM), generator=g, device=device, dtype=torch.float32), total_hint=rows)
+
+
+def cpu_baseline(idx, Q, seconds):
+    """Times the CPU oracle (oracle/knn_oracle.c, OpenMP over 32-query blocks) on a bounded sample of
+    the same workload: ALL queries of the step (so every host core has a block) against the first
+    `rows_s` KB rows, sized by a calibration run for ~`seconds` of CPU work, then scaled by rows to
+    the metric's unit (queries/s over the full 1.5M x 768 KB)."""
+    from oracle import knn as ok
+    threads = ok.num_threads()
+    Qh = Q.cpu().numpy()
+    nq = Qh.shape[0]
+    cal_rows = min(idx.ntotal, 4096)
+    X = idx.reconstruct_n(0, cal_rows)
+    ok.knn(X[:256], Qh, TOPK, metric=0)  # warm the thread pool
+    t0 = time.perf_counter()
+    ok.knn(X, Qh, TOPK, metric=0)
+    tc = time.perf_counter() - t0
+    rows_s = int(min(idx.ntotal, max(cal_rows, cal_rows * seconds / max(tc, 1e-4))))
+    X = idx.reconstruct_n(0, rows_s)
+    t0 = time.perf_counter()
+    ok.knn(X, Qh, TOPK, metric=0)
+    t = time.perf_counter() - t0
+    value = (nq / t) * rows_s / idx.ntotal  # the same queries against the full KB cost ntotal/rows_s more
+    return {
+        "value": round(value, 2), "unit": "queries/s", "cores": threads, "kind": "port",
+        "sample": f"oracle/knn_oracle.c (fmaf-chain restatement of FAISS IndexFlatIP, OpenMP x{threads}) on {nq} queries x "
+                  f"the first {rows_s} KB rows, top-{TOPK}: {t:.2f} s ({2.0 * nq * rows_s * DIM / t / 1e9:.0f} GFLOP/s); "
+                  f"scaled by rows to {idx.ntotal} x {DIM}",
+    }
+
+
+def load_traffic(workload_key):
+    """HBM bytes per scan launch from a committed rocprofv3 --pmc pass (profiles/knn_traffic.json)."""
+    p = os.path.join(ROOT, "profiles", "knn_traffic.json")
+    try:
+        with open(p) as f:
+            t = json.load(f)
+        return t.get(workload_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from viquae_amd import _lib
+    from viquae_amd.index import MI355XFlatIndex
+    from viquae_amd.sharded import ShardedFlatIndex
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: viquae_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    lib = _lib.load()
+
+    rows, nq, k = args.rows, args.nq, TOPK
+    local = MI355XFlatIndex(device=local_rank, string_factory="Flat", metric_type=0, id_offset=rank * rows)
+    build_shard(local, rows, seed=rank, device=device)
+    index = ShardedFlatIndex(string_factory="Flat", metric_type=0, local_index=local) if world > 1 else None
+    if index is not None:
+        index.ntotal = rows * world
+    g = torch.Generator(device=device)
+    g.manual_seed(100)
+    Q = torch.randn((nq, DIM), generator=g, device=device, dtype=torch.float32)  # same on every rank
+
+    stream = torch.cuda.current_stream(device)
+    ws_bytes = int(lib.mq_knn_workspace_bytes(rows, DIM, nq, k))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    D = torch.empty((nq, k), dtype=torch.float32, device=device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=device)
+
+    def local_step(ev0=None, ev1=None):
+        _lib.check(lib.mq_knn_search_f32_ev(local._packed.data_ptr(), local._sqnorm.data_ptr(), rows, DIM, Q.data_ptr(),
+                                            nq, k, 0, 0, local.id_offset, D.data_ptr(), I.data_ptr(), ws.data_ptr(),
+                                            ws_bytes, stream.cuda_stream,
+                                            ev0.cuda_event if ev0 is not None else None,
+                                            ev1.cuda_event if ev1 is not None else None), "mq_knn_search_f32_ev")
+        return D, I
+
+    def step(ev0=None, ev1=None):
+        Dl, Il = local_step(ev0, ev1)
+        if world == 1:
+            return Dl, Il
+        Ds = torch.empty((world, nq, k), dtype=Dl.dtype, device=device)
+        Is = torch.empty((world, nq, k), dtype=Il.dtype, device=device)
+        dist.all_gather_into_tensor(Ds, Dl)
+        dist.all_gather_into_tensor(Is, Il)
+        return index.merge_fn(Ds, Is, 0)
+
+    for _ in range(args.warmup):
+        step()
+    # HIP events that bracket the scan kernel on the stream it is launched on (created by a first record)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in evs:
+        a.record(stream)
+        b.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(*evs[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    scan_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        units = world * nq * args.steps
+        value = units / elapsed
+        flops = 2.0 * nq * rows * DIM  # algorithmic FLOPs of one scan launch (2.304 GFLOP/query)
+        achieved = flops / (scan_ms * 1e-3) / 1e12
+        info = (ctypes_i64 * 6)()
+        lib.mq_knn_launch_info(rows, DIM, nq, k, info)
+        workload = f"{rows}x{DIM} fp32 KB per GPU, {nq} queries, exact IP top-{k}"
+        rec = {
+            "metric": "queries/sec exact top-100 over 1.5M x 768 KB",
+            "value": round(value, 1),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (torch Philox randn generated on device, seed = shard rank; queries seed 100)",
+            "config": {
+                "workload": workload,
+                "kb_rows_total": rows * world,
+                "queries_per_step": nq,
+                "k": k,
+                "sharding": "single GPU" if world == 1 else f"row-sharded x{world}, RCCL all-gather of per-shard top-{k} + merge",
+                "unit_definition": "one query's exact top-100 over one 1.5M x 768 shard",
+                "global_queries_per_s": round(nq * args.steps / elapsed, 1),
+                "scan_launch": {"workgroups": int(info[0]), "threads": int(info[1]), "lds_bytes": int(info[2]),
+                                "query_tiles": int(info[3]), "kb_slabs": int(info[4]), "kb_chunks": int(info[5])},
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "knn_scan_kernel<IP> (v_mfma_f32_32x32x2_f32)",
+                "achieved": round(achieved, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                "kernel_ms": round(scan_ms, 3),
+                "algorithmic_flops_per_launch": flops,
+                "algorithmic_hbm_bytes_per_launch": rows * DIM * 4,
+                "hbm_frac_at_one_pass": round(rows * DIM * 4 / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                "traffic": load_traffic(f"{rows}x{DIM}_nq{nq}_k{k}"),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                rec["cpu_baseline"] = cpu_baseline(local, Q, args.cpu_seconds)
+            except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
+                rec["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+import ctypes  # noqa: E402
+
+ctypes_i64 = ctypes.c_int64
+
+if __name__ == "__main__":
+    main()

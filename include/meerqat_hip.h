@@ -81,6 +81,14 @@ int mq_knn_search_f32(const float *packed_dev, const float *sqnorm_dev, int64_t 
                       int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float *D_dev,
                       int64_t *I_dev, void *ws_dev, size_t ws_bytes, void *stream);
 
+/* Same call; additionally records the caller's hipEvent_t handles (may be NULL) on `stream`
+ * immediately before and after the scan kernel (knn_scan_kernel), so that a benchmark can time the
+ * dominant kernel on the stream it is launched on. */
+int mq_knn_search_f32_ev(const float *packed_dev, const float *sqnorm_dev, int64_t N, int d, const float *queries_dev,
+                         int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float *D_dev,
+                         int64_t *I_dev, void *ws_dev, size_t ws_bytes, void *stream, void *ev_scan_begin,
+                         void *ev_scan_end);
+
 /* Name and launch geometry of the scan kernel for the given problem (for bench.py / profiles):
  * out[0]=workgroups, out[1]=threads per workgroup, out[2]=LDS bytes, out[3]=query tiles,
  * out[4]=KB slabs, out[5]=KB chunks (256 rows each). */

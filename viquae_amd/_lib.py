@@ -29,6 +29,8 @@ SIGNATURES = {
     "mq_knn_workspace_bytes": (c_sz, [c_i64, c_int, c_int, c_int]),
     "mq_knn_search_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_int, c_int, c_i64,
                                   c_ptr, c_ptr, c_ptr, c_sz, c_ptr]),
+    "mq_knn_search_f32_ev": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_int, c_int, c_i64,
+                                     c_ptr, c_ptr, c_ptr, c_sz, c_ptr, c_ptr, c_ptr]),
     "mq_knn_launch_info": (c_int, [c_i64, c_int, c_int, c_int, ctypes.POINTER(c_i64)]),
     "mq_topk_merge_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
 }

@@ -656,9 +656,9 @@ int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[6]) {
     return MQ_OK;
 }
 
-int mq_knn_search_f32(const float* packed_dev, const float* sqnorm_dev, int64_t N, int d, const float* queries_dev,
-                      int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev,
-                      void* ws_dev, size_t ws_bytes, void* stream) {
+static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int64_t N, int d, const float* queries_dev,
+                           int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev,
+                           void* ws_dev, size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
     if (nq == 0) return MQ_OK;
     if (!packed_dev || !sqnorm_dev || !queries_dev || !D_dev || !I_dev || !ws_dev) return MQ_EINVAL;
     if (N < 0 || d <= 0 || nq < 0 || k <= 0 || (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2)) return MQ_EINVAL;
@@ -686,6 +686,7 @@ int mq_knn_search_f32(const float* packed_dev, const float* sqnorm_dev, int64_t 
         a.Xp = packed_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = lists;
         a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks;
         const dim3 grid((unsigned)(g.nqt * g.S)), block(1024);
+        if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
         if (metric == MQ_METRIC_IP) {
             MQ_HIP(hipFuncSetAttribute((const void*)knn_scan_kernel<MQ_METRIC_IP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
             hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_IP>, grid, block, LDS_TOTAL, st, a);
@@ -694,6 +695,7 @@ int mq_knn_search_f32(const float* packed_dev, const float* sqnorm_dev, int64_t 
             hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_L2>, grid, block, LDS_TOTAL, st, a);
         }
         MQ_HIP(hipGetLastError());
+        if (ev_scan_end) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_end, st));
     } else {
         MQ_HIP(hipMemsetAsync(lists, 0, (size_t)g.nqt * g.S * TQ * (size_t)k * 8, st));
     }
@@ -705,6 +707,20 @@ int mq_knn_search_f32(const float* packed_dev, const float* sqnorm_dev, int64_t 
                            (long long)id_offset, D_dev, (long long*)I_dev);
     MQ_HIP(hipGetLastError());
     return MQ_OK;
+}
+
+int mq_knn_search_f32(const float* packed_dev, const float* sqnorm_dev, int64_t N, int d, const float* queries_dev,
+                      int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev,
+                      void* ws_dev, size_t ws_bytes, void* stream) {
+    return knn_search_impl(packed_dev, sqnorm_dev, N, d, queries_dev, nq, k, metric, l2norm_queries, id_offset, D_dev,
+                           I_dev, ws_dev, ws_bytes, stream, nullptr, nullptr);
+}
+
+int mq_knn_search_f32_ev(const float* packed_dev, const float* sqnorm_dev, int64_t N, int d, const float* queries_dev,
+                         int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev,
+                         void* ws_dev, size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
+    return knn_search_impl(packed_dev, sqnorm_dev, N, d, queries_dev, nq, k, metric, l2norm_queries, id_offset, D_dev,
+                           I_dev, ws_dev, ws_bytes, stream, ev_scan_begin, ev_scan_end);
 }
 
 int mq_topk_merge_f32(const float* Ds_dev, const int64_t* Is_dev, int nshards, int nq, int k, int metric, float* D_dev,
