@@ -146,11 +146,11 @@ def main():
         Dl, Il = local_step(ev0, ev1)
         if world == 1:
             return Dl, Il
-        Ds = torch.empty((world, nq, k), dtype=Dl.dtype, device=device)
-        Is = torch.empty((world, nq, k), dtype=Il.dtype, device=device)
+        Ds = torch.empty((world * nq, k), dtype=Dl.dtype, device=device)
+        Is = torch.empty((world * nq, k), dtype=Il.dtype, device=device)
         dist.all_gather_into_tensor(Ds, Dl)
         dist.all_gather_into_tensor(Is, Il)
-        return index.merge_fn(Ds, Is, 0)
+        return index.merge_fn(Ds.view(world, nq, k), Is.view(world, nq, k), 0)
 
     for _ in range(args.warmup):
         step()

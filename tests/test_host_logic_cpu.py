@@ -1,0 +1,155 @@
+"""CPU suite: host-side mirror of meerqat.ir.search (no GPU: a test-only index object backed by the
+oracle is registered in place of the HIP index, exactly where MI355XFlatIndex would sit)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import knn as ok
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _oracle_index(X, metric, l2norm=False):
+    from datasets.search import BaseIndex, BatchedSearchResults
+
+    class OracleIndex(BaseIndex):
+        def search_batch(self, queries, k=10, **kw):
+            if len(np.shape(queries)) != 2:
+                raise ValueError("Shape of query must be 2D")
+            D, I = ok.knn(X, queries, k, metric=metric, l2norm=l2norm)
+            return BatchedSearchResults(D, I.astype(int))
+
+    return OracleIndex()
+
+
+def _kb(X, metric=0, l2norm=False):
+    import datasets
+    from viquae_amd.ir.search import Index, KnowledgeBase, register_index
+    ds = datasets.Dataset.from_dict({"vec": [r for r in X]})
+    kb = KnowledgeBase(dataset=ds)
+    register_index(kb.dataset, "idx", _oracle_index(X, metric, l2norm))
+    kb.indexes["idx"] = Index(key="q", do_L2norm=l2norm)
+    return kb
+
+
+def test_L2norm_matches_reference_definition():
+    from viquae_amd.ir.search import L2norm
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal((4, 9)).astype(np.float32)
+    assert np.array_equal(L2norm(q), q / np.linalg.norm(q, axis=1, keepdims=True))
+    with np.errstate(invalid="ignore"):
+        assert np.isnan(L2norm(np.zeros((1, 3), np.float32))).all()
+
+
+def test_search_batch_golden_plumbing():
+    z = np.load(os.path.join(GOLDEN, "knn_random.npz"))
+    X, Q = z["X"], z["Q"]
+    kb = _kb(X)
+    D, I = kb.search_batch("idx", [list(map(float, q)) for q in Q], k=10)
+    assert D.dtype == np.float32 and np.array_equal(I, z["I_m0_k10"]) and np.array_equal(D, z["D_m0_k10"])
+    kb = _kb(X, l2norm=True)  # host L2norm on queries (do_L2norm) + the index's own transform
+    D, I = kb.search_batch("idx", Q, k=10)
+    assert np.array_equal(I, z["I_l2norm_m0_k10"]) and np.array_equal(D, z["D_l2norm_m0_k10"])
+
+
+def test_search_batch_if_not_None_golden():
+    z = np.load(os.path.join(GOLDEN, "knn_random.npz"))
+    X, Q, mask = z["X"], z["Q"], z["none_mask"]
+    kb = _kb(X)
+    queries = [Q[i] if mask[i] else None for i in range(len(Q))]
+    S, Ix = kb.search_batch_if_not_None("idx", queries, k=10)
+    assert len(S) == len(Q)
+    got_D = np.stack([s for s, m in zip(S, mask) if m])
+    got_I = np.stack([s for s, m in zip(Ix, mask) if m])
+    assert np.array_equal(got_I, z["I_none_m0_k10"]) and np.array_equal(got_D, z["D_none_m0_k10"])
+    assert all(len(s) == 0 and len(i) == 0 for s, i, m in zip(S, Ix, mask) if not m)
+    S, Ix = kb.search_batch_if_not_None("idx", [None, None], k=3)
+    assert S == [[], []] and Ix == [[], []]
+
+
+def test_dataset_api_sees_registered_index():
+    X = np.random.default_rng(1).standard_normal((50, 8)).astype(np.float32)
+    kb = _kb(X, metric=1)
+    assert kb.dataset.list_indexes() == ["idx"]
+    res = kb.dataset.search_batch("idx", X[:2], k=3)
+    assert np.array_equal(np.asarray(res.total_indices)[:, 0], [0, 1])
+    from datasets.search import MissingIndex
+    with pytest.raises(MissingIndex):
+        kb.dataset.search_batch("nope", X[:2], k=3)
+
+
+def test_string_factory_and_metric_parsing():
+    from viquae_amd.index import MI355XFlatIndex, parse_string_factory
+    assert parse_string_factory(None) is False and parse_string_factory("Flat") is False
+    assert parse_string_factory("L2norm,Flat") is True
+    for bad in ("IVF4096,Flat", "HNSW32", "L2norm,PQ16", "PCA64,Flat"):
+        with pytest.raises(ValueError):
+            parse_string_factory(bad)
+    assert MI355XFlatIndex(string_factory="Flat").metric_type == 1  # FAISS default metric is L2
+    assert MI355XFlatIndex(metric_type=0).metric_type == 0
+    with pytest.raises(ValueError):
+        MI355XFlatIndex(metric_type=7)
+    with pytest.raises(ValueError):
+        MI355XFlatIndex(custom_index=object())
+
+
+def test_index_kwargs_accept_legacy_keys_and_reject_sparse_kinds(monkeypatch):
+    """Every shipped experiments/ir/**/config.json carries es/kind_str/normalization/interpolation_weight."""
+    import datasets
+    from viquae_amd.ir import search as S
+    made = {}
+
+    class FakeIndex:
+        def __init__(self, device=None, string_factory=None, metric_type=None):
+            made.update(device=device, string_factory=string_factory, metric_type=metric_type)
+
+        def add_vectors(self, ds, column=None, **kw):
+            made["column"] = column
+
+    monkeypatch.setattr(S, "MI355XFlatIndex", FakeIndex)
+    ds = datasets.Dataset.from_dict({"DPR_few_shot": [[0.0, 1.0]]})
+    kw = {"column": "DPR_few_shot", "es": False, "kind_str": "TEXT", "key": "DPR_few_shot",
+          "normalization": {"method": "normalize", "mean": 71.3295, "std": 2.16671}, "string_factory": "Flat",
+          "load": False, "device": None, "metric_type": 0}  # experiments/ir/viquae/dpr/search/config.json:5-19
+    kb = S.KnowledgeBase(dataset=ds, index_kwargs={"DPR_few_shot_dp": kw})
+    assert made == {"device": None, "string_factory": "Flat", "metric_type": 0, "column": "DPR_few_shot"}
+    assert kb.indexes["DPR_few_shot_dp"].key == "DPR_few_shot" and not kb.indexes["DPR_few_shot_dp"].do_L2norm
+    assert "DPR_few_shot_dp" in kb.dataset.list_indexes()
+    with pytest.raises(NotImplementedError):
+        kb.add_or_load_index(column="x", kind="ES")
+    with pytest.raises(KeyError):
+        kb.add_or_load_index(column="x", kind="NOPE")
+
+
+def test_shard_bounds_cover_rows_once():
+    from viquae_amd.sharded import shard_bounds
+    for n in (0, 1, 63, 64, 1000, 1_500_000, 12_000_001):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert all(lo % 64 == 0 for lo, hi in spans if hi > lo)
+
+
+def test_iter_arrow_column_zero_copy_blocks():
+    import datasets
+    from viquae_amd.index import iter_arrow_column
+    X = np.random.default_rng(2).standard_normal((1000, 12)).astype(np.float32)
+    ds = datasets.Dataset.from_dict({"v": [r for r in X], "t": [str(i) for i in range(1000)]})
+    got = np.concatenate(list(iter_arrow_column(ds, "v")))
+    assert got.dtype == np.float32 and np.array_equal(got, X)
+    sel = ds.select([5, 3, 999])
+    got = np.concatenate(list(iter_arrow_column(sel, "v")))
+    assert np.array_equal(got, X[[5, 3, 999]])
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from viquae_amd._lib import MeerqatHipError
+    from viquae_amd.index import MI355XFlatIndex
+    idx = MI355XFlatIndex(string_factory="Flat", metric_type=0)
+    with pytest.raises(MeerqatHipError):
+        idx.add_vectors(np.zeros((4, 8), np.float32))

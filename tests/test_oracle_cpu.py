@@ -1,0 +1,125 @@
+"""CPU suite: the oracle against the committed golden vectors (minted by running the reference's own
+KnowledgeBase, tools/make_golden.py) and against independent computations."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import knn as ok
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    z = np.load(os.path.join(GOLDEN, f"knn_{name}.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def _cases(g):
+    for key in g:
+        if key.startswith("I_") and not key.startswith("I_none"):
+            tag = key[2:]
+            l2 = tag.startswith("l2norm_")
+            parts = tag.replace("l2norm_", "").split("_")
+            yield tag, l2, int(parts[0][1:]), int(parts[1][1:])
+
+
+@pytest.mark.parametrize("name", ["random", "small_nq", "lattice", "ties"])
+def test_oracle_reproduces_golden(name):
+    g = _load(name)
+    X, Q = g["X"].astype(np.float32), g["Q"].astype(np.float32)
+    n = 0
+    for tag, l2, metric, k in _cases(g):
+        Qin = Q
+        if l2:
+            # the reference normalises queries on the host (ir/search.py:144-145) before the index does it again
+            Qin = (Q / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float32)
+        D, I = ok.knn(X, Qin, k, metric=metric, l2norm=l2)
+        assert np.array_equal(I, g[f"I_{tag}"]), tag
+        assert np.array_equal(D, g[f"D_{tag}"]), tag
+        n += 1
+    assert n >= 2
+
+
+@pytest.mark.parametrize("name", ["lattice", "ties"])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_golden_lattice_is_order_independent(name, metric):
+    """On integer data every fp32 summation order is exact: the golden must equal a float64 brute force
+    and a torch.mm (BLAS order) brute force -- i.e. what FAISS IndexFlat returns with lower-id tie-break."""
+    import torch
+    g = _load(name)
+    X, Q = g["X"].astype(np.float32), g["Q"].astype(np.float32)
+    k = 100
+    D64, I64 = ok.knn_numpy_f64(X, Q, k, metric)
+    assert np.array_equal(g[f"I_m{metric}_k{k}"], I64)
+    S = (torch.from_numpy(Q) @ torch.from_numpy(X).T).numpy()
+    if metric == 1:
+        S = (Q ** 2).sum(1)[:, None] + (X ** 2).sum(1)[None, :] - 2 * S
+        order = np.lexsort((np.broadcast_to(np.arange(S.shape[1]), S.shape), S), axis=1)[:, :k]
+    else:
+        order = np.lexsort((np.broadcast_to(np.arange(S.shape[1]), S.shape), -S), axis=1)[:, :k]
+    assert np.array_equal(order, g[f"I_m{metric}_k{k}"])
+    assert np.array_equal(np.take_along_axis(S, order, 1), g[f"D_m{metric}_k{k}"])
+
+
+def test_free_form_golden_matches_float64_within_ties():
+    """Free-form fp32 data: two correct fp32 implementations may swap near-ties; every index mismatch vs
+    float64 must be such a near-tie (|score diff| tiny)."""
+    g = _load("random")
+    X, Q = g["X"], g["Q"]
+    D64, I64 = ok.knn_numpy_f64(X, Q, 100, 0)
+    I = g["I_m0_k100"]
+    S = Q.astype(np.float64) @ X.astype(np.float64).T
+    for q in np.nonzero((I != I64).any(1))[0]:
+        for a, b in zip(I[q], I64[q]):
+            if a != b:
+                assert abs(S[q, a] - S[q, b]) <= 2 ** -18 * max(1.0, abs(S[q, a]))
+
+
+def test_fma_chain_definition():
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((6, 41)).astype(np.float32)
+    Q = rng.standard_normal((4, 41)).astype(np.float32)
+    D, I = ok.knn(X, Q, 6)
+    S = ok.chain_scores_python(X, Q)
+    assert np.array_equal(np.take_along_axis(S, I, 1), D)
+
+
+def test_fewer_rows_than_k_and_empty():
+    X = np.eye(3, 8, dtype=np.float32)
+    Q = np.ones((2, 8), np.float32)
+    D, I = ok.knn(X, Q, 5)
+    assert (I[:, 3:] == -1).all() and np.isneginf(D[:, 3:]).all() and (I[:, :3] == [0, 1, 2]).all()
+    D, I = ok.knn(X, Q, 5, metric=1)
+    assert (I[:, 3:] == -1).all() and np.isposinf(D[:, 3:]).all()
+    D, I = ok.knn(np.zeros((0, 8), np.float32), Q, 2)
+    assert (I == -1).all()
+
+
+def test_nan_never_enters():
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((50, 8)).astype(np.float32)
+    X[7] = np.nan
+    Q = rng.standard_normal((3, 8)).astype(np.float32)
+    D, I = ok.knn(X, Q, 50)
+    assert 7 not in I and (I[:, -1] == -1).all()
+
+
+def test_merge_equals_unsharded():
+    rng = np.random.default_rng(2)
+    X = rng.integers(-3, 4, (900, 8)).astype(np.float32)
+    Q = rng.integers(-3, 4, (11, 8)).astype(np.float32)
+    for metric in (0, 1):
+        parts = [ok.knn(X[s:s + 300], Q, 40, metric=metric, id_offset=s) for s in range(0, 900, 300)]
+        Dm, Im = ok.topk_merge(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), metric)
+        D, I = ok.knn(X, Q, 40, metric=metric)
+        assert np.array_equal(Im, I) and np.array_equal(Dm, D)
+
+
+def test_l2norm_rows_close_to_numpy():
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((20, 33)).astype(np.float32)
+    a = ok.l2norm_rows(X)
+    b = X / np.linalg.norm(X, axis=1, keepdims=True)
+    assert np.allclose(a, b, rtol=0, atol=2e-7)
+    assert np.isnan(ok.l2norm_rows(np.zeros((1, 4), np.float32))).all()  # no epsilon, like the reference

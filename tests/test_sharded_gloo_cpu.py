@@ -1,0 +1,76 @@
+"""CPU suite: the N>1 path (row shards + all-gather + merge) with world_size 2 over gloo.  HIP kernels
+cannot run here, so the two injection points of ShardedFlatIndex (local index, merge function) are
+served by the oracle; what is exercised is the product's sharding arithmetic, id offsets, collective
+call and result assembly."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _OracleLocal:
+    """Stand-in for MI355XFlatIndex on a CPU rank (same attributes ShardedFlatIndex touches)."""
+
+    def __init__(self, metric):
+        self.metric, self.id_offset, self.rows, self._torch_device = metric, 0, None, "cpu"
+
+    def add(self, rows, total_hint=None):
+        rows = np.asarray(rows, np.float32)
+        self.rows = rows if self.rows is None else np.concatenate([self.rows, rows])
+
+    def search_device(self, q, k):
+        from oracle import knn as ok
+        X = self.rows if self.rows is not None else np.zeros((0, q.shape[1]), np.float32)
+        D, I = ok.knn(X, q.numpy(), k, metric=self.metric, id_offset=self.id_offset)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+
+def _oracle_merge(Ds, Is, metric):
+    from oracle import knn as ok
+    D, I = ok.topk_merge(Ds.numpy(), Is.numpy(), metric)
+    return torch.from_numpy(D), torch.from_numpy(I)
+
+
+def _worker(rank, world, port, metric, n, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from viquae_amd.sharded import ShardedFlatIndex, shard_bounds
+        rng = np.random.default_rng(42)
+        X = rng.integers(-4, 5, (n, 12)).astype(np.float32)
+        Q = rng.integers(-4, 5, (9, 12)).astype(np.float32)
+        idx = ShardedFlatIndex(string_factory="Flat", metric_type=metric, local_index=_OracleLocal(metric),
+                               merge_fn=_oracle_merge)
+        idx.add_vectors(X)
+        lo, hi = shard_bounds(n, world, rank)
+        assert idx.local.id_offset == lo and (idx.local.rows is None or len(idx.local.rows) == hi - lo)
+        D, I = idx.search_batch(Q, 20)
+        if rank == 0:
+            np.savez(out, D=D, I=I, X=X, Q=Q)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric,n", [(0, 1000), (1, 1000), (0, 70)])
+def test_world2_sharded_equals_unsharded(tmp_path, metric, n):
+    from oracle import knn as ok
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(2, _free_port(), metric, n, out), nprocs=2, join=True)
+    z = np.load(out)
+    D, I = ok.knn(z["X"], z["Q"], 20, metric=metric)
+    assert np.array_equal(z["I"], I) and np.array_equal(z["D"], D)

@@ -41,7 +41,8 @@ class MeerqatHipError(RuntimeError):
 
 
 def lib_path():
-    return _build.SO
+    # MEERQAT_HIP_LIB: load another build of the same C ABI (A/B benchmarking of kernel variants)
+    return os.environ.get("MEERQAT_HIP_LIB") or _build.SO
 
 
 def load():

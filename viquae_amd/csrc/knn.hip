@@ -20,11 +20,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/meerqat_hip.h"
 
 typedef unsigned long long u64;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Code placement of the MFMA loop moves kernel time by +-4.5 % between 4-byte phases (measured,
+// profiles/r01_notes.md); MQ_PAD_NOPS shifts it.  Re-tune with tools/tune_placement.sh after edits.
+#ifndef MQ_PAD_NOPS
+#define MQ_PAD_NOPS 3
+#endif
 
 namespace {
 
@@ -200,7 +207,7 @@ struct ScanArgs {
     const float* qn;   // ||q||^2 per query   (L2 only)
     u64* lists;        // [nqt][S][256][k] sorted keys
     long long N;
-    int dpad, nqt, S, k;
+    int dpad, nqt, S, k, qpx;
     long long nchunks;
 };
 
@@ -257,10 +264,12 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
     int qt, slab;
     {
         const int b = blockIdx.x;
-        if ((a.S & 7) == 0) {
+        if (a.qpx > 0) {
+            // XCD groups: `qpx` query tiles per XCD; the XCDs of one group split the slabs
+            const int ngroups = a.nqt / a.qpx, xpg = 8 / ngroups, spx = a.S / xpg;
             const int xcd = b & 7, j = b >> 3;
-            slab = xcd * (a.S >> 3) + j / a.nqt;
-            qt = j % a.nqt;
+            qt = (xcd / xpg) * a.qpx + (j % a.qpx);
+            slab = (xcd % xpg) * spx + j / a.qpx;
         } else {
             slab = b / a.nqt;
             qt = b % a.nqt;
@@ -309,6 +318,10 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
         qn1 = a.qn[qt * TQ + q1];
     }
 
+#if MQ_PAD_NOPS > 0
+#pragma unroll
+    for (int i_ = 0; i_ < MQ_PAD_NOPS; ++i_) asm volatile("s_nop 0");
+#endif
     if (c0 < c1) issue(c0, 0, 0);
     int stage = 0;
 
@@ -556,7 +569,7 @@ int num_cus() {
 }
 
 struct Geometry {
-    int nqt, S, dpad;
+    int nqt, S, dpad, qpx;
     int64_t nqpad, nchunks;
     size_t off_qp, off_qn, off_qtmp, off_lists, total;
 };
@@ -569,9 +582,28 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
     g.nchunks = round_up(N > 0 ? N : 1, TN) / TN;
     int64_t S = cus / g.nqt;
     if (S < 1) S = 1;
-    if (S >= 8) S = S / 8 * 8;  // keeps the slab -> XCD mapping of knn_scan_kernel
+    if (S >= 8) S = S / 8 * 8;
     if (S > g.nchunks) S = g.nchunks;
     g.S = (int)S;
+    // Workgroup -> (query tile, slab) placement (speed only).  Workgroup b runs on XCD b % 8: give
+    // each XCD `qpx` query tiles so that their Q panels (qpx * 256 * dpad * 4 B, re-read once per KB
+    // chunk) stay in that XCD's 4 MiB L2, and let the XCDs that share those query tiles split the slabs.
+    g.qpx = 0;
+    {
+        int want = 0;
+        const char* e = getenv("MQ_KNN_QPX");
+        if (e) want = atoi(e);
+        for (int q = 1; q <= g.nqt; ++q) {
+            if (g.nqt % q) continue;
+            const int ngroups = g.nqt / q;
+            if (ngroups > 8 || 8 % ngroups) continue;
+            const int xpg = 8 / ngroups;
+            if (g.S % xpg) continue;
+            if (want > 0) { if (q == want) g.qpx = q; continue; }
+            // default: the largest Q working set that still leaves half of L2 to the KB stream
+            if ((size_t)q * TQ * g.dpad * 4 <= (size_t)2 << 20 || g.qpx == 0) g.qpx = q;
+        }
+    }
     size_t o = 0;
     g.off_qp = o;    o += (size_t)g.nqpad * g.dpad * 4;
     g.off_qn = o;    o += (size_t)g.nqpad * 4;
@@ -684,7 +716,7 @@ static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int
     if (N > 0) {
         ScanArgs a;
         a.Xp = packed_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = lists;
-        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks;
+        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx;
         const dim3 grid((unsigned)(g.nqt * g.S)), block(1024);
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
         if (metric == MQ_METRIC_IP) {

@@ -161,7 +161,10 @@ class MI355XFlatIndex(BaseIndex):
                 if isinstance(part, torch.Tensor):
                     dev = part.to(device=self._torch_device, dtype=torch.float32).contiguous()
                 else:
-                    dev = torch.from_numpy(np.ascontiguousarray(part)).to(self._torch_device, non_blocking=False)
+                    part = np.ascontiguousarray(part)
+                    if not part.flags.writeable:
+                        part = part.copy()
+                    dev = torch.from_numpy(part).to(self._torch_device, non_blocking=False)
                 _lib.check(lib.mq_pack_rows_f32(dev.data_ptr(), dev.shape[0], self.d, self.ntotal, int(self.do_l2norm),
                                                 self._packed.data_ptr(), self._capacity, self._sqnorm.data_ptr(),
                                                 stream), "mq_pack_rows_f32")

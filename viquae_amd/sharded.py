@@ -112,11 +112,12 @@ class ShardedFlatIndex(BaseIndex):
         if self.world == 1:
             return Dl, Il
         nq = Dl.shape[0]
-        Ds = torch.empty((self.world, nq, k), dtype=Dl.dtype, device=Dl.device)
-        Is = torch.empty((self.world, nq, k), dtype=Il.dtype, device=Il.device)
+        # rank-major concatenation along dim 0 ([world*nq, k]); viewed as [world, nq, k] for the merge
+        Ds = torch.empty((self.world * nq, k), dtype=Dl.dtype, device=Dl.device)
+        Is = torch.empty((self.world * nq, k), dtype=Il.dtype, device=Il.device)
         dist.all_gather_into_tensor(Ds, Dl.contiguous(), group=self.group)
         dist.all_gather_into_tensor(Is, Il.contiguous(), group=self.group)
-        return self.merge_fn(Ds, Is, self.metric_type)
+        return self.merge_fn(Ds.view(self.world, nq, k), Is.view(self.world, nq, k), self.metric_type)
 
     def search_batch(self, queries, k: int = 10, **kwargs) -> BatchedSearchResults:
         import torch
