@@ -99,6 +99,49 @@ int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[6]);
 int mq_topk_merge_f32(const float *Ds_dev, const int64_t *Is_dev, int nshards, int nq, int k, int metric,
                       float *D_dev, int64_t *I_dev, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Encoder building blocks (fp32): the arithmetic of Hugging Face DPRContextEncoder /
+ * DPRQuestionEncoder (reached from meerqat/ir/embedding.py:226; op order stated in-tree by
+ * meerqat/models/bert.py:12-380) and CLIPModel.get_image_features (meerqat/image/embedding.py:156-161).
+ * Activations are row-major fp32 [tokens, features]; weights keep nn.Linear's [out, in] layout.
+ * ------------------------------------------------------------------------------------------- */
+#define MQ_EPI_NONE 0           /* C = A.W^T                       (CLIP patch embedding, visual projection) */
+#define MQ_EPI_BIAS 1           /* C = A.W^T + b                   (Q/K/V projections)                        */
+#define MQ_EPI_BIAS_GELU 2      /* C = gelu_erf(A.W^T + b)         (BertIntermediate, bert.py:217-229)         */
+#define MQ_EPI_BIAS_QUICKGELU 3 /* C = x*sigmoid(1.702x), x=A.W^T+b (CLIP MLP fc1)                            */
+#define MQ_EPI_BIAS_RESIDUAL 4  /* C = A.W^T + b + R               (BertSelfOutput/BertOutput dense + input)  */
+
+/* nn.Linear with a fused epilogue: A [M,K], W [N,K], bias [N] or NULL, R [M,N] or NULL, C [M,N].
+ * K must be a multiple of 16; A and W 16-byte aligned. */
+int mq_gemm_nt_f32(const float *A_dev, const float *W_dev, const float *bias_dev, const float *residual_dev,
+                   float *C_dev, int M, int N, int K, int epilogue, void *stream);
+
+/* nn.LayerNorm over the last dimension (C <= 1024); X and Y may alias. */
+int mq_layernorm_f32(const float *X_dev, const float *gamma_dev, const float *beta_dev, float *Y_dev, int M, int C,
+                     float eps, void *stream);
+
+/* BertEmbeddings (meerqat/models/bert.py:153-214): LayerNorm(word[ids] + type[token_type_ids] + pos[0..L)).
+ * ids / token_type_ids are int64 [B,L] (token_type_ids may be NULL = zeros); out [B*L, H]. */
+int mq_bert_embed_ln_f32(const int64_t *input_ids_dev, const int64_t *token_type_ids_dev, const float *word_dev,
+                         const float *pos_dev, const float *type_dev, const float *gamma_dev, const float *beta_dev,
+                         float *out_dev, int B, int L, int H, float eps, void *stream);
+
+/* Multi-head self-attention core (BertSelfAttention.forward, meerqat/models/bert.py:44-136):
+ * qkv [B*L, 3*heads*head_dim] = [q | k | v] projections; attention_mask int64 [B,L] (1 = attend, as the
+ * tokenizer emits it; NULL = attend everywhere); out [B*L, heads*head_dim] = softmax(q k^T * scale + mask) v.
+ * head_dim must be 64, L <= 256. */
+int mq_attention_f32(const float *qkv_dev, const int64_t *attention_mask_dev, float *out_dev, int B, int L, int heads,
+                     int head_dim, float scale, void *stream);
+
+/* CLIPVisionEmbeddings.patch_embedding as a GEMM operand: pixels [B,C,S,S] -> [B*(S/P)^2, C*P*P]. */
+int mq_clip_patchify_f32(const float *pixels_dev, float *patches_dev, int B, int channels, int image_size,
+                         int patch_size, void *stream);
+
+/* CLIPVisionEmbeddings + pre_layrnorm: out [B*tokens, H] = LayerNorm([class | patch_emb] + position). */
+int mq_clip_assemble_ln_f32(const float *patch_emb_dev, const float *class_emb_dev, const float *pos_emb_dev,
+                            const float *gamma_dev, const float *beta_dev, float *out_dev, int B, int tokens, int H,
+                            float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,218 @@
+"""numpy fp32 restatement of the two encoders on the hot path (TEST INFRASTRUCTURE, see
+oracle/__init__.py):
+
+* ``bert_forward``  -- DPRContextEncoder / DPRQuestionEncoder = BERT encoder + CLS slice (no pooler,
+  projection_dim 0): the arithmetic the reference reaches through ``model(**inputs)`` at
+  meerqat/ir/embedding.py:226, stated in-tree by meerqat/models/bert.py (BertEmbeddings :153-214,
+  BertSelfAttention :12-136, BertSelfOutput :139-150, BertIntermediate :217-229, BertOutput :232-243,
+  BertLayer :297-380).
+* ``clip_vision_forward`` -- ``CLIPModel.get_image_features`` (meerqat/image/embedding.py:156-161,
+  experiments/image_embedding/clip/vit_config.json:18): ViT-B/32 vision tower + visual projection.
+
+PARITY: pinned.  tests/golden/{dpr,clip}_*.npz hold outputs of the Hugging Face implementations
+(transformers 5.15, the code the reference calls) on seeded weights; ``tests/test_oracle_cpu.py``
+checks this file against them (<= 2e-5 abs).  Weights are not stored: both sides regenerate them with
+``seeded_state`` (numpy Generator, tensors drawn in sorted-name order).
+"""
+import math
+
+import numpy as np
+
+try:
+    from scipy.special import erf as _erf
+except Exception:  # pragma: no cover
+    _erf = np.vectorize(math.erf)
+
+F32 = np.float32
+
+
+# ----------------------------------------------------------------------------------------------
+# configs and seeded weights
+# ----------------------------------------------------------------------------------------------
+BERT_BASE = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12)
+BERT_TINY = dict(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                 intermediate_size=512, max_position_embeddings=128, type_vocab_size=2, layer_norm_eps=1e-12)
+CLIP_VITB32 = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                   image_size=224, patch_size=32, num_channels=3, projection_dim=512, layer_norm_eps=1e-5)
+CLIP_TINY = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
+                 image_size=64, patch_size=32, num_channels=3, projection_dim=64, layer_norm_eps=1e-5)
+
+
+def bert_param_shapes(cfg, prefix="ctx_encoder.bert_model."):
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    s = {
+        "embeddings.word_embeddings.weight": (cfg["vocab_size"], H),
+        "embeddings.position_embeddings.weight": (cfg["max_position_embeddings"], H),
+        "embeddings.token_type_embeddings.weight": (cfg["type_vocab_size"], H),
+        "embeddings.LayerNorm.weight": (H,), "embeddings.LayerNorm.bias": (H,),
+    }
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"encoder.layer.{i}."
+        for n in ("query", "key", "value"):
+            s[p + f"attention.self.{n}.weight"] = (H, H)
+            s[p + f"attention.self.{n}.bias"] = (H,)
+        s[p + "attention.output.dense.weight"] = (H, H)
+        s[p + "attention.output.dense.bias"] = (H,)
+        s[p + "attention.output.LayerNorm.weight"] = (H,)
+        s[p + "attention.output.LayerNorm.bias"] = (H,)
+        s[p + "intermediate.dense.weight"] = (I, H)
+        s[p + "intermediate.dense.bias"] = (I,)
+        s[p + "output.dense.weight"] = (H, I)
+        s[p + "output.dense.bias"] = (H,)
+        s[p + "output.LayerNorm.weight"] = (H,)
+        s[p + "output.LayerNorm.bias"] = (H,)
+    return {prefix + k: v for k, v in s.items()}
+
+
+def clip_vision_param_shapes(cfg):
+    H, I, P, C = cfg["hidden_size"], cfg["intermediate_size"], cfg["patch_size"], cfg["num_channels"]
+    npos = (cfg["image_size"] // P) ** 2 + 1
+    s = {
+        "vision_model.embeddings.class_embedding": (H,),
+        "vision_model.embeddings.patch_embedding.weight": (H, C, P, P),
+        "vision_model.embeddings.position_embedding.weight": (npos, H),
+        "vision_model.pre_layrnorm.weight": (H,), "vision_model.pre_layrnorm.bias": (H,),
+        "vision_model.post_layernorm.weight": (H,), "vision_model.post_layernorm.bias": (H,),
+        "visual_projection.weight": (cfg["projection_dim"], H),
+    }
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"vision_model.encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[p + f"self_attn.{n}.weight"] = (H, H)
+            s[p + f"self_attn.{n}.bias"] = (H,)
+        for n in ("layer_norm1", "layer_norm2"):
+            s[p + n + ".weight"] = (H,)
+            s[p + n + ".bias"] = (H,)
+        s[p + "mlp.fc1.weight"] = (I, H)
+        s[p + "mlp.fc1.bias"] = (I,)
+        s[p + "mlp.fc2.weight"] = (H, I)
+        s[p + "mlp.fc2.bias"] = (H,)
+    return s
+
+
+def seeded_state(shapes, seed):
+    """name -> fp32 array, drawn in sorted-name order from numpy's PCG64 Generator.
+    Matrices/embeddings/biases ~ N(0, 0.02) except LayerNorm weights ~ 1 + N(0, 0.02), so that
+    every parameter matters in a parity test."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name in sorted(shapes):
+        w = (rng.standard_normal(shapes[name]) * 0.02).astype(F32)
+        is_ln = ("LayerNorm" in name or "layer_norm" in name or "layernorm" in name or "layrnorm" in name)
+        if is_ln and name.endswith("weight"):
+            w = (1.0 + w).astype(F32)
+        out[name] = w
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# building blocks (fp32 throughout, op order of meerqat/models/bert.py)
+# ----------------------------------------------------------------------------------------------
+def layer_norm(x, g, b, eps):
+    x = x.astype(F32)
+    mu = x.mean(axis=-1, keepdims=True, dtype=F32)
+    xc = x - mu
+    var = (xc * xc).mean(axis=-1, keepdims=True, dtype=F32)
+    return (xc / np.sqrt(var + F32(eps)) * g + b).astype(F32)
+
+
+def linear(x, w, b=None):
+    y = x.astype(F32) @ w.astype(F32).T
+    return (y + b).astype(F32) if b is not None else y.astype(F32)
+
+
+def gelu_erf(x):
+    return (x * F32(0.5) * (F32(1.0) + _erf(x / F32(math.sqrt(2.0))).astype(F32))).astype(F32)
+
+
+def quick_gelu(x):
+    return (x / (F32(1.0) + np.exp(-F32(1.702) * x))).astype(F32)
+
+
+def softmax_lastdim(s):
+    s = s - s.max(axis=-1, keepdims=True)
+    e = np.exp(s).astype(F32)
+    return (e / e.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
+
+
+def mha(q, k, v, heads, add_mask=None, scale_q=False):
+    """q,k,v [B,L,H] -> context [B,L,H].  BERT: scores / sqrt(dh) (+ additive mask); CLIP scales q first."""
+    B, L, H = q.shape
+    dh = H // heads
+    sp = lambda t: t.reshape(B, L, heads, dh).transpose(0, 2, 1, 3)  # noqa: E731
+    qh, kh, vh = sp(q), sp(k), sp(v)
+    if scale_q:
+        s = (qh * F32(dh ** -0.5)) @ kh.transpose(0, 1, 3, 2)
+    else:
+        s = (qh @ kh.transpose(0, 1, 3, 2)) / F32(math.sqrt(dh))
+    if add_mask is not None:
+        s = s + add_mask
+    p = softmax_lastdim(s.astype(F32))
+    ctx = (p @ vh).astype(F32)
+    return ctx.transpose(0, 2, 1, 3).reshape(B, L, H)
+
+
+def bert_forward(state, cfg, input_ids, token_type_ids=None, attention_mask=None, prefix="ctx_encoder.bert_model.",
+                 return_hidden=False):
+    """DPR encoder output: last_hidden_state[:, 0, :] (HF DPREncoder with projection_dim == 0)."""
+    g = lambda n: state[prefix + n]  # noqa: E731
+    ids = np.asarray(input_ids)
+    B, L = ids.shape
+    tt = np.zeros_like(ids) if token_type_ids is None else np.asarray(token_type_ids)
+    eps, heads = cfg["layer_norm_eps"], cfg["num_attention_heads"]
+    h = g("embeddings.word_embeddings.weight")[ids] + g("embeddings.token_type_embeddings.weight")[tt] \
+        + g("embeddings.position_embeddings.weight")[np.arange(L)][None]
+    h = layer_norm(h, g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"), eps)
+    add_mask = None
+    if attention_mask is not None:
+        m = np.asarray(attention_mask).astype(F32)
+        add_mask = ((F32(1.0) - m) * np.finfo(F32).min)[:, None, None, :]
+    hidden = [h]
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"encoder.layer.{i}."
+        q = linear(h, g(p + "attention.self.query.weight"), g(p + "attention.self.query.bias"))
+        k = linear(h, g(p + "attention.self.key.weight"), g(p + "attention.self.key.bias"))
+        v = linear(h, g(p + "attention.self.value.weight"), g(p + "attention.self.value.bias"))
+        ctx = mha(q, k, v, heads, add_mask)
+        a = linear(ctx, g(p + "attention.output.dense.weight"), g(p + "attention.output.dense.bias"))
+        h = layer_norm(a + h, g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias"), eps)
+        f = gelu_erf(linear(h, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias")))
+        o = linear(f, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
+        h = layer_norm(o + h, g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"), eps)
+        hidden.append(h)
+    out = h[:, 0, :].astype(F32)
+    return (out, hidden) if return_hidden else out
+
+
+def clip_vision_forward(state, cfg, pixel_values, return_hidden=False):
+    """CLIPModel.get_image_features: visual_projection(post_layernorm(encoder(...)[:, 0]))."""
+    x = np.asarray(pixel_values, dtype=F32)
+    B, C, Hh, Ww = x.shape
+    P, H, heads, eps = cfg["patch_size"], cfg["hidden_size"], cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    gh, gw = Hh // P, Ww // P
+    # conv(stride = kernel = P, no bias) == GEMM over (c, ph, pw)-flattened patches
+    patches = x.reshape(B, C, gh, P, gw, P).transpose(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * P * P)
+    wpe = state["vision_model.embeddings.patch_embedding.weight"].reshape(H, C * P * P)
+    pe = linear(patches, wpe)
+    cls = np.broadcast_to(state["vision_model.embeddings.class_embedding"], (B, 1, H))
+    h = np.concatenate([cls, pe], axis=1) + state["vision_model.embeddings.position_embedding.weight"][None]
+    h = layer_norm(h, state["vision_model.pre_layrnorm.weight"], state["vision_model.pre_layrnorm.bias"], eps)
+    hidden = [h]
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"vision_model.encoder.layers.{i}."
+        r = h
+        y = layer_norm(h, state[p + "layer_norm1.weight"], state[p + "layer_norm1.bias"], eps)
+        q = linear(y, state[p + "self_attn.q_proj.weight"], state[p + "self_attn.q_proj.bias"])
+        k = linear(y, state[p + "self_attn.k_proj.weight"], state[p + "self_attn.k_proj.bias"])
+        v = linear(y, state[p + "self_attn.v_proj.weight"], state[p + "self_attn.v_proj.bias"])
+        ctx = mha(q, k, v, heads, None, scale_q=True)
+        h = r + linear(ctx, state[p + "self_attn.out_proj.weight"], state[p + "self_attn.out_proj.bias"])
+        r = h
+        y = layer_norm(h, state[p + "layer_norm2.weight"], state[p + "layer_norm2.bias"], eps)
+        y = quick_gelu(linear(y, state[p + "mlp.fc1.weight"], state[p + "mlp.fc1.bias"]))
+        h = (r + linear(y, state[p + "mlp.fc2.weight"], state[p + "mlp.fc2.bias"])).astype(F32)
+        hidden.append(h)
+    pooled = layer_norm(h[:, 0, :], state["vision_model.post_layernorm.weight"], state["vision_model.post_layernorm.bias"], eps)
+    out = linear(pooled, state["visual_projection.weight"])
+    return (out, hidden) if return_hidden else out

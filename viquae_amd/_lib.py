@@ -32,6 +32,14 @@ SIGNATURES = {
     "mq_knn_search_f32_ev": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_int, c_int, c_i64,
                                      c_ptr, c_ptr, c_ptr, c_sz, c_ptr, c_ptr, c_ptr]),
     "mq_knn_launch_info": (c_int, [c_i64, c_int, c_int, c_int, ctypes.POINTER(c_i64)]),
+    "mq_gemm_nt_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "mq_layernorm_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, ctypes.c_float, c_ptr]),
+    "mq_bert_embed_ln_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int,
+                                     ctypes.c_float, c_ptr]),
+    "mq_attention_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, ctypes.c_float, c_ptr]),
+    "mq_clip_patchify_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "mq_clip_assemble_ln_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, ctypes.c_float,
+                                        c_ptr]),
     "mq_topk_merge_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
 }
 

@@ -1,0 +1,427 @@
+// encoder.hip -- fp32 transformer-encoder building blocks for gfx950 (MI355X): the arithmetic the
+// reference delegates to Hugging Face DPRContextEncoder / CLIPModel.get_image_features
+// (meerqat/ir/embedding.py:226, meerqat/image/embedding.py:156-161; op order stated in-tree by
+// meerqat/models/bert.py:12-380).  C ABI: include/meerqat_hip.h.
+//
+//   gemm_nt_kernel        C[M,N] = A[M,K] . W[N,K]^T (+bias)(+GELU|quick_gelu)(+residual) on
+//                         v_mfma_f32_32x32x2_f32, 256x256x16 tiles, LDS-DMA double buffer
+//   layernorm_kernel      row LayerNorm (one wave per row)
+//   bert_embed_ln_kernel  word + token-type + position gather, LayerNorm
+//   attention_kernel      softmax(q k^T * scale + mask) v per (sequence, head), keys/values in LDS
+//   clip_patchify_kernel  NCHW pixels -> [B*patches, C*P*P] rows (the conv-as-GEMM operand)
+//   clip_assemble_ln_kernel  [CLS | patch embeddings] + position embeddings, pre-LayerNorm
+//
+// All activations are row-major fp32 [tokens, features]; weights keep the PyTorch nn.Linear layout
+// [out_features, in_features] (K contiguous for both GEMM operands, no repacking).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/meerqat_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+extern "C" void mq_internal_set_hip_error(int e);
+
+namespace {
+
+#define ENC_HIP(call)                                  \
+    do {                                               \
+        hipError_t _e = (call);                        \
+        if (_e != hipSuccess) { mq_internal_set_hip_error((int)_e); return MQ_EHIP; } \
+    } while (0)
+
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(unsigned long)(lds_char*)p; }
+// one 1-KiB LDS-DMA piece: LDS destination = lds_dst (wave-uniform) + lane*16, global source per lane.
+// Issued from inline asm so hipcc does not drain it in front of the next ds_read (see knn.hip).
+__device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM  C = A . W^T
+// ------------------------------------------------------------------------------------------------
+constexpr int GT = 256;   // tile edge (rows of A and rows of W per workgroup)
+constexpr int GBK = 16;   // k-depth per LDS stage: one 64-byte row segment per tile row
+constexpr int G_STAGE_FLOATS = GT * GBK;            // one operand, one stage
+constexpr int G_LDS_BYTES = 2 * 2 * G_STAGE_FLOATS * 4;  // A and W, two stages = 64 KiB
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_QUICKGELU = 3, EPI_BIAS_RESIDUAL = 4 };
+
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + expf(-1.702f * x)); }
+
+// LDS image of a tile stage: [256 rows][16 floats], the four 16-byte chunks of a row XOR-swizzled by
+// (row>>2)&3 so that ds_read_b128 of one k-chunk across 32 consecutive rows is bank-conflict free.
+// The DMA writes LDS linearly (lane*16), so the swizzle is applied to the per-lane SOURCE chunk.
+template <int EPI>
+__global__ __launch_bounds__(1024) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, const float* __restrict__ R,
+                                                       float* __restrict__ C, int M, int N, int K, int ntm, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);
+    float* Ws = As + 2 * G_STAGE_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+
+    // tile of this workgroup: consecutive workgroups on one XCD (b % 8) walk the N tiles of one M tile
+    int mt, nt;
+    {
+        const int b = blockIdx.x;
+        if ((ntm & 7) == 0) {
+            const int xcd = b & 7, j = b >> 3;
+            mt = (j / ntn) * 8 + xcd;
+            nt = j % ntn;
+        } else {
+            mt = b / ntn;
+            nt = b % ntn;
+        }
+    }
+    const int m0 = mt * GT, n0 = nt * GT;
+
+    // DMA: wave w moves rows [16w, 16w+16) of both operand tiles; lane -> (row 16w + lane/4, chunk lane%4)
+    const int drow = 16 * w + (lane >> 2);
+    const int dchunk = (lane & 3) ^ ((drow >> 2) & 3);
+    int am = m0 + drow; if (am > M - 1) am = M - 1;
+    int wn = n0 + drow; if (wn > N - 1) wn = N - 1;
+    const float* asrc = A + (size_t)am * K + dchunk * 4;
+    const float* wsrc = W + (size_t)wn * K + dchunk * 4;
+    const unsigned lds_a = __builtin_amdgcn_readfirstlane(lds_addr_of(As + 16 * w * GBK));
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_addr_of(Ws + 16 * w * GBK));
+
+    // fragment reads: lane (i = lane&31, kh = lane>>5) reads chunk (2j+kh) of row (64*wr + 32a + i)
+    const int i = lane & 31, kh = lane >> 5;
+    const int sw = (i >> 2) & 3;
+    const int c0 = ((0 + kh) ^ sw) * 4, c1 = ((2 + kh) ^ sw) * 4;  // float offsets of chunks j=0,1 inside the row
+    const int arow = (64 * wr + i) * GBK, brow = (64 * wc + i) * GBK;
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    const int nk = K / GBK;
+    dma16(asrc, lds_a);
+    dma16(wsrc, lds_w);
+    int stage = 0;
+    for (int kb = 0; kb < nk; ++kb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kb + 1 < nk) {
+            dma16(asrc + (size_t)(kb + 1) * GBK, lds_a + (stage ^ 1) * (G_STAGE_FLOATS * 4));
+            dma16(wsrc + (size_t)(kb + 1) * GBK, lds_w + (stage ^ 1) * (G_STAGE_FLOATS * 4));
+        }
+        const float* as = As + stage * G_STAGE_FLOATS + arow;
+        const float* ws = Ws + stage * G_STAGE_FLOATS + brow;
+        const float4 a0j0 = *reinterpret_cast<const float4*>(as + c0);
+        const float4 a1j0 = *reinterpret_cast<const float4*>(as + 32 * GBK + c0);
+        const float4 b0j0 = *reinterpret_cast<const float4*>(ws + c0);
+        const float4 b1j0 = *reinterpret_cast<const float4*>(ws + 32 * GBK + c0);
+        const float4 a0j1 = *reinterpret_cast<const float4*>(as + c1);
+        const float4 a1j1 = *reinterpret_cast<const float4*>(as + 32 * GBK + c1);
+        const float4 b0j1 = *reinterpret_cast<const float4*>(ws + c1);
+        const float4 b1j1 = *reinterpret_cast<const float4*>(ws + 32 * GBK + c1);
+#define MQ_MFMA4(A0, A1, B0, B1, E)                                            \
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.E, B0.E, acc00, 0, 0, 0); \
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.E, B1.E, acc01, 0, 0, 0); \
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.E, B0.E, acc10, 0, 0, 0); \
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.E, B1.E, acc11, 0, 0, 0);
+        MQ_MFMA4(a0j0, a1j0, b0j0, b1j0, x)
+        MQ_MFMA4(a0j0, a1j0, b0j0, b1j0, y)
+        MQ_MFMA4(a0j0, a1j0, b0j0, b1j0, z)
+        MQ_MFMA4(a0j0, a1j0, b0j0, b1j0, w)
+        MQ_MFMA4(a0j1, a1j1, b0j1, b1j1, x)
+        MQ_MFMA4(a0j1, a1j1, b0j1, b1j1, y)
+        MQ_MFMA4(a0j1, a1j1, b0j1, b1j1, z)
+        MQ_MFMA4(a0j1, a1j1, b0j1, b1j1, w)
+#undef MQ_MFMA4
+        stage ^= 1;
+    }
+
+    // epilogue: C/D map of 32x32x2: col j = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int nb0 = n0 + 64 * wc + i, nb1 = nb0 + 32;
+    float bias0 = 0.f, bias1 = 0.f;
+    if (EPI != EPI_NONE) {
+        if (nb0 < N) bias0 = bias[nb0];
+        if (nb1 < N) bias1 = bias[nb1];
+    }
+    const int mbase = m0 + 64 * wr + 4 * kh;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int mr0 = mbase + (reg & 3) + 8 * (reg >> 2), mr1 = mr0 + 32;
+        float v00 = acc00[reg] + bias0, v01 = acc01[reg] + bias1, v10 = acc10[reg] + bias0, v11 = acc11[reg] + bias1;
+        if (EPI == EPI_BIAS_GELU) { v00 = gelu_erf(v00); v01 = gelu_erf(v01); v10 = gelu_erf(v10); v11 = gelu_erf(v11); }
+        if (EPI == EPI_BIAS_QUICKGELU) { v00 = quick_gelu(v00); v01 = quick_gelu(v01); v10 = quick_gelu(v10); v11 = quick_gelu(v11); }
+        if (mr0 < M) {
+            if (nb0 < N) { if (EPI == EPI_BIAS_RESIDUAL) v00 += R[(size_t)mr0 * N + nb0]; C[(size_t)mr0 * N + nb0] = v00; }
+            if (nb1 < N) { if (EPI == EPI_BIAS_RESIDUAL) v01 += R[(size_t)mr0 * N + nb1]; C[(size_t)mr0 * N + nb1] = v01; }
+        }
+        if (mr1 < M) {
+            if (nb0 < N) { if (EPI == EPI_BIAS_RESIDUAL) v10 += R[(size_t)mr1 * N + nb0]; C[(size_t)mr1 * N + nb0] = v10; }
+            if (nb1 < N) { if (EPI == EPI_BIAS_RESIDUAL) v11 += R[(size_t)mr1 * N + nb1]; C[(size_t)mr1 * N + nb1] = v11; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm family: one wave per row, row held in registers (C <= 1024)
+// ------------------------------------------------------------------------------------------------
+constexpr int LN_MAXPER = 16;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// normalises v[] (this lane's elements c = lane + 64 t, t < nper) and stores
+__device__ __forceinline__ void ln_store(float (&v)[LN_MAXPER], int C, int lane, const float* __restrict__ g,
+                                         const float* __restrict__ b, float eps, float* __restrict__ out) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXPER; ++t) { const int c = lane + 64 * t; if (c < C) s += v[t]; }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXPER; ++t) { const int c = lane + 64 * t; if (c < C) { const float d = v[t] - mean; q += d * d; } }
+    const float var = wave_sum(q) / (float)C;
+    const float inv = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int t = 0; t < LN_MAXPER; ++t) {
+        const int c = lane + 64 * t;
+        if (c < C) out[c] = (v[t] - mean) * inv * g[c] + b[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ X, const float* __restrict__ g,
+                                                        const float* __restrict__ b, float* __restrict__ Y, int M, int C,
+                                                        float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float v[LN_MAXPER];
+#pragma unroll
+    for (int t = 0; t < LN_MAXPER; ++t) { const int c = lane + 64 * t; v[t] = (c < C) ? X[(size_t)row * C + c] : 0.f; }
+    ln_store(v, C, lane, g, b, eps, Y + (size_t)row * C);
+}
+
+// BertEmbeddings (meerqat/models/bert.py:153-214): (word[id] + type[tt]) + pos[t], then LayerNorm
+__global__ __launch_bounds__(256) void bert_embed_ln_kernel(const long long* __restrict__ ids, const long long* __restrict__ tts,
+                                                            const float* __restrict__ word, const float* __restrict__ pos,
+                                                            const float* __restrict__ type, const float* __restrict__ g,
+                                                            const float* __restrict__ b, float* __restrict__ out, int M,
+                                                            int L, int H, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const long long id = ids[row];
+    const long long tt = tts ? tts[row] : 0;
+    const int t_pos = row % L;
+    float v[LN_MAXPER];
+#pragma unroll
+    for (int t = 0; t < LN_MAXPER; ++t) {
+        const int c = lane + 64 * t;
+        v[t] = (c < H) ? (word[(size_t)id * H + c] + type[(size_t)tt * H + c]) + pos[(size_t)t_pos * H + c] : 0.f;
+    }
+    ln_store(v, H, lane, g, b, eps, out + (size_t)row * H);
+}
+
+// CLIPVisionEmbeddings + pre_layrnorm: token 0 = class embedding, token 1+p = patch embedding p; + position
+__global__ __launch_bounds__(256) void clip_assemble_ln_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
+                                                               const float* __restrict__ pos, const float* __restrict__ g,
+                                                               const float* __restrict__ b, float* __restrict__ out, int M,
+                                                               int T, int H, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int bi = row / T, t_pos = row % T;
+    const float* src = t_pos == 0 ? cls : pe + ((size_t)bi * (T - 1) + (t_pos - 1)) * H;
+    float v[LN_MAXPER];
+#pragma unroll
+    for (int t = 0; t < LN_MAXPER; ++t) {
+        const int c = lane + 64 * t;
+        v[t] = (c < H) ? src[c] + pos[(size_t)t_pos * H + c] : 0.f;
+    }
+    ln_store(v, H, lane, g, b, eps, out + (size_t)row * H);
+}
+
+// pixels [B,Cn,S,S] -> rows [B*G*G, Cn*P*P] in (c, ph, pw) order = flattened conv weight order
+__global__ void clip_patchify_kernel(const float* __restrict__ px, float* __restrict__ out, int B, int Cn, int S, int P) {
+    const int G = S / P;
+    const size_t total4 = (size_t)B * Cn * S * S / 4;
+    const size_t e4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e4 >= total4) return;
+    const size_t e = e4 * 4;  // output element index, 4 consecutive pw
+    const int KP = Cn * P * P;
+    const size_t rowi = e / KP;
+    const int col = (int)(e - rowi * KP);
+    const int c = col / (P * P), ph = (col / P) % P, pw = col % P;
+    const int bi = (int)(rowi / (G * G)), gy = (int)(rowi % (G * G)) / G, gx = (int)(rowi % (G * G)) % G;
+    const float4 v = *reinterpret_cast<const float4*>(px + (((size_t)bi * Cn + c) * S + gy * P + ph) * S + gx * P + pw);
+    *reinterpret_cast<float4*>(out + e) = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention: one workgroup per (sequence, head); thread t owns query row t; K and V of the head in LDS
+// ------------------------------------------------------------------------------------------------
+constexpr int DH = 64;
+
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, const long long* __restrict__ mask,
+                                                        float* __restrict__ out, int L, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ks = reinterpret_cast<float*>(smem);   // [L][64]
+    float* Vs = Ks + (size_t)L * DH;              // [L][64]
+    int* keep = reinterpret_cast<int*>(Vs + (size_t)L * DH);  // [L]
+    const int bi = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int H = heads * DH, ld = 3 * H;
+    const float* base = qkv + (size_t)bi * L * ld + h * DH;
+    for (int e = threadIdx.x; e < L * (DH / 4); e += blockDim.x) {
+        const int j = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
+        *reinterpret_cast<float4*>(Ks + j * DH + c4) = *reinterpret_cast<const float4*>(base + (size_t)j * ld + H + c4);
+        *reinterpret_cast<float4*>(Vs + j * DH + c4) = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * H + c4);
+    }
+    for (int j = threadIdx.x; j < L; j += blockDim.x) keep[j] = mask ? (mask[(size_t)bi * L + j] != 0) : 1;
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= L) return;
+    float q[DH], o[DH];
+#pragma unroll
+    for (int c = 0; c < DH; c += 4) {
+        const float4 f = *reinterpret_cast<const float4*>(base + (size_t)t * ld + c);
+        q[c] = f.x; q[c + 1] = f.y; q[c + 2] = f.z; q[c + 3] = f.w;
+        o[c] = o[c + 1] = o[c + 2] = o[c + 3] = 0.f;
+    }
+    float mx = -INFINITY, den = 0.f;
+    for (int j = 0; j < L; ++j) {
+        if (!keep[j]) continue;  // additive finfo.min mask == weight exactly 0
+        const float* kr = Ks + j * DH;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH; c += 4) {
+            const float4 f = *reinterpret_cast<const float4*>(kr + c);
+            s = fmaf(q[c], f.x, s); s = fmaf(q[c + 1], f.y, s); s = fmaf(q[c + 2], f.z, s); s = fmaf(q[c + 3], f.w, s);
+        }
+        s *= scale;
+        const float mn = fmaxf(mx, s);
+        const float corr = expf(mx - mn);  // 0 on the first key (mx = -inf)
+        const float p = expf(s - mn);
+        den = den * corr + p;
+        const float* vr = Vs + j * DH;
+#pragma unroll
+        for (int c = 0; c < DH; c += 4) {
+            const float4 f = *reinterpret_cast<const float4*>(vr + c);
+            o[c] = fmaf(p, f.x, o[c] * corr); o[c + 1] = fmaf(p, f.y, o[c + 1] * corr);
+            o[c + 2] = fmaf(p, f.z, o[c + 2] * corr); o[c + 3] = fmaf(p, f.w, o[c + 3] * corr);
+        }
+        mx = mn;
+    }
+    const float inv = 1.0f / den;
+    float* dst = out + ((size_t)bi * L + t) * H + h * DH;
+#pragma unroll
+    for (int c = 0; c < DH; c += 4) {
+        float4 f; f.x = o[c] * inv; f.y = o[c + 1] * inv; f.z = o[c + 2] * inv; f.w = o[c + 3] * inv;
+        *reinterpret_cast<float4*>(dst + c) = f;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mq_gemm_nt_f32(const float* A_dev, const float* W_dev, const float* bias_dev, const float* residual_dev, float* C_dev,
+                   int M, int N, int K, int epilogue, void* stream) {
+    if (M == 0 || N == 0) return MQ_OK;
+    if (!A_dev || !W_dev || !C_dev || M < 0 || N < 0 || K <= 0 || (K % GBK) != 0) return MQ_EINVAL;
+    if (epilogue < EPI_NONE || epilogue > EPI_BIAS_RESIDUAL) return MQ_EINVAL;
+    if (epilogue != EPI_NONE && !bias_dev) return MQ_EINVAL;
+    if (epilogue == EPI_BIAS_RESIDUAL && !residual_dev) return MQ_EINVAL;
+    if (((uintptr_t)A_dev | (uintptr_t)W_dev) & 15) return MQ_EINVAL;
+    const int ntm = (M + GT - 1) / GT, ntn = (N + GT - 1) / GT;
+    const dim3 grid((unsigned)(ntm * ntn)), block(1024);
+    hipStream_t st = (hipStream_t)stream;
+#define MQ_LAUNCH(E)                                                                                                  \
+    case E:                                                                                                           \
+        ENC_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES)); \
+        hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, block, G_LDS_BYTES, st, A_dev, W_dev, bias_dev, residual_dev, C_dev, M, N, K, ntm, ntn); \
+        break;
+    switch (epilogue) {
+        MQ_LAUNCH(EPI_NONE)
+        MQ_LAUNCH(EPI_BIAS)
+        MQ_LAUNCH(EPI_BIAS_GELU)
+        MQ_LAUNCH(EPI_BIAS_QUICKGELU)
+        MQ_LAUNCH(EPI_BIAS_RESIDUAL)
+    }
+#undef MQ_LAUNCH
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_layernorm_f32(const float* X_dev, const float* gamma_dev, const float* beta_dev, float* Y_dev, int M, int C, float eps,
+                     void* stream) {
+    if (M == 0) return MQ_OK;
+    if (!X_dev || !gamma_dev || !beta_dev || !Y_dev || M < 0 || C <= 0) return MQ_EINVAL;
+    if (C > 64 * LN_MAXPER) return MQ_EUNSUPPORTED;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X_dev, gamma_dev,
+                       beta_dev, Y_dev, M, C, eps);
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_bert_embed_ln_f32(const int64_t* input_ids_dev, const int64_t* token_type_ids_dev, const float* word_dev,
+                         const float* pos_dev, const float* type_dev, const float* gamma_dev, const float* beta_dev,
+                         float* out_dev, int B, int L, int H, float eps, void* stream) {
+    if (B == 0 || L == 0) return MQ_OK;
+    if (!input_ids_dev || !word_dev || !pos_dev || !type_dev || !gamma_dev || !beta_dev || !out_dev || B < 0 || L < 0 || H <= 0)
+        return MQ_EINVAL;
+    if (H > 64 * LN_MAXPER) return MQ_EUNSUPPORTED;
+    const int M = B * L;
+    hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)input_ids_dev, (const long long*)token_type_ids_dev, word_dev, pos_dev, type_dev,
+                       gamma_dev, beta_dev, out_dev, M, L, H, eps);
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_attention_f32(const float* qkv_dev, const int64_t* attention_mask_dev, float* out_dev, int B, int L, int heads,
+                     int head_dim, float scale, void* stream) {
+    if (B == 0 || L == 0) return MQ_OK;
+    if (!qkv_dev || !out_dev || B < 0 || L < 0 || heads <= 0) return MQ_EINVAL;
+    if (head_dim != DH || L > 256) return MQ_EUNSUPPORTED;
+    const size_t lds = (size_t)L * DH * 4 * 2 + (size_t)L * 4;
+    const int threads = (L + 63) / 64 * 64;
+    ENC_HIP(hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * heads)), dim3(threads), lds, (hipStream_t)stream, qkv_dev,
+                       (const long long*)attention_mask_dev, out_dev, L, heads, scale);
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_clip_patchify_f32(const float* pixels_dev, float* patches_dev, int B, int channels, int image_size, int patch_size,
+                         void* stream) {
+    if (B == 0) return MQ_OK;
+    if (!pixels_dev || !patches_dev || B < 0 || channels <= 0 || image_size <= 0 || patch_size <= 0) return MQ_EINVAL;
+    if (image_size % patch_size || patch_size % 4) return MQ_EUNSUPPORTED;
+    const size_t total4 = (size_t)B * channels * image_size * image_size / 4;
+    hipLaunchKernelGGL(clip_patchify_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pixels_dev,
+                       patches_dev, B, channels, image_size, patch_size);
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_clip_assemble_ln_f32(const float* patch_emb_dev, const float* class_emb_dev, const float* pos_emb_dev,
+                            const float* gamma_dev, const float* beta_dev, float* out_dev, int B, int tokens, int H, float eps,
+                            void* stream) {
+    if (B == 0) return MQ_OK;
+    if (!patch_emb_dev || !class_emb_dev || !pos_emb_dev || !gamma_dev || !beta_dev || !out_dev || B < 0 || tokens < 2 || H <= 0)
+        return MQ_EINVAL;
+    if (H > 64 * LN_MAXPER) return MQ_EUNSUPPORTED;
+    const int M = B * tokens;
+    hipLaunchKernelGGL(clip_assemble_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, patch_emb_dev,
+                       class_emb_dev, pos_emb_dev, gamma_dev, beta_dev, out_dev, M, tokens, H, eps);
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+}  // extern "C"

@@ -631,6 +631,7 @@ const char* mq_strerror(int code) {
 }
 
 int mq_last_hip_error(void) { return g_last_hip_error; }
+void mq_internal_set_hip_error(int e) { g_last_hip_error = e; }  /* used by encoder.hip */
 
 int64_t mq_padded_rows(int64_t n_rows) { return round_up(n_rows > 0 ? n_rows : 1, TN); }
 int mq_padded_dim(int d) { return (int)round_up(d, BK); }

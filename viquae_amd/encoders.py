@@ -1,0 +1,329 @@
+"""HIP-backed encoders with the Hugging Face call surface the reference uses.
+
+``get_pretrained(class_name, ...)`` in the reference resolves ``DPRContextEncoder``,
+``DPRQuestionEncoder`` and ``CLIPModel`` in ``transformers`` (meerqat/data/loading.py:167-183); the
+mirror in :mod:`viquae_amd.data.loading` resolves the same names here first.  The objects below are
+``torch.nn.Module``s (so ``model.to(device).eval()`` and the reference's ``nn.DataParallel`` wrapping,
+meerqat/ir/embedding.py:285-288, keep working) whose ``forward`` runs entirely in libmeerqat_hip.so
+(csrc/encoder.hip): fused embedding+LayerNorm, MFMA GEMMs with fused bias/GELU/residual epilogues,
+attention, LayerNorm.  Weights are read from a Hugging Face checkpoint directory (``config.json`` +
+``model.safetensors`` or ``pytorch_model.bin``) or from a ``state_dict`` with HF tensor names.
+
+fp32 in, fp32 out; parity target <= 1e-3 abs against the HF implementations (tests/golden/).
+No CPU fallback: calling ``forward`` without the HIP library or a GPU raises.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL = 0, 1, 2, 3, 4
+
+
+class ModelOutput(dict):
+    """dict with attribute access: ``outputs['pooler_output']`` (meerqat/ir/embedding.py:231-234) and
+    ``outputs.pooler_output`` both work."""
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+
+# --------------------------------------------------------------------------------------------------
+# thin op wrappers over the C ABI (torch tensors in, torch tensors out, current stream)
+# --------------------------------------------------------------------------------------------------
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _check_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.MeerqatHipError("viquae_amd encoders run on MI355X only: move the model and its inputs to a GPU "
+                                       "(no CPU fallback)")
+
+
+def gemm_nt(a, w, bias=None, residual=None, epilogue=EPI_NONE, out=None):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T)."""
+    _check_cuda(a, w)
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.mq_gemm_nt_f32(a.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                      residual.data_ptr() if residual is not None else None, out.data_ptr(), M, N, K,
+                                      epilogue, _stream(a)), "mq_gemm_nt_f32")
+    return out
+
+
+def layernorm(x, g, b, eps, out=None):
+    _check_cuda(x)
+    lib = _lib.load()
+    M, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.mq_layernorm_f32(x.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), M, C, float(eps), _stream(x)),
+                   "mq_layernorm_f32")
+    return out
+
+
+def attention(qkv, mask, B, L, heads, scale):
+    _check_cuda(qkv)
+    lib = _lib.load()
+    H = qkv.shape[1] // 3
+    out = torch.empty((B * L, H), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        _lib.check(lib.mq_attention_f32(qkv.data_ptr(), mask.data_ptr() if mask is not None else None, out.data_ptr(), B, L,
+                                        heads, H // heads, float(scale), _stream(qkv)), "mq_attention_f32")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# checkpoint reading
+# --------------------------------------------------------------------------------------------------
+def read_checkpoint(path):
+    """(config dict, state dict of CPU tensors) from a Hugging Face ``save_pretrained`` directory."""
+    with open(os.path.join(path, "config.json")) as f:
+        config = json.load(f)
+    st = os.path.join(path, "model.safetensors")
+    pt = os.path.join(path, "pytorch_model.bin")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        state = load_file(st)
+    elif os.path.exists(pt):
+        state = torch.load(pt, map_location="cpu", weights_only=True)
+    else:
+        raise FileNotFoundError(f"no model.safetensors or pytorch_model.bin under {path}")
+    return config, state
+
+
+def _t(x):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(x)
+    return x.detach().to(torch.float32).contiguous()
+
+
+class _HipEncoder(nn.Module):
+    def _reg(self, name, tensor):
+        self.register_buffer(name.replace(".", "_"), _t(tensor), persistent=False)
+        return getattr(self, name.replace(".", "_"))
+
+
+# --------------------------------------------------------------------------------------------------
+# BERT / DPR
+# --------------------------------------------------------------------------------------------------
+class BertEncoderHIP(_HipEncoder):
+    """BertModel without pooler (DPR builds it with add_pooling_layer=False)."""
+
+    def __init__(self, config, state, prefix):
+        super().__init__()
+        g = lambda n: state[prefix + n]  # noqa: E731
+        self.hidden = int(config["hidden_size"])
+        self.layers = int(config["num_hidden_layers"])
+        self.heads = int(config["num_attention_heads"])
+        self.eps = float(config.get("layer_norm_eps", 1e-12))
+        if config.get("hidden_act", "gelu") != "gelu":
+            raise NotImplementedError("only the exact-erf GELU of bert-base is provided")
+        if config.get("position_embedding_type", "absolute") != "absolute":
+            raise NotImplementedError("only absolute position embeddings")
+        if self.hidden // self.heads != 64:
+            raise NotImplementedError("attention head size must be 64")
+        self._reg("w_word", g("embeddings.word_embeddings.weight"))
+        self._reg("w_pos", g("embeddings.position_embeddings.weight"))
+        self._reg("w_type", g("embeddings.token_type_embeddings.weight"))
+        self._reg("emb_g", g("embeddings.LayerNorm.weight"))
+        self._reg("emb_b", g("embeddings.LayerNorm.bias"))
+        for i in range(self.layers):
+            p = f"encoder.layer.{i}."
+            self._reg(f"l{i}_wqkv", torch.cat([_t(g(p + f"attention.self.{n}.weight")) for n in ("query", "key", "value")]))
+            self._reg(f"l{i}_bqkv", torch.cat([_t(g(p + f"attention.self.{n}.bias")) for n in ("query", "key", "value")]))
+            self._reg(f"l{i}_wo", g(p + "attention.output.dense.weight"))
+            self._reg(f"l{i}_bo", g(p + "attention.output.dense.bias"))
+            self._reg(f"l{i}_g1", g(p + "attention.output.LayerNorm.weight"))
+            self._reg(f"l{i}_b1", g(p + "attention.output.LayerNorm.bias"))
+            self._reg(f"l{i}_wi", g(p + "intermediate.dense.weight"))
+            self._reg(f"l{i}_bi", g(p + "intermediate.dense.bias"))
+            self._reg(f"l{i}_w2", g(p + "output.dense.weight"))
+            self._reg(f"l{i}_b2", g(p + "output.dense.bias"))
+            self._reg(f"l{i}_g2", g(p + "output.LayerNorm.weight"))
+            self._reg(f"l{i}_b2n", g(p + "output.LayerNorm.bias"))
+
+    @torch.no_grad()
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, output_hidden_states=False):
+        _check_cuda(input_ids, self.w_word)
+        lib = _lib.load()
+        B, L = input_ids.shape
+        if L > self.w_pos.shape[0]:
+            raise ValueError(f"sequence length {L} exceeds max_position_embeddings {self.w_pos.shape[0]}")
+        dev = input_ids.device
+        ids = input_ids.to(torch.int64).contiguous()
+        tt = token_type_ids.to(torch.int64).contiguous() if token_type_ids is not None else None
+        mask = attention_mask.to(torch.int64).contiguous() if attention_mask is not None else None
+        H = self.hidden
+        h = torch.empty((B * L, H), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mq_bert_embed_ln_f32(ids.data_ptr(), tt.data_ptr() if tt is not None else None, self.w_word.data_ptr(),
+                                                self.w_pos.data_ptr(), self.w_type.data_ptr(), self.emb_g.data_ptr(),
+                                                self.emb_b.data_ptr(), h.data_ptr(), B, L, H, self.eps, _stream(h)),
+                       "mq_bert_embed_ln_f32")
+        hidden = [h.view(B, L, H)] if output_hidden_states else None
+        scale = 1.0 / math.sqrt(H // self.heads)
+        for i in range(self.layers):
+            w = lambda n: getattr(self, f"l{i}_{n}")  # noqa: E731
+            qkv = gemm_nt(h, w("wqkv"), w("bqkv"), None, EPI_BIAS)
+            ctx = attention(qkv, mask, B, L, self.heads, scale)
+            a = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL)
+            h1 = layernorm(a, w("g1"), w("b1"), self.eps, out=a)
+            f = gemm_nt(h1, w("wi"), w("bi"), None, EPI_BIAS_GELU)
+            o = gemm_nt(f, w("w2"), w("b2"), h1, EPI_BIAS_RESIDUAL)
+            h = layernorm(o, w("g2"), w("b2n"), self.eps, out=o)
+            if output_hidden_states:
+                hidden.append(h.view(B, L, H))
+        return h.view(B, L, H), hidden
+
+
+class _DPREncoder(_HipEncoder):
+    _prefix = None
+    config_class = dict
+
+    def __init__(self, config, state):
+        super().__init__()
+        self.config = dict(config)
+        if int(self.config.get("projection_dim", 0) or 0) != 0:
+            raise NotImplementedError("DPR projection_dim > 0 is not used by the reference checkpoints")
+        self.bert_model = BertEncoderHIP(self.config, state, self._prefix)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, **kwargs):
+        config, state = read_checkpoint(pretrained_model_name_or_path)
+        return cls(config, state)
+
+    @classmethod
+    def from_state_dict(cls, config, state):
+        return cls(config, state)
+
+    @torch.no_grad()
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, output_hidden_states=False, **unused):
+        last, hidden = self.bert_model(input_ids, token_type_ids, attention_mask, output_hidden_states)
+        out = ModelOutput(pooler_output=last[:, 0, :].contiguous())
+        if output_hidden_states:
+            out["hidden_states"] = tuple(hidden)
+        return out
+
+
+class DPRContextEncoder(_DPREncoder):
+    """transformers.DPRContextEncoder (experiments/ir/viquae/dpr/passages/config.json:2-5)."""
+    _prefix = "ctx_encoder.bert_model."
+
+
+class DPRQuestionEncoder(_DPREncoder):
+    """transformers.DPRQuestionEncoder (experiments/ir/viquae/dpr/questions/config.json)."""
+    _prefix = "question_encoder.bert_model."
+
+
+# --------------------------------------------------------------------------------------------------
+# CLIP vision tower
+# --------------------------------------------------------------------------------------------------
+class CLIPModel(_HipEncoder):
+    """transformers.CLIPModel restricted to ``get_image_features`` (the ``call`` of
+    experiments/image_embedding/clip/vit_config.json:18): ViT vision tower + visual projection."""
+    config_class = dict
+
+    def __init__(self, config, state):
+        super().__init__()
+        self.config = dict(config)
+        v = dict(config.get("vision_config", config))
+        self.hidden = int(v["hidden_size"])
+        self.layers = int(v["num_hidden_layers"])
+        self.heads = int(v["num_attention_heads"])
+        self.image_size, self.patch = int(v["image_size"]), int(v["patch_size"])
+        self.channels = int(v.get("num_channels", 3))
+        self.eps = float(v.get("layer_norm_eps", 1e-5))
+        act = v.get("hidden_act", "quick_gelu")
+        if act not in ("quick_gelu", "gelu"):
+            raise NotImplementedError(f"CLIP activation {act}")
+        self.act = EPI_BIAS_QUICKGELU if act == "quick_gelu" else EPI_BIAS_GELU
+        if self.hidden // self.heads != 64:
+            raise NotImplementedError("attention head size must be 64")
+        s = state
+        self._reg("cls", s["vision_model.embeddings.class_embedding"])
+        self._reg("wpe", _t(s["vision_model.embeddings.patch_embedding.weight"]).reshape(self.hidden, -1))
+        self._reg("pos", s["vision_model.embeddings.position_embedding.weight"])
+        self._reg("pre_g", s["vision_model.pre_layrnorm.weight"])
+        self._reg("pre_b", s["vision_model.pre_layrnorm.bias"])
+        self._reg("post_g", s["vision_model.post_layernorm.weight"])
+        self._reg("post_b", s["vision_model.post_layernorm.bias"])
+        self._reg("wproj", s["visual_projection.weight"])
+        for i in range(self.layers):
+            p = f"vision_model.encoder.layers.{i}."
+            self._reg(f"l{i}_wqkv", torch.cat([_t(s[p + f"self_attn.{n}.weight"]) for n in ("q_proj", "k_proj", "v_proj")]))
+            self._reg(f"l{i}_bqkv", torch.cat([_t(s[p + f"self_attn.{n}.bias"]) for n in ("q_proj", "k_proj", "v_proj")]))
+            self._reg(f"l{i}_wo", s[p + "self_attn.out_proj.weight"])
+            self._reg(f"l{i}_bo", s[p + "self_attn.out_proj.bias"])
+            self._reg(f"l{i}_g1", s[p + "layer_norm1.weight"])
+            self._reg(f"l{i}_b1", s[p + "layer_norm1.bias"])
+            self._reg(f"l{i}_g2", s[p + "layer_norm2.weight"])
+            self._reg(f"l{i}_b2n", s[p + "layer_norm2.bias"])
+            self._reg(f"l{i}_w1", s[p + "mlp.fc1.weight"])
+            self._reg(f"l{i}_bb1", s[p + "mlp.fc1.bias"])
+            self._reg(f"l{i}_w2", s[p + "mlp.fc2.weight"])
+            self._reg(f"l{i}_bb2", s[p + "mlp.fc2.bias"])
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, **kwargs):
+        config, state = read_checkpoint(pretrained_model_name_or_path)
+        return cls(config, state)
+
+    @classmethod
+    def from_state_dict(cls, config, state):
+        return cls(config, state)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("only get_image_features is on the reference's hot path "
+                                  "(experiments/image_embedding/clip/vit_config.json:18)")
+
+    @torch.no_grad()
+    def get_image_features(self, pixel_values=None, **unused):
+        _check_cuda(pixel_values, self.cls)
+        lib = _lib.load()
+        px = pixel_values.to(torch.float32).contiguous()
+        B, C, S, S2 = px.shape
+        if (C, S, S2) != (self.channels, self.image_size, self.image_size):
+            raise ValueError(f"expected pixel_values [B,{self.channels},{self.image_size},{self.image_size}], got {tuple(px.shape)}")
+        dev, H = px.device, self.hidden
+        G = S // self.patch
+        T = G * G + 1
+        patches = torch.empty((B * G * G, C * self.patch * self.patch), dtype=torch.float32, device=dev)
+        h = torch.empty((B * T, H), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mq_clip_patchify_f32(px.data_ptr(), patches.data_ptr(), B, C, S, self.patch, _stream(px)),
+                       "mq_clip_patchify_f32")
+            pe = gemm_nt(patches, self.wpe, None, None, EPI_NONE)
+            _lib.check(lib.mq_clip_assemble_ln_f32(pe.data_ptr(), self.cls.data_ptr(), self.pos.data_ptr(), self.pre_g.data_ptr(),
+                                                   self.pre_b.data_ptr(), h.data_ptr(), B, T, H, self.eps, _stream(px)),
+                       "mq_clip_assemble_ln_f32")
+        scale = (H // self.heads) ** -0.5
+        for i in range(self.layers):
+            w = lambda n: getattr(self, f"l{i}_{n}")  # noqa: E731
+            y = layernorm(h, w("g1"), w("b1"), self.eps)
+            qkv = gemm_nt(y, w("wqkv"), w("bqkv"), None, EPI_BIAS)
+            ctx = attention(qkv, None, B, T, self.heads, scale)
+            h = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, out=h)
+            y = layernorm(h, w("g2"), w("b2n"), self.eps, out=y)
+            f = gemm_nt(y, w("w1"), w("bb1"), None, self.act)
+            h = gemm_nt(f, w("w2"), w("bb2"), h, EPI_BIAS_RESIDUAL, out=h)
+        pooled = layernorm(h.view(B, T, H)[:, 0, :].contiguous(), self.post_g, self.post_b, self.eps)
+        return gemm_nt(pooled, self.wproj, None, None, EPI_NONE)
+
+
+HIP_CLASSES = {"DPRContextEncoder": DPRContextEncoder, "DPRQuestionEncoder": DPRQuestionEncoder, "CLIPModel": CLIPModel}
