@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--rows", type=int, default=KB_ROWS, help="KB rows per GPU (default: BASELINE size)")
     ap.add_argument("--nq", type=int, default=NQ)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encoders", action="store_true", help="skip the secondary encoder throughput figures")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
     return ap.parse_args()
 
@@ -231,6 +232,25 @@ def main():
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 rec["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e!r}"}
+        if world == 1 and not args.no_encoders:
+            # secondary BASELINE figures (configs[2], configs[3]); the headline `value` stays queries/s
+            try:
+                del local, ws
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_encoders
+                d = bench_encoders.dpr_throughput(B=2048, L=100, steps=2)
+                c = bench_encoders.clip_throughput(B=3072, steps=2)
+                rec["secondary"] = {
+                    "kb_passages_encoded_per_s": round(d["passages_per_s"], 1),
+                    "dpr": {"workload": "DPR bert-base, 2048 x 100 synthetic tokens per batch, fp32", "ms_per_batch": round(d["ms_per_batch"], 2),
+                            "tflops": round(d["tflops"], 2), "frac_of_f32_mfma_peak": round(d["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)},
+                    "images_encoded_per_s": round(c["images_per_s"], 1),
+                    "clip": {"workload": "CLIP ViT-B/32, 3072 x 224x224 synthetic images per batch, fp32", "ms_per_batch": round(c["ms_per_batch"], 2),
+                             "tflops": round(c["tflops"], 2), "frac_of_f32_mfma_peak": round(c["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)},
+                }
+            except Exception as e:
+                rec["secondary"] = {"error": repr(e)}
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()

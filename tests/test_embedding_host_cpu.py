@@ -1,0 +1,149 @@
+"""CPU suite: host-side mirrors of meerqat.ir.embedding / meerqat.image.embedding / data.loading /
+models.utils (plumbing only: the encoder is replaced by a fake callable, no arithmetic is checked)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_prepare_inputs_recursion_and_error():
+    from viquae_amd.utils import prepare_inputs
+    data = {"a": torch.ones(2), "b": [torch.zeros(1), (torch.ones(1),)], "c": {"d": torch.ones(3)}}
+    out = prepare_inputs(data, torch.device("cpu"))
+    assert isinstance(out["b"], list) and isinstance(out["b"][1], tuple) and out["c"]["d"].shape == (3,)
+    with pytest.raises(TypeError):
+        prepare_inputs({"a": "text"}, torch.device("cpu"))
+
+
+def test_class_resolution_prefers_hip_encoders():
+    from viquae_amd import encoders
+    from viquae_amd.data.loading import get_class_from_name
+    assert get_class_from_name("DPRContextEncoder") is encoders.DPRContextEncoder
+    assert get_class_from_name("DPRQuestionEncoder") is encoders.DPRQuestionEncoder
+    assert get_class_from_name("CLIPModel") is encoders.CLIPModel
+    assert get_class_from_name("BertTokenizer").__module__.startswith("transformers")
+    with pytest.raises(ValueError):
+        get_class_from_name("NoSuchClass")
+
+
+def test_load_pretrained_in_kwargs_reads_reference_style_config(tmp_path):
+    """experiments/ir/viquae/dpr/passages/config.json shape: nested dicts with class_name are replaced by objects."""
+    from safetensors.torch import save_file
+    from oracle import encoders as oe
+    from viquae_amd import encoders
+    from viquae_amd.data.loading import load_pretrained_in_kwargs
+    cfg = oe.BERT_TINY
+    state = oe.seeded_state(oe.bert_param_shapes(cfg), 1)
+    mdir = tmp_path / "context_model"
+    mdir.mkdir()
+    save_file({k: torch.from_numpy(v) for k, v in state.items()}, str(mdir / "model.safetensors"))
+    json.dump(dict(cfg, hidden_act="gelu"), open(mdir / "config.json", "w"))
+    config = {"model": {"class_name": "DPRContextEncoder", "pretrained_model_name_or_path": str(mdir)},
+              "tokenization_kwargs": {"max_length": 256, "padding": "max_length"}, "key": "passage",
+              "save_as": "DPR_few_shot", "output_key": "pooler_output", "map_kwargs": {"batch_size": 2048}}
+    out = load_pretrained_in_kwargs(config)
+    assert isinstance(out["model"], encoders.DPRContextEncoder) and out["key"] == "passage"
+    assert out["model"].bert_model.layers == cfg["num_hidden_layers"]
+    # weights are buffers: .to()/.eval()/DataParallel-style replication see them
+    assert sum(b.numel() for b in out["model"].buffers()) == sum(v.size for v in state.values())
+
+
+class _Tok:
+    sep_token = "[SEP]"
+
+    def __call__(self, texts, **kw):
+        self.seen, self.kw = list(texts), kw
+        n = len(texts)
+        return {"input_ids": torch.arange(n * 4).reshape(n, 4), "attention_mask": torch.ones(n, 4, dtype=torch.long)}
+
+
+class _Model(torch.nn.Module):
+    def forward(self, input_ids=None, attention_mask=None, **kw):
+        return {"pooler_output": input_ids.float() * 2, "hidden_states": [input_ids.float()[:, :, None].repeat(1, 1, 3)] * 2}
+
+    def get_text_features(self, input_ids=None, attention_mask=None):
+        return input_ids.float() + 1
+
+
+def test_embed_output_selection_and_errors():
+    from viquae_amd.ir.embedding import embed
+    batch = {"passage": ["a", "b", "c"]}
+    tok = _Tok()
+    out = embed(dict(batch), _Model(), tok, tokenization_kwargs={"padding": "max_length"}, output_key="pooler_output",
+                save_as="DPR_few_shot")
+    assert out["DPR_few_shot"].shape == (3, 4) and isinstance(out["DPR_few_shot"], np.ndarray)
+    assert tok.seen == ["a", "b", "c"] and tok.kw == {"padding": "max_length"}
+    out = embed(dict(batch), _Model(), tok, call="get_text_features", save_as="t")  # Tensor output, no output_key needed
+    assert np.array_equal(out["t"][0], [1, 2, 3, 4])
+    with pytest.raises(ValueError):
+        embed(dict(batch), _Model(), tok)  # dict output without output_key
+    out = embed(dict(batch), _Model(), tok, output_key="hidden_states", layers=[0, 1], save_as="h")
+    assert out["h_layer_1"].shape == (3, 3) and "h" not in out
+
+
+def test_expand_query_variants():
+    from viquae_amd.ir.embedding import expand_query
+    b = {"input": ["q1", "q2"], "pred": ["Paris", "Rome"], "id": ["a", "b"]}
+    assert expand_query(b, key="input") == ["q1", "q2"]
+    assert expand_query(b, key="input", tokenizer=_Tok(), qe_predictions_key="pred") == ["q1 [SEP] Paris", "q2 [SEP] Rome"]
+
+    class Run:
+        run = {"a": {"1": 0.9, "0": 0.1}, "b": {"0": 0.7}}
+    kb = [{"wikidata_label": "Zero"}, {"wikidata_label": "One"}]
+    assert expand_query(b, key="input", kb=kb, run=Run(), tokenizer=_Tok()) == ["q1 [SEP] One", "q2 [SEP] Zero"]
+
+
+def test_image_embed_handles_unreadable_images(tmp_path, monkeypatch):
+    from PIL import Image
+    from viquae_amd.data import loading
+    from viquae_amd.image import embedding as IE
+    monkeypatch.setattr(loading, "IMAGE_PATH", tmp_path)
+    Image.new("RGB", (8, 8), (255, 0, 0)).save(tmp_path / "a.png")
+    Image.new("RGB", (8, 8), (0, 255, 0)).save(tmp_path / "c.png")
+
+    def transform(images, return_tensors="pt"):
+        return {"pixel_values": torch.stack([torch.tensor(np.asarray(im), dtype=torch.float32).permute(2, 0, 1) for im in images])}
+
+    class M(torch.nn.Module):
+        def get_image_features(self, pixel_values=None):
+            return pixel_values.mean(dim=(2, 3))
+    monkeypatch.setattr(IE, "device", torch.device("cpu"))
+    with pytest.warns(UserWarning):
+        out = IE.embed({"image": ["a.png", "missing.png", "c.png"]}, M(), transform, save_as="clip", call="get_image_features")
+    assert out["clip"][1] is None and np.allclose(out["clip"][0], [255, 0, 0]) and np.allclose(out["clip"][2], [0, 255, 0])
+    with pytest.warns(UserWarning):
+        assert IE.embed({"image": ["nope.png"]}, M(), transform) == [None]
+    with pytest.raises(NotImplementedError):
+        IE.get_model_and_transform({"type": "torchvision"})
+
+
+def test_encoder_forward_without_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from oracle import encoders as oe
+    from viquae_amd._lib import MeerqatHipError
+    from viquae_amd.encoders import DPRContextEncoder
+    cfg = oe.BERT_TINY
+    m = DPRContextEncoder.from_state_dict(cfg, oe.seeded_state(oe.bert_param_shapes(cfg), 0))
+    with pytest.raises(MeerqatHipError):
+        m(input_ids=torch.ones((1, 4), dtype=torch.long))
+
+
+@pytest.mark.parametrize("name,cfgname,kind", [("dpr_tiny", "BERT_TINY", "dpr"), ("dpr_tiny_L100", "BERT_TINY", "dpr"),
+                                               ("dpr_base_8x100", "BERT_BASE", "dpr"), ("clip_tiny", "CLIP_TINY", "clip")])
+def test_encoder_oracle_matches_hf_goldens(name, cfgname, kind):
+    """Pins the numpy encoder oracle to outputs of the Hugging Face code the reference calls."""
+    from oracle import encoders as oe
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{name}.npz"))
+    cfg = getattr(oe, cfgname)
+    if kind == "dpr":
+        state = oe.seeded_state(oe.bert_param_shapes(cfg), int(z["seed"]))
+        out = oe.bert_forward(state, cfg, z["input_ids"], z["token_type_ids"] if "token_type_ids" in z.files else None,
+                              z["attention_mask"] if "attention_mask" in z.files else None)
+        assert np.abs(out - z["pooler_output"]).max() < 2e-5
+    else:
+        state = oe.seeded_state(oe.clip_vision_param_shapes(cfg), int(z["seed"]))
+        out = oe.clip_vision_forward(state, cfg, z["pixel_values"].astype(np.float32))
+        assert np.abs(out - z["image_features"]).max() < 2e-5

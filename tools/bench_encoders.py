@@ -1,0 +1,89 @@
+"""Encoder throughput on one MI355X: BASELINE.json configs[2] (DPR bert-base, 100-token passages) and
+configs[3] (CLIP ViT-B/32, 224x224 images), synthetic inputs generated on device, seeded random weights."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from viquae_amd.encoders import CLIPModel, DPRContextEncoder
+
+BERT_BASE = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12)
+CLIP_VITB32 = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                   image_size=224, patch_size=32, num_channels=3, projection_dim=512, layer_norm_eps=1e-5)
+
+
+def random_bert_state(cfg, seed, prefix="ctx_encoder.bert_model."):
+    g = torch.Generator().manual_seed(seed)
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    r = lambda *s: torch.randn(*s, generator=g) * 0.02  # noqa: E731
+    st = {"embeddings.word_embeddings.weight": r(cfg["vocab_size"], H), "embeddings.position_embeddings.weight": r(cfg["max_position_embeddings"], H),
+          "embeddings.token_type_embeddings.weight": r(cfg["type_vocab_size"], H), "embeddings.LayerNorm.weight": 1 + r(H), "embeddings.LayerNorm.bias": r(H)}
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"encoder.layer.{i}."
+        for n in ("query", "key", "value"):
+            st[p + f"attention.self.{n}.weight"], st[p + f"attention.self.{n}.bias"] = r(H, H), r(H)
+        st[p + "attention.output.dense.weight"], st[p + "attention.output.dense.bias"] = r(H, H), r(H)
+        st[p + "attention.output.LayerNorm.weight"], st[p + "attention.output.LayerNorm.bias"] = 1 + r(H), r(H)
+        st[p + "intermediate.dense.weight"], st[p + "intermediate.dense.bias"] = r(I, H), r(I)
+        st[p + "output.dense.weight"], st[p + "output.dense.bias"] = r(H, I), r(H)
+        st[p + "output.LayerNorm.weight"], st[p + "output.LayerNorm.bias"] = 1 + r(H), r(H)
+    return {prefix + k: v for k, v in st.items()}
+
+
+def random_clip_state(cfg, seed):
+    g = torch.Generator().manual_seed(seed)
+    H, I, P = cfg["hidden_size"], cfg["intermediate_size"], cfg["patch_size"]
+    r = lambda *s: torch.randn(*s, generator=g) * 0.02  # noqa: E731
+    st = {"vision_model.embeddings.class_embedding": r(H), "vision_model.embeddings.patch_embedding.weight": r(H, 3, P, P),
+          "vision_model.embeddings.position_embedding.weight": r((cfg["image_size"] // P) ** 2 + 1, H),
+          "vision_model.pre_layrnorm.weight": 1 + r(H), "vision_model.pre_layrnorm.bias": r(H),
+          "vision_model.post_layernorm.weight": 1 + r(H), "vision_model.post_layernorm.bias": r(H),
+          "visual_projection.weight": r(cfg["projection_dim"], H)}
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"vision_model.encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            st[p + f"self_attn.{n}.weight"], st[p + f"self_attn.{n}.bias"] = r(H, H), r(H)
+        for n in ("layer_norm1", "layer_norm2"):
+            st[p + n + ".weight"], st[p + n + ".bias"] = 1 + r(H), r(H)
+        st[p + "mlp.fc1.weight"], st[p + "mlp.fc1.bias"] = r(I, H), r(I)
+        st[p + "mlp.fc2.weight"], st[p + "mlp.fc2.bias"] = r(H, I), r(H)
+    return st
+
+
+def time_it(fn, steps, warmup=1):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def dpr_throughput(B=2048, L=100, steps=2, device="cuda"):
+    model = DPRContextEncoder.from_state_dict(dict(BERT_BASE), random_bert_state(BERT_BASE, 0)).to(device).eval()
+    g = torch.Generator(device=device).manual_seed(1)
+    ids = torch.randint(1000, 30000, (B, L), generator=g, device=device)
+    mask = torch.ones((B, L), dtype=torch.int64, device=device)
+    tt = torch.zeros((B, L), dtype=torch.int64, device=device)
+    t = time_it(lambda: model(input_ids=ids, token_type_ids=tt, attention_mask=mask)["pooler_output"], steps)
+    flops = 12 * (14155776 * L + 3072 * L * L) * B  # 17.36 GFLOP / passage at L = 100
+    return {"passages_per_s": B / t, "ms_per_batch": t * 1e3, "batch": B, "seq_len": L, "tflops": flops / t / 1e12}
+
+
+def clip_throughput(B=3072, steps=2, device="cuda"):
+    model = CLIPModel.from_state_dict({"vision_config": dict(CLIP_VITB32)}, random_clip_state(CLIP_VITB32, 0)).to(device).eval()
+    g = torch.Generator(device=device).manual_seed(2)
+    px = torch.randn((B, 3, 224, 224), generator=g, device=device)
+    t = time_it(lambda: model.get_image_features(pixel_values=px), steps)
+    return {"images_per_s": B / t, "ms_per_batch": t * 1e3, "batch": B, "tflops": 8.82e9 * B / t / 1e12}
+
+
+if __name__ == "__main__":
+    print(json.dumps({"dpr": dpr_throughput(), "clip": clip_throughput()}))

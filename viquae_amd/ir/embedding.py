@@ -1,0 +1,155 @@
+"""Mirror of ``meerqat.ir.embedding`` for the text-only path:
+``expand_query`` (:128-144), ``get_inputs`` (:155-194), ``embed`` (:197-246), ``dataset_embed``
+(:249-272) and the ``__main__`` wiring (:275-298) as :func:`main`.
+
+The model is one of :mod:`viquae_amd.encoders` (or anything with the same call surface); its
+``forward`` runs in HIP kernels.  The multimodal branch of the reference (ECA / ILF encoders fed
+with face and image features, :29-125,181-192) is outside this build and raises.
+"""
+import json
+
+import torch
+
+from ..utils import prepare_inputs
+
+
+def expand_query(batch, key="passage", kb=None, run=None, tokenizer=None, qe_predictions_key=None,
+                 doc_name_key="wikidata_label"):
+    """Optionally appends '[SEP] <name of the top-1 visual result / predicted entity>' to each text."""
+    assert run is None or qe_predictions_key is None
+    if run is not None:
+        texts = []
+        for text_input, q_id in zip(batch[key], batch["id"]):
+            doc_id = next(iter(run.run[q_id]))
+            texts.append(f"{text_input} {tokenizer.sep_token} {kb[int(doc_id)][doc_name_key]}")
+        return texts
+    if qe_predictions_key is not None:
+        return [f"{text_input} {tokenizer.sep_token} {doc_name}"
+                for text_input, doc_name in zip(batch[key], batch[qe_predictions_key])]
+    return batch[key]
+
+
+def is_multimodal(model):
+    cfg = getattr(model, "config", None)
+    return cfg is not None and type(cfg).__name__ == "MMConfig"
+
+
+def get_inputs(batch, model, tokenizer, tokenization_kwargs={}, key="passage", kb=None, run=None, qe_predictions_key=None):
+    if is_multimodal(model):
+        raise NotImplementedError("multimodal encoders (ECA/ILF) are outside the MI355X build (SURVEY.md section 2)")
+    text_inputs = expand_query(batch, key=key, kb=kb, run=run, tokenizer=tokenizer, qe_predictions_key=qe_predictions_key)
+    return tokenizer(text_inputs, **tokenization_kwargs)
+
+
+def embed(batch, model, tokenizer, tokenization_kwargs={}, key="passage", save_as="text_embedding", output_key=None,
+          forward_kwargs={}, layers=None, kb=None, call=None, run=None, qe_predictions_key=None):
+    """Tokenise ``batch[key]``, run the encoder, write ``batch[save_as]`` (numpy [B, H]).
+
+    ``output_key`` selects from dict/list/tuple outputs; ``layers`` dumps the first-token state of the
+    given layers into ``{save_as}_layer_{layer}`` (the model must then return per-layer states);
+    ``call`` names a method to call instead of ``model(...)`` (e.g. ``get_text_features``)."""
+    inputs = get_inputs(batch, model, tokenizer, tokenization_kwargs=tokenization_kwargs, key=key, kb=kb, run=run,
+                        qe_predictions_key=qe_predictions_key)
+    inputs = prepare_inputs(inputs, _model_device(model))
+    method = model if call is None else getattr(model, call)
+    with torch.no_grad():
+        outputs = method(**inputs, **forward_kwargs)
+    if isinstance(outputs, torch.Tensor):
+        output = outputs
+    elif isinstance(outputs, (dict, list, tuple)):
+        if output_key is None:
+            raise ValueError(f"You should set output_key to choose from the model's outputs (got {output_key})")
+        output = outputs[output_key]
+    else:
+        raise TypeError(f"Invalid type '{type(outputs)}' for model's outputs:\n{outputs}")
+    if layers is None:
+        batch[save_as] = output.cpu().numpy()
+    else:
+        for layer in layers:
+            batch[f"{save_as}_layer_{layer}"] = output[layer][:, 0].cpu().numpy()
+    return batch
+
+
+def _model_device(model):
+    for t in list(getattr(model, "buffers", lambda: [])()) + list(getattr(model, "parameters", lambda: [])()):
+        return t.device
+    return None
+
+
+def dataset_embed(dataset_path, map_kwargs={}, output_path=None, keep_columns=None, run=None, qe_predictions=None,
+                  qe_predictions_key=None, **fn_kwargs):
+    """load_from_disk -> Dataset.map(embed, batched=True) -> save_to_disk."""
+    from datasets import DatasetDict, load_from_disk
+    dataset = load_from_disk(dataset_path)
+    if output_path is None:
+        output_path = dataset_path
+        assert keep_columns is None, f"You probably don't want to overwrite {dataset_path} by keeping only {keep_columns}"
+    elif keep_columns is not None:
+        keep_columns = set(keep_columns)
+        dataset = dataset.remove_columns([c for c in dataset.column_names if c not in keep_columns])
+    if run is not None:
+        raise NotImplementedError("query expansion from a ranx Run needs ranx (not installed); pass qe_predictions instead")
+    if qe_predictions is not None:
+        assert qe_predictions_key is not None
+        with open(qe_predictions, "rt") as file:
+            qe_predictions = json.load(file)
+        if isinstance(dataset, DatasetDict):
+            raise NotImplementedError("The format of predictions saved in trainee are not compatible with a DatasetDict")
+        dataset = dataset.add_column(qe_predictions_key, qe_predictions)
+    fn_kwargs["run"] = run
+    fn_kwargs["qe_predictions_key"] = qe_predictions_key
+    dataset = dataset.map(embed, batched=True, fn_kwargs=fn_kwargs, **map_kwargs)
+    return _save(dataset, dataset_path, output_path)
+
+
+
+def _save(dataset, dataset_path, output_path):
+    """``save_to_disk``; the reference's default is to overwrite the input dataset, which recent
+    ``datasets`` refuses to do in place ("a dataset can't overwrite itself"): write next to it, then swap."""
+    import os
+    import shutil
+    from datasets import load_from_disk
+    if os.path.abspath(str(output_path)) != os.path.abspath(str(dataset_path)):
+        dataset.save_to_disk(output_path)
+        return dataset
+    tmp = str(output_path).rstrip("/") + ".mq_tmp"
+    shutil.rmtree(tmp, ignore_errors=True)
+    dataset.save_to_disk(tmp)
+    del dataset
+    shutil.rmtree(output_path)
+    os.rename(tmp, output_path)
+    return load_from_disk(output_path)
+
+def main(dataset_path, config_path, kb_path=None, output_path=None):
+    """The reference's ``python -m meerqat.ir.embedding <dataset> <config> [--kb --output]``."""
+    from datasets import load_from_disk
+    from ..data.loading import load_pretrained_in_kwargs
+    from ..utils import device
+    with open(config_path, "rt") as file:
+        config = load_pretrained_in_kwargs(json.load(file))
+    tok = dict(return_tensors="pt", padding="max_length", truncation=True)
+    tok.update(config.get("tokenization_kwargs", {}))
+    config["tokenization_kwargs"] = tok
+    model = config.pop("model").to(device).eval()
+    # the reference wraps the model in nn.DataParallel when several GPUs are visible
+    # (ir/embedding.py:287-288); here one process drives one GPU and rows are split across ranks
+    kb = None
+    if kb_path:
+        kb = load_from_disk(kb_path)
+        kb = kb.remove_columns([c for c in kb.column_names if c not in {"wikidata_label"}])
+    return dataset_embed(dataset_path, model=model, kb=kb, output_path=output_path, **config)
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description="embed a dataset column with a HIP-backed encoder")
+    ap.add_argument("dataset")
+    ap.add_argument("config")
+    ap.add_argument("--kb")
+    ap.add_argument("--output")
+    ap.add_argument("--disable_caching", action="store_true")
+    a = ap.parse_args()
+    if a.disable_caching:
+        import datasets
+        datasets.disable_caching()
+    main(a.dataset, a.config, a.kb, a.output)
