@@ -1,0 +1,24 @@
+"""Cycle accounting of knn_scan_kernel (needs a -DMQ_TIMING build: MEERQAT_HIP_LIB=ab/lib_timing.so)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from viquae_amd import _lib
+from viquae_amd.index import MI355XFlatIndex
+
+N, d, nq, k = 1_500_000, 768, 4096, 100
+dev = torch.device("cuda")
+idx = MI355XFlatIndex(string_factory="Flat", metric_type=0)
+g = torch.Generator(device=dev); g.manual_seed(0)
+for s in range(0, N, 1 << 16):
+    idx.add(torch.randn((min(1 << 16, N - s), d), generator=g, device=dev), total_hint=N)
+Q = torch.randn((nq, d), generator=g, device=dev)
+dbg = torch.zeros(256 * 16 * 4, dtype=torch.int64, device=dev)
+os.environ["MQ_DBG_PTR"] = str(dbg.data_ptr())
+idx.search_device(Q, k); torch.cuda.synchronize()
+dbg.zero_()
+idx.search_device(Q, k); torch.cuda.synchronize()
+t = dbg.view(256, 16, 4).double()
+tot = t.sum(-1)
+print("per-wave total cycles: mean %.3e min %.3e max %.3e" % (tot.mean(), tot.min(), tot.max()))
+for i, name in enumerate(["K loop", "scan+append", "barrier", "compaction"]):
+    print(f"{name:12s} mean {t[..., i].mean():.3e} ({100 * t[..., i].mean() / tot.mean():.2f} %)  max-wave {t[..., i].max():.3e}")

@@ -40,17 +40,16 @@ constexpr int BK = 16;      // k-depth of one LDS stage
 constexpr int TQ = 256;     // queries per workgroup tile
 constexpr int TN = 256;     // KB rows per chunk
 constexpr int NWAVES = 16;  // 4 (row panels) x 4 (query panels), one 64x64 sub-tile per wave
-constexpr int CAND = 32;    // candidate slots per query between two list merges
-constexpr int FLUSH_AT = 24;
-constexpr int KCAP = MQ_KNN_MAX_K;  // list scratch per wave
+constexpr int NSTAGE = 3;   // LDS ring depth of the operand tiles
+constexpr int POOL = 512;   // per-(query, slab) candidate pool in HBM: sorted top-k prefix + unsorted tail
+constexpr int PR = POOL / 64;  // pool keys per lane when one wave sorts a pool
 
 // LDS carve (bytes)
-constexpr int LDS_XS = 0;                              // [2][4][16][64] f32
-constexpr int LDS_QS = LDS_XS + 2 * 4 * BK * 64 * 4;   // [2][4][16][64] f32
-constexpr int LDS_CAND = LDS_QS + 2 * 4 * BK * 64 * 4; // [256][CAND] u64
-constexpr int LDS_SCRL = LDS_CAND + TQ * CAND * 8;     // [16][KCAP] u64
-constexpr int LDS_CNT = LDS_SCRL + NWAVES * KCAP * 8;  // cnt[256], cnt0[256], tau[256], qflag[256], wgflag[4]
-constexpr int LDS_TOTAL = LDS_CNT + 4 * TQ * 4 + 16;
+constexpr int LDS_XS = 0;                                   // [NSTAGE][4][16][64] f32
+constexpr int LDS_QS = LDS_XS + NSTAGE * 4 * BK * 64 * 4;   // [NSTAGE][4][16][64] f32
+constexpr int LDS_CNT = LDS_QS + NSTAGE * 4 * BK * 64 * 4;  // gcnt[256] int, tau[256] f32
+constexpr int LDS_TOTAL = LDS_CNT + 2 * TQ * 4;
+static_assert(MQ_KNN_MAX_K + TN <= POOL, "a compacted pool must take every row of one more chunk");
 
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
 
@@ -71,6 +70,13 @@ __device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// same piece with a wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: the per-step
+// address update is scalar arithmetic only
+__device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ unsigned key_row(u64 key) { return 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull); }
 
@@ -205,53 +211,145 @@ struct ScanArgs {
     const float* Qp;   // queries, panel layout (nqt * 4 panels)
     const float* xn;   // ||x||^2 per KB row (L2 only)
     const float* qn;   // ||q||^2 per query   (L2 only)
-    u64* lists;        // [nqt][S][256][k] sorted keys
+    u64* lists;        // [nqt][S][256][POOL] keys: after the scan, entries [0,k) are the sorted top-k
     long long N;
     int dpad, nqt, S, k, qpx;
     long long nchunks;
+    unsigned long long* dbg;  // MQ_TIMING builds only
 };
 
-// One wave merges the first n candidate keys of query q into its sorted list (global memory,
-// owned by this workgroup) and refreshes the query's threshold.
-__device__ __forceinline__ void flush_query(u64* __restrict__ Lg, const u64* __restrict__ B, int n, int k,
-                                            u64* __restrict__ sL, float* tau_q, int lane) {
-    const u64 l0 = (lane < k) ? Lg[lane] : 0ull;
-    const u64 l1 = (lane + 64 < k) ? Lg[lane + 64] : 0ull;
-    sL[lane] = l0;
-    sL[lane + 64] = l1;
-    const u64 mb = (lane < n) ? B[lane] : 0ull;
-    int cB = 0, c0 = 0, c1 = 0;
-    for (int j = 0; j < n; ++j) {
-        const u64 bj = B[j];
-        cB += (bj > mb);
-        c0 += (bj > l0);
-        c1 += (bj > l1);
+// ---- per-query candidate pool (HBM, owned by one workgroup) ------------------------------------
+// A candidate that beats the query's threshold tau is appended, unsorted, to the query's pool: slot
+// from an LDS atomic counter, one 8-byte global store.  A pool is COMPACTED only when another whole
+// chunk might not fit (count > POOL - TN): one wave bitonic-sorts its POOL keys in registers, keeps
+// the k best (written back sorted) and refreshes tau.  Between compactions tau is stale but valid
+// (the k-th best of a subset).  Each refill takes ~(POOL-TN-k)/k times more rows than the previous
+// one, so a pool is compacted a handful of times per slab, and the pool can never overflow: no
+// staging buffers, no overflow path, no re-scan of the accumulators.
+
+// wave-wide bitonic sort, descending, of 2 x 64 keys (element index = r*64 + lane): final ordering of a
+// compacted pool (k <= 128), once per query per slab
+__device__ __forceinline__ void sort128_desc(u64 (&v)[2], int lane) {
+#pragma unroll
+    for (int kk = 2; kk <= 128; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j >= 1; j >>= 1) {
+            if (j == 64) {
+                const u64 a = v[0], b = v[1];  // kk == 128: descending
+                v[0] = a > b ? a : b;
+                v[1] = a > b ? b : a;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const bool up = ((r * 64 + lane) & kk) != 0;
+                    const bool lower = (lane & j) == 0;
+                    const unsigned lo = __shfl_xor((unsigned)v[r], j);
+                    const unsigned hi = __shfl_xor((unsigned)(v[r] >> 32), j);
+                    const u64 o = ((u64)hi << 32) | lo;
+                    const bool take_max = (lower != up);
+                    v[r] = take_max ? (v[r] > o ? v[r] : o) : (v[r] < o ? v[r] : o);
+                }
+            }
+        }
     }
-    int lo = 0, hi = k;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (sL[mid] > mb) lo = mid + 1; else hi = mid;
-    }
-    const int pB = cB + lo;
-    const int p0 = lane + c0;
-    const int p1 = lane + 64 + c1;
-    if (mb != 0ull && pB < k) { Lg[pB] = mb; if (pB == k - 1) *tau_q = key_score(mb); }
-    if (l0 != 0ull && p0 < k) { Lg[p0] = l0; if (p0 == k - 1) *tau_q = key_score(l0); }
-    if (l1 != 0ull && p1 < k) { Lg[p1] = l1; if (p1 == k - 1) *tau_q = key_score(l1); }
 }
+
+// k-th largest of the wave's PR x 64 unique keys (k <= number of non-zero keys): bisection on the key
+// bits, high (score) word first with 32-bit compares; the low (row) word only matters when several
+// keys share the k-th score.
+__device__ __forceinline__ u64 wave_kth_largest(const u64 (&v)[PR], int k) {
+    unsigned hi[PR];
+#pragma unroll
+    for (int r = 0; r < PR; ++r) hi[r] = (unsigned)(v[r] >> 32);
+    unsigned Th = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = Th | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < PR; ++r) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(hi[r] >= cand));
+        if (c >= k) Th = cand;
+    }
+    int cgt = 0, ceq = 0;
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        cgt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(hi[r] > Th));
+        ceq += __builtin_popcountll(__builtin_amdgcn_ballot_w64(hi[r] == Th));
+    }
+    if (cgt + ceq == k) return (u64)Th << 32;  // every key of the k-th score is kept
+    const int need = k - cgt;                   // of the ceq keys with the k-th score, keep the `need` largest low words
+    unsigned Tl = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = Tl | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < PR; ++r)
+            c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(hi[r] == Th && (unsigned)v[r] >= cand));
+        if (c >= need) Tl = cand;
+    }
+    return ((u64)Th << 32) | Tl;
+}
+
+// Keep the k best of the pool's first g entries at [0,k) and refresh tau; returns the new count.
+// No sort: the k-th largest key T is found by bisection on the key bits (keys are unique, so exactly
+// k keys are >= T), survivors are packed with ballot prefix sums.  `sorted`: additionally order the
+// survivors best-first and zero-fill up to k (end of the slab).
+// The entries were stored by other waves of this workgroup: read them past the CU's L1 (agent-scope
+// relaxed loads are served by L2), after the caller's __syncthreads().
+__device__ __forceinline__ int compact_pool(u64* __restrict__ P, int g, int k, float* tau_q, int lane, bool sorted) {
+    u64 v[PR];
+#pragma unroll
+    for (int r = 0; r < PR; ++r)
+        v[r] = (r * 64 + lane < g) ? __hip_atomic_load(P + r * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    int ng = g;
+    if (g > k) {
+        const u64 T = wave_kth_largest(v, k);
+        // pack the k survivors to the front (order irrelevant)
+        int base = 0;
+        const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int r = 0; r < PR; ++r) {
+            const bool keep = v[r] >= T;
+            const u64 m = __builtin_amdgcn_ballot_w64(keep);
+            if (keep) P[base + __builtin_popcountll(m & lt)] = v[r];
+            base += __builtin_popcountll(m);
+        }
+        if (lane == 0) *tau_q = key_score(T);
+        ng = k;
+        if (!sorted) return ng;
+        // the packed survivors were written by this wave; re-read them (own stores, same wave: program order)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < PR; ++r)
+            v[r] = (r < 2 && r * 64 + lane < k) ? __hip_atomic_load(P + r * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+    if (sorted) {
+        u64 s2[2] = {v[0], v[1]};  // g <= k <= 128 or the packed survivors: everything lives in idx < 128
+        sort128_desc(s2, lane);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int idx = r * 64 + lane;
+            if (idx < k) P[idx] = s2[r];  // zeros (empty) sort last: slots >= ng are zero-filled
+        }
+    }
+    return ng;
+}
+
+#ifdef MQ_TIMING
+// cycle accounting per wave (tools/ only): [0] K loop, [1] scan+append, [2] barrier, [3] compaction
+#define MQ_T(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc_[i] += now_ - tlast_; tlast_ = now_; }
+#define MQ_T_DUMP if (lane == 0) { for (int i_ = 0; i_ < 4; ++i_) a.dbg[((size_t)blockIdx.x * NWAVES + w) * 4 + i_] = tacc_[i_]; }
+#else
+#define MQ_T(i)
+#define MQ_T_DUMP
+#endif
 
 template <int METRIC>
 __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Xs = reinterpret_cast<float*>(smem + LDS_XS);
     float* Qs = reinterpret_cast<float*>(smem + LDS_QS);
-    u64* cand = reinterpret_cast<u64*>(smem + LDS_CAND);
-    u64* scrL = reinterpret_cast<u64*>(smem + LDS_SCRL);
-    int* cnt = reinterpret_cast<int*>(smem + LDS_CNT);
-    int* cnt0 = cnt + TQ;
-    float* tau = reinterpret_cast<float*>(cnt0 + TQ);
-    int* qflag = reinterpret_cast<int*>(tau + TQ);
-    int* wgflag = qflag + TQ;
+    int* gcnt = reinterpret_cast<int*>(smem + LDS_CNT);
+    float* tau = reinterpret_cast<float*>(gcnt + TQ);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -275,25 +373,28 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
             qt = b % a.nqt;
         }
     }
-    const long long c0 = (a.nchunks * slab) / a.S;
-    const long long c1 = (a.nchunks * (slab + 1)) / a.S;
+    qt = __builtin_amdgcn_readfirstlane(qt);
+    slab = __builtin_amdgcn_readfirstlane(slab);
+    const int c0 = __builtin_amdgcn_readfirstlane((int)((a.nchunks * slab) / a.S));
+    const int c1 = __builtin_amdgcn_readfirstlane((int)((a.nchunks * (slab + 1)) / a.S));
     const int k = a.k;
-    u64* mylists = a.lists + ((size_t)qt * a.S + slab) * (size_t)TQ * k;
+    u64* mylists = a.lists + ((size_t)qt * a.S + slab) * (size_t)TQ * POOL;
 
-    for (int i = tid; i < TQ * k; i += 1024) mylists[i] = 0ull;
     if (tid < TQ) {
-        cnt[tid] = 0;
-        cnt0[tid] = 0;
+        gcnt[tid] = 0;
         tau[tid] = -INFINITY;
-        qflag[tid] = 0;
     }
-    if (tid == 0) wgflag[0] = 0;
 
     const int nkb = a.dpad / BK;
     const int pp = w >> 2, quarter = w & 3;
-    // per-lane DMA sources; LDS destination is wave-uniform base + lane*16 (hardware rule)
-    const float* qsrc0 = a.Qp + (((size_t)(qt * 4 + pp) * a.dpad + quarter * 4) * PANEL) + lane * 4;
+    // DMA addressing: per-lane byte offset (constant for the whole kernel, the same for the KB and the
+    // query operand) + wave-uniform base that advances by scalar arithmetic; LDS destination is
+    // wave-uniform base + lane*16 (hardware rule)
+    const unsigned dma_voff = (unsigned)((((size_t)pp * a.dpad + quarter * 4) * PANEL + lane * 4) * 4);
     const int lds_piece = pp * (BK * 64) + quarter * 256;
+    const char* const xbase0 = reinterpret_cast<const char*>(a.Xp);
+    const char* const qbase0 = reinterpret_cast<const char*>(a.Qp) + (size_t)qt * 4 * a.dpad * (PANEL * 4);
+    const unsigned chunk_bytes = (unsigned)(4 * a.dpad * (PANEL * 4));  // 4 panels (< 4 GiB: dpad < 2^20)
 
     // LDS-DMA (global_load_lds_dwordx4) issued from inline asm so that hipcc does not count it:
     // with the builtin it drains vmcnt(0) in front of the next ds_read and the prefetch of step t+1
@@ -301,11 +402,11 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
     // before the barrier that opens the step which reads the data).
     const unsigned lds_x = __builtin_amdgcn_readfirstlane(lds_addr(Xs + lds_piece));
     const unsigned lds_q = __builtin_amdgcn_readfirstlane(lds_addr(Qs + lds_piece));
-    auto issue = [&](long long c, int kb, int stage) __attribute__((always_inline)) {
-        const float* xsrc = a.Xp + (((size_t)(c * 4 + pp) * a.dpad + (size_t)kb * BK + quarter * 4) * PANEL) + lane * 4;
-        const float* qsrc = qsrc0 + (size_t)kb * BK * PANEL;
-        dma16(xsrc, lds_x + stage * (4096 * 4));
-        dma16(qsrc, lds_q + stage * (4096 * 4));
+    auto issue = [&](int c, int kb, int stage) __attribute__((always_inline)) {
+        const char* xb = xbase0 + (size_t)c * chunk_bytes + (size_t)kb * (BK * PANEL * 4);
+        const char* qb = qbase0 + (size_t)kb * (BK * PANEL * 4);
+        dma16s(xb, dma_voff, lds_x + stage * (4096 * 4));
+        dma16s(qb, dma_voff, lds_q + stage * (4096 * 4));
     };
 
     const int i2 = (lane & 31) * 2;
@@ -322,42 +423,95 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
 #pragma unroll
     for (int i_ = 0; i_ < MQ_PAD_NOPS; ++i_) asm volatile("s_nop 0");
 #endif
-    if (c0 < c1) issue(c0, 0, 0);
-    int stage = 0;
-
-    for (long long c = c0; c < c1; ++c) {
-        f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-        for (int kb = 0; kb < nkb; ++kb) {
-            // the DMA of this step has landed (vmcnt(0) precedes the barrier) and every wave is
-            // done reading the other stage
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (kb + 1 < nkb) issue(c, kb + 1, stage ^ 1);
-            else if (c + 1 < c1) issue(c + 1, 0, stage ^ 1);
-            const float* xs = Xs + stage * 4096 + wr * (BK * 64) + kh * 64 + i2;
-            const float* qs = Qs + stage * 4096 + wc * (BK * 64) + kh * 64 + i2;
-#pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                const float2 xa = *reinterpret_cast<const float2*>(xs + kk * 128);
-                const float2 qb = *reinterpret_cast<const float2*>(qs + kk * 128);
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, qb.x, acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, qb.y, acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, qb.x, acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, qb.y, acc11, 0, 0, 0);
-            }
-            stage ^= 1;
+    // Three-stage LDS ring, ONE barrier per K-step placed in the MIDDLE of the step's MFMA block:
+    //   step t:  MFMA kk=0..3 | vmcnt(0) + barrier + issue DMA(t+2) | MFMA kk=4..7 (+ first reads of step t+1)
+    // The barrier proves (a) every wave's DMA pieces of step t+1 have landed, (b) every wave is done
+    // with step t-1, whose stage DMA(t+2) overwrites.  Waves arrive with MFMAs queued on both sides
+    // of it and the operands of the next MFMAs already in registers, so the matrix pipe does not
+    // drain at the barrier (it did, ~19 % of the time, with the barrier at the step boundary).
+    int ci = c0;
+    int kbi = 0;
+    auto issue_next = [&](int stg) __attribute__((always_inline)) {
+        if (ci < c1) {
+            issue(ci, kbi, stg);
+            if (++kbi == nkb) { kbi = 0; ++ci; }
         }
+    };
+    issue_next(0);
+    issue_next(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    int xoff = wr * (BK * 64) + kh * 64 + i2;
+    int qoff = wc * (BK * 64) + kh * 64 + i2;
+#define MQ_LD2(p) (*reinterpret_cast<const float2*>(p))
+#define MQ_M4(X, Q)                                                          \
+    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(X.x, Q.x, acc00, 0, 0, 0);  \
+    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(X.x, Q.y, acc01, 0, 0, 0);  \
+    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(X.y, Q.x, acc10, 0, 0, 0);  \
+    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(X.y, Q.y, acc11, 0, 0, 0);
+    float2 fx0 = MQ_LD2(Xs + xoff), fq0 = MQ_LD2(Qs + qoff);
+    float2 fx1 = MQ_LD2(Xs + xoff + 128), fq1 = MQ_LD2(Qs + qoff + 128);
 
+#ifdef MQ_TIMING
+    unsigned long long tacc_[4] = {0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
+#endif
+    for (int c = c0; c < c1; ++c) {
+        f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+        // pin the fragment offsets in registers HERE: if they are reloaded from a spill slot inside the
+        // K loop, hipcc's vmcnt(0) for that reload also drains the LDS-DMA prefetch half a step early
+        asm volatile("" : "+v"(xoff), "+v"(qoff));
+        for (int kb = 0; kb < nkb; ++kb) {
+            const float* xs = Xs + cur * 4096 + xoff;
+            const float* qs = Qs + cur * 4096 + qoff;
+            const float2 fx2 = MQ_LD2(xs + 2 * 128), fq2 = MQ_LD2(qs + 2 * 128);
+            MQ_M4(fx0, fq0)
+            const float2 fx3 = MQ_LD2(xs + 3 * 128), fq3 = MQ_LD2(qs + 3 * 128);
+            MQ_M4(fx1, fq1)
+            const float2 fx4 = MQ_LD2(xs + 4 * 128), fq4 = MQ_LD2(qs + 4 * 128);
+            MQ_M4(fx2, fq2)
+            const float2 fx5 = MQ_LD2(xs + 5 * 128), fq5 = MQ_LD2(qs + 5 * 128);
+            MQ_M4(fx3, fq3)
+            // raw s_barrier, no fence: __syncthreads() would also wait lgkmcnt(0), i.e. park every wave
+            // until its just-issued fragment reads return -- 16 waves' reads in lockstep are a ~500-cycle
+            // LDS burst during which the matrix pipe starves.  The only cross-wave facts needed here are
+            // the DMA landing (vmcnt) and program order; the empty asm statements keep hipcc from moving
+            // LDS accesses across the barrier.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_next(cur >= 1 ? cur - 1 : 2);  // stage (cur + 2) % 3
+            const float2 fx6 = MQ_LD2(xs + 6 * 128), fq6 = MQ_LD2(qs + 6 * 128);
+            MQ_M4(fx4, fq4)
+            const float2 fx7 = MQ_LD2(xs + 7 * 128), fq7 = MQ_LD2(qs + 7 * 128);
+            MQ_M4(fx5, fq5)
+            cur = cur == 2 ? 0 : cur + 1;
+            const float* xn_ = Xs + cur * 4096 + xoff;
+            const float* qn_ = Qs + cur * 4096 + qoff;
+            fx0 = MQ_LD2(xn_); fq0 = MQ_LD2(qn_);
+            MQ_M4(fx6, fq6)
+            fx1 = MQ_LD2(xn_ + 128); fq1 = MQ_LD2(qn_ + 128);
+            MQ_M4(fx7, fq7)
+        }
+#undef MQ_M4
+#undef MQ_LD2
+
+#ifdef MQ_ABLATE_NO_EPILOGUE
+        // timing ablation only (tools/): keeps the accumulators live, skips the selection
+        asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11));
+        continue;
+#endif
         // ---------------- selection epilogue ----------------
         // C/D map of 32x32x2: column j = lane&31 (query 2j+b of the wave's panel),
         // row i' = (reg&3) + 8*(reg>>2) + 4*(lane>>5)  (KB row 2i'+a of the wave's panel)
-        const long long rowbase = c * TN + wr * 64 + 8 * kh;
-        const bool ragged = (c + 1) * (long long)TN > a.N;
+        const unsigned rowbase = (unsigned)c * TN + wr * 64 + 8 * kh;
+        const unsigned nrows = (unsigned)a.N;
+        const bool ragged = ((long long)c + 1) * TN > a.N;
 
         if (METRIC == MQ_METRIC_L2) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const long long r0 = rowbase + 2 * ((reg & 3) + 8 * (reg >> 2));
+                const unsigned r0 = rowbase + 2 * ((reg & 3) + 8 * (reg >> 2));
                 const float2 xn2 = *reinterpret_cast<const float2*>(a.xn + r0);  // rows r0, r0+1 (padded alloc)
                 float d;
                 d = (qn0 + xn2.x) - 2.0f * acc00[reg]; acc00[reg] = -(d < 0.f ? 0.f : d);
@@ -367,74 +521,51 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
             }
         }
 
-        // sub = -1: all registers, all queries; sub >= 0: only registers with (reg>>1)==sub and only
-        // queries being re-done after an overflow
-        auto scan_acc = [&](int sub) __attribute__((always_inline)) {
+        // append every score that beats the query's threshold (strict: an equal score from a later row
+        // never displaces an earlier id, like FAISS's heap)
+        MQ_T(0)
+        {
             const float t0 = tau[q0], t1 = tau[q1];
-            const bool do0 = sub < 0 || qflag[q0] == 2;
-            const bool do1 = sub < 0 || qflag[q1] == 2;
+            u64* P0 = mylists + (size_t)q0 * POOL;
+            u64* P1 = P0 + POOL;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                if (sub >= 0 && (reg >> 1) != sub) continue;
-                const long long r0 = rowbase + 2 * ((reg & 3) + 8 * (reg >> 2));
-                const bool v0 = !ragged || r0 < a.N;
-                const bool v1 = !ragged || r0 + 1 < a.N;
+                const unsigned r0 = rowbase + 2 * ((reg & 3) + 8 * (reg >> 2));
+                const bool v0 = !ragged || r0 < nrows;
+                const bool v1 = !ragged || r0 + 1 < nrows;
                 const float g00 = acc00[reg], g01 = acc01[reg], g10 = acc10[reg], g11 = acc11[reg];
-                const bool p00 = do0 && v0 && g00 > t0;
-                const bool p01 = do1 && v0 && g01 > t1;
-                const bool p10 = do0 && v1 && g10 > t0;
-                const bool p11 = do1 && v1 && g11 > t1;
+                const bool p00 = v0 && g00 > t0;
+                const bool p01 = v0 && g01 > t1;
+                const bool p10 = v1 && g10 > t0;
+                const bool p11 = v1 && g11 > t1;
                 if (__builtin_amdgcn_ballot_w64(p00 || p01 || p10 || p11) == 0ull) continue;
-                if (p00) { const int s = atomicAdd(&cnt[q0], 1); if (s < CAND) cand[q0 * CAND + s] = make_key(g00, (unsigned)r0); }
-                if (p01) { const int s = atomicAdd(&cnt[q1], 1); if (s < CAND) cand[q1 * CAND + s] = make_key(g01, (unsigned)r0); }
-                if (p10) { const int s = atomicAdd(&cnt[q0], 1); if (s < CAND) cand[q0 * CAND + s] = make_key(g10, (unsigned)(r0 + 1)); }
-                if (p11) { const int s = atomicAdd(&cnt[q1], 1); if (s < CAND) cand[q1 * CAND + s] = make_key(g11, (unsigned)(r0 + 1)); }
+                if (p00) P0[atomicAdd(&gcnt[q0], 1)] = make_key(g00, r0);
+                if (p01) P1[atomicAdd(&gcnt[q1], 1)] = make_key(g01, r0);
+                if (p10) P0[atomicAdd(&gcnt[q0], 1)] = make_key(g10, r0 + 1);
+                if (p11) P1[atomicAdd(&gcnt[q1], 1)] = make_key(g11, r0 + 1);
             }
-        };
-
-        scan_acc(-1);
-        __syncthreads();
-        if (tid < TQ) {
-            const int cq = cnt[tid];
-            int f = 0;
-            if (cq > CAND) f = 2;                                    // overflow: roll this chunk back, merge, re-do
-            else if (cq >= FLUSH_AT || (c + 1 == c1 && cq > 0)) f = 1;  // nearly full (or end of slab): merge
-            qflag[tid] = f;
-            if (f) atomicOr(&wgflag[0], f);
-            else cnt0[tid] = cq;
         }
-        __syncthreads();
-        const int wf = wgflag[0];
-        if (wf) {
-            for (int j = 0; j < TQ / NWAVES; ++j) {
-                const int q = w + NWAVES * j;
-                const int f = __builtin_amdgcn_readfirstlane(qflag[q]);
-                if (f) {
-                    const int n = __builtin_amdgcn_readfirstlane((f == 2) ? cnt0[q] : cnt[q]);
-                    flush_query(mylists + (size_t)q * k, cand + q * CAND, n, k, scrL + w * KCAP, &tau[q], lane);
-                    if (lane == 0) { cnt[q] = 0; cnt0[q] = 0; }
-                }
+        MQ_T(1)
+        __syncthreads();  // appended keys are in L2 (vmcnt(0) precedes the barrier), counters final
+        MQ_T(2)
+#ifdef MQ_ABLATE_NO_FLUSH
+        if (tid < TQ) gcnt[tid] = 0;  // timing ablation only: drop the candidates
+        continue;
+#endif
+        const bool last = (c + 1 == c1);
+        for (int j = 0; j < TQ / NWAVES; ++j) {
+            const int q = w + NWAVES * j;
+            const int g = __builtin_amdgcn_readfirstlane(gcnt[q]);
+            if (g > POOL - TN || last) {
+                u64* P = mylists + (size_t)q * POOL;
+                const int ng = compact_pool(P, g, k, &tau[q], lane, last);
+                if (lane == 0) gcnt[q] = ng;
             }
-            __syncthreads();
-            if (wf & 2) {
-                for (int sub = 0; sub < 8; ++sub) {
-                    scan_acc(sub);  // <= 2 regs x 2 rows x 2 halves x 4 row panels = 32 = CAND appends per query
-                    __syncthreads();
-                    for (int j = 0; j < TQ / NWAVES; ++j) {
-                        const int q = w + NWAVES * j;
-                        const int n = __builtin_amdgcn_readfirstlane(qflag[q] == 2 ? cnt[q] : 0);
-                        if (n > 0) {
-                            flush_query(mylists + (size_t)q * k, cand + q * CAND, n, k, scrL + w * KCAP, &tau[q], lane);
-                            if (lane == 0) cnt[q] = 0;
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
-            if (tid == 0) wgflag[0] = 0;
-            __syncthreads();
         }
+        // tau / gcnt updates are ordered before their next use by the barriers of the next chunk's K loop
+        MQ_T(3)
     }
+    MQ_T_DUMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -497,7 +628,7 @@ __global__ __launch_bounds__(128) void slab_merge_kernel(const u64* __restrict__
     const int q = blockIdx.x;
     const int qt = q / TQ, ql = q % TQ;
     auto fetch = [&](int s, int t) {
-        const u64 key = lists[(((size_t)qt * S + s) * TQ + ql) * (size_t)k + t];
+        const u64 key = lists[(((size_t)qt * S + s) * TQ + ql) * (size_t)POOL + t];
         Ent e;
         e.g = key_score(key);
         e.id = key ? (long long)key_row(key) : -1;
@@ -608,7 +739,7 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
     g.off_qp = o;    o += (size_t)g.nqpad * g.dpad * 4;
     g.off_qn = o;    o += (size_t)g.nqpad * 4;
     g.off_qtmp = o;  o += (size_t)round_up((int64_t)(nq > 0 ? nq : 1) * d * 4, 256);
-    g.off_lists = o; o += (size_t)g.nqt * g.S * TQ * (size_t)k * 8;
+    g.off_lists = o; o += (size_t)g.nqt * g.S * TQ * (size_t)POOL * 8;
     g.total = round_up((int64_t)o, 256);
     return g;
 }
@@ -717,7 +848,7 @@ static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int
     if (N > 0) {
         ScanArgs a;
         a.Xp = packed_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = lists;
-        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx;
+        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = (unsigned long long*)getenv("MQ_DBG_PTR") ? (unsigned long long*)strtoull(getenv("MQ_DBG_PTR"), nullptr, 0) : nullptr;
         const dim3 grid((unsigned)(g.nqt * g.S)), block(1024);
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
         if (metric == MQ_METRIC_IP) {
@@ -730,7 +861,7 @@ static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int
         MQ_HIP(hipGetLastError());
         if (ev_scan_end) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_end, st));
     } else {
-        MQ_HIP(hipMemsetAsync(lists, 0, (size_t)g.nqt * g.S * TQ * (size_t)k * 8, st));
+        MQ_HIP(hipMemsetAsync(lists, 0, (size_t)g.nqt * g.S * TQ * (size_t)POOL * 8, st));
     }
     if (metric == MQ_METRIC_IP)
         hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, st, lists, nq, g.S, k,
