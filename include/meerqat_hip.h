@@ -89,6 +89,30 @@ int mq_knn_search_f32_ev(const float *packed_dev, const float *sqnorm_dev, int64
                          int64_t *I_dev, void *ws_dev, size_t ws_bytes, void *stream, void *ev_scan_begin,
                          void *ev_scan_end);
 
+/* ---------------------------------------------------------------------------------------------
+ * Screened search: SAME exact result as mq_knn_search_f32 (inner product), computed as a bf16
+ * screening scan over a bf16 copy of the shard + exact fp32 re-scoring of the few survivors
+ * (csrc/knn_screen.inc states the error bound that makes the screen lossless).  Extra shard buffers:
+ *   rowmajor_dev [N, d] fp32  : the stored rows in row-major order (re-scoring operand)
+ *   bf16_dev                  : mq_knn_screen_bytes(N, d) bytes, bf16 copy (rows padded to 256, d to 64)
+ *   xmax2_dev                 : one float, max ||x||^2 over the shard (max of sqnorm_dev[0..N))
+ * mq_knn_screen_prepare fills rowmajor/bf16 for rows [row_offset, row_offset+n) from the panel buffer.
+ * Query tiles whose bounded candidate buffers overflow are recomputed by the exact scan inside the
+ * same call.  Workspace: mq_knn_workspace_bytes (covers both paths).
+ * ------------------------------------------------------------------------------------------- */
+size_t mq_knn_screen_bytes(int64_t n_rows, int d);
+int mq_knn_screen_prepare(const float *packed_dev, int64_t capacity_rows, int d, int64_t row_offset, int64_t n,
+                          float *rowmajor_dev, uint16_t *bf16_dev, void *stream);
+int mq_knn_search_screened_f32(const float *packed_dev, const float *sqnorm_dev, const float *rowmajor_dev,
+                               const uint16_t *bf16_dev, const float *xmax2_dev, int64_t N, int d,
+                               const float *queries_dev, int nq, int k, int l2norm_queries, int64_t id_offset,
+                               float *D_dev, int64_t *I_dev, void *ws_dev, size_t ws_bytes, void *stream,
+                               void *ev_scan_begin, void *ev_scan_end);
+/* Telemetry of the last screened search held in ws_dev (synchronises the stream): out[0] = query
+ * tiles recomputed by the exact scan, out[1] = candidates re-scored in total, out[2] = max per query,
+ * out[3] / out[4] = max / total slab-pool entries, out[5] = max margin (1e-6 units), out[6] = slabs. */
+int mq_knn_screen_stats(int64_t N, int d, int nq, int k, const void *ws_dev, int64_t out[8], void *stream);
+
 /* Name and launch geometry of the scan kernel for the given problem (for bench.py / profiles):
  * out[0]=workgroups, out[1]=threads per workgroup, out[2]=LDS bytes, out[3]=query tiles,
  * out[4]=KB slabs, out[5]=KB chunks (256 rows each). */

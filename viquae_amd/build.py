@@ -28,7 +28,7 @@ def needs_build():
     so_m = os.path.getmtime(SO)
     deps = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps.append(os.path.join(HERE, "..", "include", "meerqat_hip.h"))
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc"))]
     return any(os.path.getmtime(d) > so_m for d in deps)
 
 

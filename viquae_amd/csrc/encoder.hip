@@ -35,10 +35,11 @@ typedef __attribute__((address_space(3))) char lds_char;
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(unsigned long)(lds_char*)p; }
 // one 1-KiB LDS-DMA piece: LDS destination = lds_dst (wave-uniform) + lane*16, global source per lane.
 // Issued from inline asm so hipcc does not drain it in front of the next ds_read (see knn.hip).
-__device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_dst) {
+// wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: the per-step update is scalar
+__device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -47,7 +48,8 @@ __device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_dst) {
 constexpr int GT = 256;   // tile edge (rows of A and rows of W per workgroup)
 constexpr int GBK = 16;   // k-depth per LDS stage: one 64-byte row segment per tile row
 constexpr int G_STAGE_FLOATS = GT * GBK;            // one operand, one stage
-constexpr int G_LDS_BYTES = 2 * 2 * G_STAGE_FLOATS * 4;  // A and W, two stages = 64 KiB
+constexpr int G_NSTAGE = 3;                         // LDS ring depth
+constexpr int G_LDS_BYTES = G_NSTAGE * 2 * G_STAGE_FLOATS * 4;  // A and W, three stages = 96 KiB
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_QUICKGELU = 3, EPI_BIAS_RESIDUAL = 4 };
 
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel(const float* __restrict__
                                                        float* __restrict__ C, int M, int N, int K, int ntm, int ntn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);
-    float* Ws = As + 2 * G_STAGE_FLOATS;
+    float* Ws = As + G_NSTAGE * G_STAGE_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -83,17 +85,26 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel(const float* __restrict__
             nt = b % ntn;
         }
     }
+    mt = __builtin_amdgcn_readfirstlane(mt);
+    nt = __builtin_amdgcn_readfirstlane(nt);
     const int m0 = mt * GT, n0 = nt * GT;
 
-    // DMA: wave w moves rows [16w, 16w+16) of both operand tiles; lane -> (row 16w + lane/4, chunk lane%4)
+    // DMA: wave w moves rows [16w, 16w+16) of both operand tiles; lane -> (row 16w + lane/4, chunk lane%4).
+    // Source = wave-uniform tile base (advances 64 B per K step, scalar) + per-lane byte offset (constant).
     const int drow = 16 * w + (lane >> 2);
     const int dchunk = (lane & 3) ^ ((drow >> 2) & 3);
     int am = m0 + drow; if (am > M - 1) am = M - 1;
     int wn = n0 + drow; if (wn > N - 1) wn = N - 1;
-    const float* asrc = A + (size_t)am * K + dchunk * 4;
-    const float* wsrc = W + (size_t)wn * K + dchunk * 4;
+    const unsigned a_voff = (unsigned)(((size_t)(am - m0) * K + dchunk * 4) * 4);
+    const unsigned w_voff = (unsigned)(((size_t)(wn - n0) * K + dchunk * 4) * 4);
+    const char* const abase = reinterpret_cast<const char*>(A + (size_t)m0 * K);
+    const char* const wbase = reinterpret_cast<const char*>(W + (size_t)n0 * K);
     const unsigned lds_a = __builtin_amdgcn_readfirstlane(lds_addr_of(As + 16 * w * GBK));
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_addr_of(Ws + 16 * w * GBK));
+    auto issue = [&](int kb, int stg) __attribute__((always_inline)) {
+        dma16s(abase + (size_t)kb * (GBK * 4), a_voff, lds_a + stg * (G_STAGE_FLOATS * 4));
+        dma16s(wbase + (size_t)kb * (GBK * 4), w_voff, lds_w + stg * (G_STAGE_FLOATS * 4));
+    };
 
     // fragment reads: lane (i = lane&31, kh = lane>>5) reads chunk (2j+kh) of row (64*wr + 32a + i)
     const int i = lane & 31, kh = lane >> 5;
@@ -103,42 +114,45 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel(const float* __restrict__
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
     const int nk = K / GBK;
-    dma16(asrc, lds_a);
-    dma16(wsrc, lds_w);
-    int stage = 0;
-    for (int kb = 0; kb < nk; ++kb) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kb + 1 < nk) {
-            dma16(asrc + (size_t)(kb + 1) * GBK, lds_a + (stage ^ 1) * (G_STAGE_FLOATS * 4));
-            dma16(wsrc + (size_t)(kb + 1) * GBK, lds_w + (stage ^ 1) * (G_STAGE_FLOATS * 4));
-        }
-        const float* as = As + stage * G_STAGE_FLOATS + arow;
-        const float* ws = Ws + stage * G_STAGE_FLOATS + brow;
-        const float4 a0j0 = *reinterpret_cast<const float4*>(as + c0);
-        const float4 a1j0 = *reinterpret_cast<const float4*>(as + 32 * GBK + c0);
-        const float4 b0j0 = *reinterpret_cast<const float4*>(ws + c0);
-        const float4 b1j0 = *reinterpret_cast<const float4*>(ws + 32 * GBK + c0);
-        const float4 a0j1 = *reinterpret_cast<const float4*>(as + c1);
-        const float4 a1j1 = *reinterpret_cast<const float4*>(as + 32 * GBK + c1);
-        const float4 b0j1 = *reinterpret_cast<const float4*>(ws + c1);
-        const float4 b1j1 = *reinterpret_cast<const float4*>(ws + 32 * GBK + c1);
+    // Three-stage ring, one raw barrier per K step in the MIDDLE of the step's MFMA block (see knn.hip)
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#define MQ_LD4(p) (*reinterpret_cast<const float4*>(p))
 #define MQ_MFMA4(A0, A1, B0, B1, E)                                            \
         acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.E, B0.E, acc00, 0, 0, 0); \
         acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.E, B1.E, acc01, 0, 0, 0); \
         acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.E, B0.E, acc10, 0, 0, 0); \
         acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.E, B1.E, acc11, 0, 0, 0);
+    float4 a0j0 = MQ_LD4(As + arow + c0), a1j0 = MQ_LD4(As + arow + 32 * GBK + c0);
+    float4 b0j0 = MQ_LD4(Ws + brow + c0), b1j0 = MQ_LD4(Ws + brow + 32 * GBK + c0);
+    int cur = 0;
+    for (int kb = 0; kb < nk; ++kb) {
+        const float* as = As + cur * G_STAGE_FLOATS + arow;
+        const float* ws = Ws + cur * G_STAGE_FLOATS + brow;
+        const float4 a0j1 = MQ_LD4(as + c1), a1j1 = MQ_LD4(as + 32 * GBK + c1);
+        const float4 b0j1 = MQ_LD4(ws + c1), b1j1 = MQ_LD4(ws + 32 * GBK + c1);
         MQ_MFMA4(a0j0, a1j0, b0j0, b1j0, x)
         MQ_MFMA4(a0j0, a1j0, b0j0, b1j0, y)
         MQ_MFMA4(a0j0, a1j0, b0j0, b1j0, z)
         MQ_MFMA4(a0j0, a1j0, b0j0, b1j0, w)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kb + 2 < nk) issue(kb + 2, cur >= 1 ? cur - 1 : 2);
+        cur = cur == 2 ? 0 : cur + 1;
+        const float* an = As + cur * G_STAGE_FLOATS + arow;
+        const float* wn_ = Ws + cur * G_STAGE_FLOATS + brow;
+        a0j0 = MQ_LD4(an + c0); a1j0 = MQ_LD4(an + 32 * GBK + c0);
+        b0j0 = MQ_LD4(wn_ + c0); b1j0 = MQ_LD4(wn_ + 32 * GBK + c0);
         MQ_MFMA4(a0j1, a1j1, b0j1, b1j1, x)
         MQ_MFMA4(a0j1, a1j1, b0j1, b1j1, y)
         MQ_MFMA4(a0j1, a1j1, b0j1, b1j1, z)
         MQ_MFMA4(a0j1, a1j1, b0j1, b1j1, w)
-#undef MQ_MFMA4
-        stage ^= 1;
     }
+#undef MQ_MFMA4
+#undef MQ_LD4
 
     // epilogue: C/D map of 32x32x2: col j = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int nb0 = n0 + 64 * wc + i, nb1 = nb0 + 32;

@@ -216,6 +216,7 @@ struct ScanArgs {
     int dpad, nqt, S, k, qpx;
     long long nchunks;
     unsigned long long* dbg;  // MQ_TIMING builds only
+    const int* only;          // optional [nqt] flags: scan only the flagged query tiles (fallback of the screened path)
 };
 
 // ---- per-query candidate pool (HBM, owned by one workgroup) ------------------------------------
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
     }
     qt = __builtin_amdgcn_readfirstlane(qt);
     slab = __builtin_amdgcn_readfirstlane(slab);
+    if (a.only && a.only[qt] == 0) return;
     const int c0 = __builtin_amdgcn_readfirstlane((int)((a.nchunks * slab) / a.S));
     const int c1 = __builtin_amdgcn_readfirstlane((int)((a.nchunks * (slab + 1)) / a.S));
     const int k = a.k;
@@ -623,9 +625,10 @@ __device__ __forceinline__ void merge_lists(int nlists, int k, Fetch fetch, Ent*
 template <int METRIC>
 __global__ __launch_bounds__(128) void slab_merge_kernel(const u64* __restrict__ lists, int nq, int S, int k,
                                                          long long id_offset, float* __restrict__ D,
-                                                         long long* __restrict__ I) {
+                                                         long long* __restrict__ I, const int* __restrict__ only) {
     __shared__ Ent Ra[128], Rb[128], Ls[128];
     const int q = blockIdx.x;
+    if (only && only[q / TQ] == 0) return;
     const int qt = q / TQ, ql = q % TQ;
     auto fetch = [&](int s, int t) {
         const u64 key = lists[(((size_t)qt * S + s) * TQ + ql) * (size_t)POOL + t];
@@ -672,6 +675,8 @@ __global__ __launch_bounds__(128) void shard_merge_kernel(const float* __restric
     }
 }
 
+#include "knn_screen.inc"
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -703,6 +708,9 @@ struct Geometry {
     int nqt, S, dpad, qpx;
     int64_t nqpad, nchunks;
     size_t off_qp, off_qn, off_qtmp, off_lists, total;
+    // screened path extras
+    int dp;
+    size_t off_qb, off_margin, off_pcount, off_ovf, off_gthr, off_cand, off_ckeys, off_ccount;
 };
 
 Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
@@ -739,7 +747,17 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
     g.off_qp = o;    o += (size_t)g.nqpad * g.dpad * 4;
     g.off_qn = o;    o += (size_t)g.nqpad * 4;
     g.off_qtmp = o;  o += (size_t)round_up((int64_t)(nq > 0 ? nq : 1) * d * 4, 256);
-    g.off_lists = o; o += (size_t)g.nqt * g.S * TQ * (size_t)POOL * 8;
+    g.off_lists = o; o += (size_t)g.nqt * g.S * TQ * (size_t)SPOOL * 8;  // SPOOL >= POOL: shared by both paths
+    g.dp = (int)round_up(d, SBK);
+    const size_t nq1 = (size_t)(nq > 0 ? nq : 1);
+    g.off_qb = o;     o += (size_t)round_up((int64_t)g.nqpad * g.dp * 2, 256);
+    g.off_margin = o; o += (size_t)g.nqpad * 4;
+    g.off_pcount = o; o += (size_t)g.nqt * g.S * TQ * 4;
+    g.off_ovf = o;    o += (size_t)round_up((int64_t)g.nqt * 4, 256);
+    g.off_gthr = o;   o += (size_t)g.nqpad * 4;
+    g.off_cand = o;   o += nq1 * RMAX * 4;
+    g.off_ckeys = o;  o += nq1 * RMAX * 8;
+    g.off_ccount = o; o += (size_t)round_up((int64_t)nq1 * 4, 256);
     g.total = round_up((int64_t)o, 256);
     return g;
 }
@@ -848,7 +866,7 @@ static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int
     if (N > 0) {
         ScanArgs a;
         a.Xp = packed_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = lists;
-        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = (unsigned long long*)getenv("MQ_DBG_PTR") ? (unsigned long long*)strtoull(getenv("MQ_DBG_PTR"), nullptr, 0) : nullptr;
+        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = (unsigned long long*)getenv("MQ_DBG_PTR") ? (unsigned long long*)strtoull(getenv("MQ_DBG_PTR"), nullptr, 0) : nullptr; a.only = nullptr;
         const dim3 grid((unsigned)(g.nqt * g.S)), block(1024);
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
         if (metric == MQ_METRIC_IP) {
@@ -865,10 +883,10 @@ static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int
     }
     if (metric == MQ_METRIC_IP)
         hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, st, lists, nq, g.S, k,
-                           (long long)id_offset, D_dev, (long long*)I_dev);
+                           (long long)id_offset, D_dev, (long long*)I_dev, (const int*)nullptr);
     else
         hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(128), 0, st, lists, nq, g.S, k,
-                           (long long)id_offset, D_dev, (long long*)I_dev);
+                           (long long)id_offset, D_dev, (long long*)I_dev, (const int*)nullptr);
     MQ_HIP(hipGetLastError());
     return MQ_OK;
 }
@@ -885,6 +903,145 @@ int mq_knn_search_f32_ev(const float* packed_dev, const float* sqnorm_dev, int64
                          void* ws_dev, size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
     return knn_search_impl(packed_dev, sqnorm_dev, N, d, queries_dev, nq, k, metric, l2norm_queries, id_offset, D_dev,
                            I_dev, ws_dev, ws_bytes, stream, ev_scan_begin, ev_scan_end);
+}
+
+/* ---- screened path (bf16 screening + exact re-scoring): see knn_screen.inc ---- */
+size_t mq_knn_screen_bytes(int64_t n_rows, int d) {
+    return (size_t)mq_padded_rows(n_rows) * (size_t)round_up(d, SBK) * 2;
+}
+
+int mq_knn_screen_prepare(const float* packed_dev, int64_t capacity_rows, int d, int64_t row_offset, int64_t n,
+                          float* rowmajor_dev, uint16_t* bf16_dev, void* stream) {
+    if (n == 0) return MQ_OK;
+    if (!packed_dev || !rowmajor_dev || !bf16_dev || n < 0 || d <= 0 || row_offset < 0 || row_offset + n > capacity_rows)
+        return MQ_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int dpad = mq_padded_dim(d), dp = (int)round_up(d, SBK);
+    float* rm = rowmajor_dev + (size_t)row_offset * d;
+    const int64_t total = n * (int64_t)d;
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, packed_dev, d, dpad, row_offset, n, rm);
+    MQ_HIP(hipGetLastError());
+    const int64_t quads = n * (int64_t)(dp / 4);
+    hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, rm, n, d, dp,
+                       (unsigned short*)bf16_dev + (size_t)row_offset * dp);
+    MQ_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev, const float* rowmajor_dev,
+                               const uint16_t* bf16_dev, const float* xmax2_dev, int64_t N, int d, const float* queries_dev,
+                               int nq, int k, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev, void* ws_dev,
+                               size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
+    if (nq == 0) return MQ_OK;
+    if (!packed_dev || !sqnorm_dev || !rowmajor_dev || !bf16_dev || !xmax2_dev || !queries_dev || !D_dev || !I_dev || !ws_dev)
+        return MQ_EINVAL;
+    if (N <= 0 || d <= 0 || nq < 0 || k <= 0) return MQ_EINVAL;
+    if (k > MQ_KNN_MAX_K) return MQ_EUNSUPPORTED;
+    if (N >= 0xFFFFFFFFll) return MQ_EUNSUPPORTED;
+    const Geometry g = geometry(N, d, nq, k, num_cus());
+    if (ws_bytes < g.total) return MQ_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)ws_dev;
+    float* Qp = (float*)(ws + g.off_qp);
+    float* qn = (float*)(ws + g.off_qn);
+    float* qtmp = (float*)(ws + g.off_qtmp);
+    u64* pools = (u64*)(ws + g.off_lists);
+    unsigned short* Qb = (unsigned short*)(ws + g.off_qb);
+    float* margin = (float*)(ws + g.off_margin);
+    int* pcount = (int*)(ws + g.off_pcount);
+    int* ovf = (int*)(ws + g.off_ovf);
+    unsigned* cand = (unsigned*)(ws + g.off_cand);
+    u64* ckeys = (u64*)(ws + g.off_ckeys);
+    int* ccount = (int*)(ws + g.off_ccount);
+
+    // queries: optional "L2norm," transform applied ONCE in row-major form (so that the panel copy, the
+    // bf16 copy and the re-scoring all see the same fp32 values), then panel pack (+ ||q||^2) and bf16 copy
+    const float* q_rm = queries_dev;
+    if (l2norm_queries) {
+        MQ_HIP(hipMemcpyAsync(qtmp, queries_dev, (size_t)nq * d * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, qtmp, (int64_t)nq, d);
+        MQ_HIP(hipGetLastError());
+        q_rm = qtmp;
+    }
+    MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
+    MQ_HIP(hipMemsetAsync(Qb, 0, (size_t)g.nqpad * g.dp * 2, st));
+    MQ_HIP(hipMemsetAsync(ovf, 0, (size_t)round_up((int64_t)g.nqt * 4, 256) + (size_t)g.nqpad * 4, st));  // ovf + gthr
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((nq + PANEL - 1) / PANEL)), dim3(256), 0, st, q_rm, (int64_t)nq, d,
+                       g.dpad, (int64_t)0, 0, Qp, qn);
+    MQ_HIP(hipGetLastError());
+    {
+        const int64_t quads = (int64_t)nq * (g.dp / 4);
+        hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, q_rm, (int64_t)nq, d, g.dp, Qb);
+        MQ_HIP(hipGetLastError());
+        hipLaunchKernelGGL(screen_margin_kernel, dim3((unsigned)((g.nqpad + 255) / 256)), dim3(256), 0, st, qn, xmax2_dev, nq,
+                           (int)g.nqpad, g.dp, margin);
+        MQ_HIP(hipGetLastError());
+    }
+    // 1. bf16 screening scan
+    {
+        ScreenArgs a;
+        a.Xb = bf16_dev; a.Qb = Qb; a.margin = margin; a.pools = pools; a.pcount = pcount; a.ovf = ovf; a.gthr = (unsigned*)(ws + g.off_gthr);
+        a.N = N; a.dp = g.dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx; a.nchunks = g.nchunks;
+        if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
+        MQ_HIP(hipFuncSetAttribute((const void*)screen_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_TOTAL));
+        hipLaunchKernelGGL(screen_scan_kernel, dim3((unsigned)(g.nqt * g.S)), dim3(1024), S_LDS_TOTAL, st, a);
+        MQ_HIP(hipGetLastError());
+        if (ev_scan_end) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_end, st));
+    }
+    // 2.-4. candidates -> exact scores -> exact top-k
+    hipLaunchKernelGGL(cand_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin, ovf, nq, g.S, k, cand, ccount);
+    MQ_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq, RMAX / 64), dim3(64), 0, st, rowmajor_dev, q_rm, d, cand, ccount, ckeys);
+    MQ_HIP(hipGetLastError());
+    hipLaunchKernelGGL(final_select_kernel, dim3((unsigned)nq), dim3(64), 0, st, ckeys, ccount, ovf, k, (long long)id_offset, D_dev,
+                       (long long*)I_dev);
+    MQ_HIP(hipGetLastError());
+    // 5. query tiles whose bounded buffers overflowed are recomputed by the exact scan (no-op otherwise:
+    //    every workgroup of an unflagged tile returns at once)
+    {
+        ScanArgs a;
+        a.Xp = packed_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = pools;
+        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = nullptr; a.only = ovf;
+        MQ_HIP(hipFuncSetAttribute((const void*)knn_scan_kernel<MQ_METRIC_IP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+        hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_IP>, dim3((unsigned)(g.nqt * g.S)), dim3(1024), LDS_TOTAL, st, a);
+        MQ_HIP(hipGetLastError());
+        hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, st, pools, nq, g.S, k,
+                           (long long)id_offset, D_dev, (long long*)I_dev, (const int*)ovf);
+        MQ_HIP(hipGetLastError());
+    }
+    return MQ_OK;
+}
+
+/* Debug/telemetry of the last screened search held in `ws_dev`: out[0] = flagged query tiles,
+ * out[1] = total candidates re-scored, out[2] = max candidates of one query.  Synchronises the stream. */
+int mq_knn_screen_stats(int64_t N, int d, int nq, int k, const void* ws_dev, int64_t out[8], void* stream) {
+    if (!ws_dev || !out || nq <= 0) return MQ_EINVAL;
+    const Geometry g = geometry(N, d, nq, k, num_cus());
+    MQ_HIP(hipStreamSynchronize((hipStream_t)stream));
+    const size_t npc = (size_t)g.nqt * g.S * TQ;
+    int* ovf = (int*)malloc((size_t)g.nqt * 4);
+    int* cc = (int*)malloc((size_t)nq * 4);
+    int* pc = (int*)malloc(npc * 4);
+    float* mg = (float*)malloc((size_t)nq * 4);
+    if (!ovf || !cc || !pc || !mg) { free(ovf); free(cc); free(pc); free(mg); return MQ_EINVAL; }
+    hipError_t e1 = hipMemcpy(ovf, (const char*)ws_dev + g.off_ovf, (size_t)g.nqt * 4, hipMemcpyDeviceToHost);
+    hipError_t e2 = hipMemcpy(cc, (const char*)ws_dev + g.off_ccount, (size_t)nq * 4, hipMemcpyDeviceToHost);
+    hipError_t e3 = hipMemcpy(pc, (const char*)ws_dev + g.off_pcount, npc * 4, hipMemcpyDeviceToHost);
+    hipError_t e4 = hipMemcpy(mg, (const char*)ws_dev + g.off_margin, (size_t)nq * 4, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int i = 0; i < g.nqt; ++i) out[0] += ovf[i] != 0;
+    for (int i = 0; i < nq; ++i) { out[1] += cc[i]; if (cc[i] > out[2]) out[2] = cc[i]; }
+    for (size_t i = 0; i < npc; ++i) { out[4] += pc[i]; if (pc[i] > out[3]) out[3] = pc[i]; }
+    float mm = 0.f;
+    for (int i = 0; i < nq; ++i) if (mg[i] > mm || mg[i] != mg[i]) mm = mg[i];
+    out[5] = (int64_t)(mm * 1e6f);  /* max margin in 1e-6 units */
+    out[6] = g.S;
+    free(ovf); free(cc); free(pc); free(mg);
+    if (e1 != hipSuccess) return hip_fail(e1);
+    if (e2 != hipSuccess) return hip_fail(e2);
+    if (e3 != hipSuccess) return hip_fail(e3);
+    if (e4 != hipSuccess) return hip_fail(e4);
+    return MQ_OK;
 }
 
 int mq_topk_merge_f32(const float* Ds_dev, const int64_t* Is_dev, int nshards, int nq, int k, int metric, float* D_dev,

@@ -92,7 +92,7 @@ class MI355XFlatIndex(BaseIndex):
     """Exact IP / L2 index over an fp32 matrix held in HBM in the kernel's panel layout."""
 
     def __init__(self, device: Optional[Union[int, list]] = None, string_factory: Optional[str] = None,
-                 metric_type: Optional[int] = None, custom_index=None, id_offset: int = 0):
+                 metric_type: Optional[int] = None, custom_index=None, id_offset: int = 0, screen: Optional[bool] = None):
         if custom_index is not None:
             raise ValueError("custom_index is a FAISS object; MI355XFlatIndex builds its own index")
         self.device = device
@@ -110,6 +110,14 @@ class MI355XFlatIndex(BaseIndex):
         self._capacity = 0
         self._ws = None
         self._torch_device = None
+        # screened search (bf16 screening + exact re-scoring, same results, csrc/knn_screen.inc): inner-product
+        # indexes only; costs 1.5x the shard's HBM footprint.  MQ_KNN_SCREEN=0/1 overrides the default.
+        if screen is None:
+            screen = os.environ.get("MQ_KNN_SCREEN", "1") != "0"
+        self.screen = bool(screen) and self.metric_type == METRIC_INNER_PRODUCT
+        self._rowmajor = None  # torch.float32 [capacity, d] (screened path only)
+        self._bf16 = None      # torch.uint8 bf16 copy
+        self._xmax2 = None     # torch.float32 [1]: max ||x||^2
 
     # ------------------------------------------------------------------ construction
     def _ensure_capacity(self, n_total, d):
@@ -132,6 +140,13 @@ class MI355XFlatIndex(BaseIndex):
             # panels are contiguous: the old buffer is a prefix of the new one
             new_packed[: self._packed.numel()].copy_(self._packed)
             new_sqnorm[: self._sqnorm.numel()].copy_(self._sqnorm)
+        if self.screen:
+            new_rm = torch.empty((cap, self.d), dtype=torch.float32, device=self._torch_device)
+            new_bf = torch.zeros(int(lib.mq_knn_screen_bytes(cap, self.d)), dtype=torch.uint8, device=self._torch_device)
+            if self._rowmajor is not None and self.ntotal > 0:
+                new_rm[: self.ntotal].copy_(self._rowmajor[: self.ntotal])
+                new_bf[: self._bf16.numel()].copy_(self._bf16)
+            self._rowmajor, self._bf16 = new_rm, new_bf
         self._packed, self._sqnorm, self._capacity = new_packed, new_sqnorm, cap
 
     def add(self, vecs, total_hint: Optional[int] = None):
@@ -168,6 +183,11 @@ class MI355XFlatIndex(BaseIndex):
                 _lib.check(lib.mq_pack_rows_f32(dev.data_ptr(), dev.shape[0], self.d, self.ntotal, int(self.do_l2norm),
                                                 self._packed.data_ptr(), self._capacity, self._sqnorm.data_ptr(),
                                                 stream), "mq_pack_rows_f32")
+                if self.screen:
+                    _lib.check(lib.mq_knn_screen_prepare(self._packed.data_ptr(), self._capacity, self.d, self.ntotal,
+                                                         dev.shape[0], self._rowmajor.data_ptr(), self._bf16.data_ptr(), stream),
+                               "mq_knn_screen_prepare")
+                    self._xmax2 = None
                 self.ntotal += dev.shape[0]
                 # `dev` must outlive the kernel: synchronise before it is released
                 torch.cuda.current_stream(self._torch_device).synchronize()
@@ -223,6 +243,8 @@ class MI355XFlatIndex(BaseIndex):
             raise NotImplementedError(f"k={k} > {MAX_K}: the fused MI355X scan keeps at most {MAX_K} neighbours "
                                       "(the reference uses k=100)")
         nq = queries.shape[0]
+        if self.ntotal == 0:
+            raise ValueError("the index is empty: call add_vectors first")
         queries = queries.to(dtype=torch.float32).contiguous()
         D = torch.empty((nq, k), dtype=torch.float32, device=self._torch_device)
         I = torch.empty((nq, k), dtype=torch.int64, device=self._torch_device)
@@ -232,11 +254,20 @@ class MI355XFlatIndex(BaseIndex):
                 q = queries[s:s + _QUERY_CHUNK]
                 nb = int(lib.mq_knn_workspace_bytes(self.ntotal, self.d, q.shape[0], k))
                 ws = self._workspace(nb)
-                _lib.check(lib.mq_knn_search_f32(self._packed.data_ptr(), self._sqnorm.data_ptr(), self.ntotal, self.d,
-                                                 q.data_ptr(), q.shape[0], k, self.metric_type, int(self.do_l2norm),
-                                                 self.id_offset, D[s:s + _QUERY_CHUNK].data_ptr(),
-                                                 I[s:s + _QUERY_CHUNK].data_ptr(), ws.data_ptr(), ws.numel(), stream),
-                           "mq_knn_search_f32")
+                Dq, Iq = D[s:s + _QUERY_CHUNK], I[s:s + _QUERY_CHUNK]
+                if self.screen:
+                    if self._xmax2 is None:
+                        self._xmax2 = torch.nan_to_num(self._sqnorm[: self.ntotal], nan=0.0, posinf=0.0).max().reshape(1).contiguous()
+                    _lib.check(lib.mq_knn_search_screened_f32(
+                        self._packed.data_ptr(), self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(),
+                        self._xmax2.data_ptr(), self.ntotal, self.d, q.data_ptr(), q.shape[0], k, int(self.do_l2norm),
+                        self.id_offset, Dq.data_ptr(), Iq.data_ptr(), ws.data_ptr(), ws.numel(), stream, None, None),
+                        "mq_knn_search_screened_f32")
+                else:
+                    _lib.check(lib.mq_knn_search_f32(self._packed.data_ptr(), self._sqnorm.data_ptr(), self.ntotal, self.d,
+                                                     q.data_ptr(), q.shape[0], k, self.metric_type, int(self.do_l2norm),
+                                                     self.id_offset, Dq.data_ptr(), Iq.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                     stream), "mq_knn_search_f32")
         return D, I
 
     def search_batch(self, queries, k: int = 10, **kwargs) -> BatchedSearchResults:
@@ -262,6 +293,15 @@ class MI355XFlatIndex(BaseIndex):
         return SearchResults(scores[0], indices[0].astype(int))
 
     # ------------------------------------------------------------------ persistence
+    def screen_stats(self, nq, k):
+        """(query tiles recomputed exactly, candidates re-scored, max per query) of the last screened search."""
+        import ctypes
+        lib = _lib.load()
+        out = (ctypes.c_int64 * 8)()
+        _lib.check(lib.mq_knn_screen_stats(self.ntotal, self.d, nq, k, self._ws.data_ptr(), out,
+                                           __import__("torch").cuda.current_stream(self._torch_device).cuda_stream))
+        return tuple(int(x) for x in out)
+
     def reconstruct_n(self, start=0, n=None):
         """Stored rows (after any L2norm transform) as numpy [n,d]."""
         import torch
