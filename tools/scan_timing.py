@@ -7,7 +7,7 @@ from viquae_amd.index import MI355XFlatIndex
 
 N, d, nq, k = 1_500_000, 768, 4096, 100
 dev = torch.device("cuda")
-idx = MI355XFlatIndex(string_factory="Flat", metric_type=0)
+idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=os.environ.get("SCREEN", "0") == "1")
 g = torch.Generator(device=dev); g.manual_seed(0)
 for s in range(0, N, 1 << 16):
     idx.add(torch.randn((min(1 << 16, N - s), d), generator=g, device=dev), total_hint=N)

@@ -981,6 +981,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     {
         ScreenArgs a;
         a.Xb = bf16_dev; a.Qb = Qb; a.margin = margin; a.pools = pools; a.pcount = pcount; a.ovf = ovf; a.gthr = (unsigned*)(ws + g.off_gthr);
+        a.dbg = getenv("MQ_DBG_PTR") ? (unsigned long long*)strtoull(getenv("MQ_DBG_PTR"), nullptr, 0) : nullptr;
         a.N = N; a.dp = g.dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx; a.nchunks = g.nchunks;
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
         MQ_HIP(hipFuncSetAttribute((const void*)screen_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_TOTAL));
@@ -991,7 +992,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     // 2.-4. candidates -> exact scores -> exact top-k
     hipLaunchKernelGGL(cand_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin, ovf, nq, g.S, k, cand, ccount);
     MQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq, RMAX / 64), dim3(64), 0, st, rowmajor_dev, q_rm, d, cand, ccount, ckeys);
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq, RMAX / 64), dim3(256), 0, st, rowmajor_dev, q_rm, d, cand, ccount, ckeys);
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(final_select_kernel, dim3((unsigned)nq), dim3(64), 0, st, ckeys, ccount, ovf, k, (long long)id_offset, D_dev,
                        (long long*)I_dev);
