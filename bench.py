@@ -5,9 +5,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1]): exact inner-product top-100 of 4096 fp32 queries against a
-synthetic 1.5M x 768 fp32 KB resident in HBM (panel layout), on ONE MI355X.  A "step" is one
-mq_knn_search_f32 call (query pack + fused scan/top-k + slab merge) over the whole batch; inputs
-are already in HBM when the timed region starts, D/I are written to HBM inside it.
+synthetic 1.5M x 768 fp32 KB resident in HBM, on ONE MI355X.  A "step" is one search call over the
+whole batch; inputs are already in HBM when the timed region starts, D/I are written inside it.
+Two exact paths exist and return bit-identical results (checked in every run):
+  --mode screened (default): mq_knn_search_screened_f32 = bf16 MFMA screening scan with a provable
+      error margin + exact fp32 re-scoring of the survivors (csrc/knn_screen.inc);
+  --mode exact_f32: mq_knn_search_f32 = fp32 MFMA scan with the top-k fused (csrc/knn.hip).
+The headline `value` is the selected mode; the other path is timed next to it (`other_exact_path`).
 
 N > 1 (BASELINE configs[4] shape): the KB is row-sharded, one 1.5M-row
 shard per rank (weak scaling: per-GPU work fixed), queries replicated; each step = local scan +
@@ -32,6 +36,7 @@ DIM = 768
 NQ = 4096
 TOPK = 100
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -42,6 +47,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=KB_ROWS, help="KB rows per GPU (default: BASELINE size)")
     ap.add_argument("--nq", type=int, default=NQ)
+    ap.add_argument("--mode", choices=["screened", "exact_f32"], default="screened",
+                    help="screened: bf16 screening scan + exact fp32 re-scoring (default, same results); exact_f32: fp32 MFMA scan")
+    ap.add_argument("--no-other-path", action="store_true", help="do not time the other exact path next to the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encoders", action="store_true", help="skip the secondary encoder throughput figures")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
@@ -120,7 +128,7 @@ def main():
     lib = _lib.load()
 
     rows, nq, k = args.rows, args.nq, TOPK
-    local = MI355XFlatIndex(device=local_rank, string_factory="Flat", metric_type=0, id_offset=rank * rows)
+    local = MI355XFlatIndex(device=local_rank, string_factory="Flat", metric_type=0, id_offset=rank * rows, screen=True)
     build_shard(local, rows, seed=rank, device=device)
     index = ShardedFlatIndex(string_factory="Flat", metric_type=0, local_index=local) if world > 1 else None
     if index is not None:
@@ -135,12 +143,22 @@ def main():
     D = torch.empty((nq, k), dtype=torch.float32, device=device)
     I = torch.empty((nq, k), dtype=torch.int64, device=device)
 
-    def local_step(ev0=None, ev1=None):
-        _lib.check(lib.mq_knn_search_f32_ev(local._packed.data_ptr(), local._sqnorm.data_ptr(), rows, DIM, Q.data_ptr(),
-                                            nq, k, 0, 0, local.id_offset, D.data_ptr(), I.data_ptr(), ws.data_ptr(),
-                                            ws_bytes, stream.cuda_stream,
-                                            ev0.cuda_event if ev0 is not None else None,
-                                            ev1.cuda_event if ev1 is not None else None), "mq_knn_search_f32_ev")
+    mode = args.mode
+    if mode == "screened":
+        local.search_device(Q[:256].contiguous(), k)  # builds the shard-level scalars of the screened path (max ||x||^2)
+
+    def local_step(ev0=None, ev1=None, which=None):
+        e0 = ev0.cuda_event if ev0 is not None else None
+        e1 = ev1.cuda_event if ev1 is not None else None
+        if (which or mode) == "screened":
+            _lib.check(lib.mq_knn_search_screened_f32(
+                local._packed.data_ptr(), local._sqnorm.data_ptr(), local._rowmajor.data_ptr(), local._bf16.data_ptr(),
+                local._xmax2.data_ptr(), rows, DIM, Q.data_ptr(), nq, k, 0, local.id_offset, D.data_ptr(), I.data_ptr(),
+                ws.data_ptr(), ws_bytes, stream.cuda_stream, e0, e1), "mq_knn_search_screened_f32")
+        else:
+            _lib.check(lib.mq_knn_search_f32_ev(local._packed.data_ptr(), local._sqnorm.data_ptr(), rows, DIM, Q.data_ptr(),
+                                                nq, k, 0, 0, local.id_offset, D.data_ptr(), I.data_ptr(), ws.data_ptr(),
+                                                ws_bytes, stream.cuda_stream, e0, e1), "mq_knn_search_f32_ev")
         return D, I
 
     def step(ev0=None, ev1=None):
@@ -153,13 +171,17 @@ def main():
         dist.all_gather_into_tensor(Is, Il)
         return index.merge_fn(Ds.view(world, nq, k), Is.view(world, nq, k), 0)
 
+    def make_events(n):
+        evs_ = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in evs_:  # HIP events are created by a first record on the launch stream
+            a.record(stream)
+            b.record(stream)
+        return evs_
+
     for _ in range(args.warmup):
         step()
-    # HIP events that bracket the scan kernel on the stream it is launched on (created by a first record)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in evs:
-        a.record(stream)
-        b.record(stream)
+    # HIP events that bracket the dominant kernel on the stream it is launched on
+    evs = make_events(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -179,6 +201,26 @@ def main():
 
     scan_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
 
+    # the other exact path, timed next to the headline (rank 0, N = 1): a few steps are enough
+    other = None
+    if world == 1 and not args.no_other_path:
+        which = "exact_f32" if mode == "screened" else "screened"
+        if which == "screened" and local._xmax2 is None:
+            local.search_device(Q[:256].contiguous(), k)
+        D_head, I_head = D.clone(), I.clone()
+        n2 = max(2, min(5, args.steps))
+        local_step(which=which)
+        evs2 = make_events(n2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for a, b in evs2:
+            local_step(a, b, which=which)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+        other = {"path": which, "value": round(nq * n2 / el2, 1), "unit": "queries/s", "ms_per_step": round(el2 / n2 * 1e3, 3),
+                 "kernel_ms": round(sum(a.elapsed_time(b) for a, b in evs2) / n2, 3),
+                 "results_identical_to_headline_path": bool(torch.equal(D, D_head) and torch.equal(I, I_head))}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         units = world * nq * args.steps
@@ -188,6 +230,14 @@ def main():
         info = (ctypes_i64 * 6)()
         lib.mq_knn_launch_info(rows, DIM, nq, k, info)
         workload = f"{rows}x{DIM} fp32 KB per GPU, {nq} queries, exact IP top-{k}"
+        if mode == "screened":
+            peak, kernel = PEAK_BF16_MFMA_TFLOPS, "screen_scan_kernel (v_mfma_f32_32x32x16_bf16, relaxed top-k fused)"
+            alg_bytes = rows * DIM * 2  # bf16 copy of the shard, one pass
+            dtype = "bf16 screen + f32 exact re-score"
+        else:
+            peak, kernel = PEAK_F32_MFMA_TFLOPS, "knn_scan_kernel<IP> (v_mfma_f32_32x32x2_f32, top-k fused)"
+            alg_bytes = rows * DIM * 4
+            dtype = "f32"
         rec = {
             "metric": "queries/sec exact top-100 over 1.5M x 768 KB",
             "value": round(value, 1),
@@ -199,10 +249,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": dtype,
             "data": "synthetic (torch Philox randn generated on device, seed = shard rank; queries seed 100)",
             "config": {
                 "workload": workload,
+                "path": mode,
                 "kb_rows_total": rows * world,
                 "queries_per_step": nq,
                 "k": k,
@@ -214,18 +265,30 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "knn_scan_kernel<IP> (v_mfma_f32_32x32x2_f32)",
+                "kernel": kernel,
                 "achieved": round(achieved, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                "frac": round(achieved / peak, 4),
                 "kernel_ms": round(scan_ms, 3),
                 "algorithmic_flops_per_launch": flops,
-                "algorithmic_hbm_bytes_per_launch": rows * DIM * 4,
-                "hbm_frac_at_one_pass": round(rows * DIM * 4 / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                "traffic": load_traffic(f"{rows}x{DIM}_nq{nq}_k{k}"),
+                "algorithmic_hbm_bytes_per_launch": alg_bytes,
+                "hbm_frac_at_one_pass": round(alg_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                "traffic": load_traffic(f"{mode}_{rows}x{DIM}_nq{nq}_k{k}"),
             },
         }
+        if mode == "screened":
+            local._ws, keep = ws, local._ws
+            st = local.screen_stats(nq, k)
+            local._ws = keep
+            rec["config"]["screen"] = {"query_tiles_recomputed_exactly": st[0], "candidates_rescored_per_query": round(st[1] / nq, 1),
+                                       "max_candidates_of_a_query": st[2]}
+        if other is not None:
+            rec["other_exact_path"] = other
+            if other["path"] == "exact_f32":
+                a2 = flops / (other["kernel_ms"] * 1e-3) / 1e12
+                other["roofline"] = {"bound": "mfma", "kernel": "knn_scan_kernel<IP> (v_mfma_f32_32x32x2_f32)", "achieved": round(a2, 2),
+                                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(a2 / PEAK_F32_MFMA_TFLOPS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 rec["cpu_baseline"] = cpu_baseline(local, Q, args.cpu_seconds)

@@ -1,0 +1,96 @@
+"""GPU: the screened search (bf16 screening scan + exact fp32 re-scoring, csrc/knn_screen.inc) must return
+exactly what the exact fp32 scan and the CPU oracle return -- scores bit-for-bit, ids, tie order -- on
+friendly data (no fallback) and on data built to defeat the screen (fallback to the exact scan)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(X, factory="Flat"):
+    from viquae_amd.index import MI355XFlatIndex
+    a = MI355XFlatIndex(string_factory=factory, metric_type=0, screen=True)
+    b = MI355XFlatIndex(string_factory=factory, metric_type=0, screen=False)
+    a.add_vectors(X)
+    b.add_vectors(X)
+    assert a.screen and not b.screen
+    return a, b
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(20000, 768, 300, 100), (5000, 64, 37, 10), (3000, 100, 5, 128), (70000, 128, 513, 100)])
+def test_screened_equals_exact_scan_and_oracle(n, d, nq, k):
+    from oracle import knn as ok
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    a, b = _pair(X)
+    Da, Ia = a.search_batch(Q, k)
+    Db, Ib = b.search_batch(Q, k)
+    assert np.array_equal(Ia, Ib) and np.array_equal(Da, Db)
+    Do, Io = ok.knn(X, Q, k)
+    assert np.array_equal(Ia, Io) and np.array_equal(Da, Do)
+    flagged, rescored, mx = a.screen_stats(nq, k)[:3]
+    assert flagged == 0 and rescored >= nq * min(k, n) and mx <= 1024  # the screen did the work, nothing fell back
+
+
+def test_screen_is_lossless_on_adversarial_scales():
+    """Rows with wildly different norms: the margin uses max ||x||, so the screen must still keep every true
+    neighbour (or fall back); results stay exact."""
+    from oracle import knn as ok
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((12000, 96), dtype=np.float32)
+    X[::7] *= 50.0
+    X[1::13] *= 1e-3
+    Q = rng.standard_normal((64, 96), dtype=np.float32)
+    a, _ = _pair(X)
+    D, I = a.search_batch(Q, 100)
+    Do, Io = ok.knn(X, Q, 100)
+    assert np.array_equal(I, Io) and np.array_equal(D, Do)
+
+
+def test_tie_heavy_data_falls_back_and_stays_exact():
+    """Small-integer data: thousands of rows share the k-th score, the candidate buffers overflow, the tile is
+    flagged and recomputed by the exact scan (lower id wins ties)."""
+    from oracle import knn as ok
+    rng = np.random.default_rng(11)
+    X = rng.integers(-1, 2, (40000, 16)).astype(np.float32)
+    Q = rng.integers(-1, 2, (21, 16)).astype(np.float32)
+    a, _ = _pair(X)
+    D, I = a.search_batch(Q, 100)
+    Do, Io = ok.knn(X, Q, 100)
+    assert np.array_equal(I, Io) and np.array_equal(D, Do)
+    assert a.screen_stats(21, 100)[0] == 1  # the single query tile was recomputed exactly
+
+
+def test_screened_l2norm_factory_and_incremental_add():
+    from oracle import knn as ok
+    from viquae_amd.index import MI355XFlatIndex
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((9000, 80), dtype=np.float32)
+    Q = rng.standard_normal((33, 80), dtype=np.float32)
+    a = MI355XFlatIndex(string_factory="L2norm,Flat", metric_type=0, screen=True)
+    a.add(X[:6400])
+    a.add(X[6400:])
+    D, I = a.search_batch(Q, 50)
+    Do, Io = ok.knn(X, Q, 50, l2norm=True)
+    assert np.array_equal(I, Io) and np.array_equal(D, Do)
+
+
+def test_l2_metric_never_uses_the_screen():
+    from viquae_amd.index import MI355XFlatIndex
+    idx = MI355XFlatIndex(string_factory="Flat", metric_type=1, screen=True)
+    assert idx.screen is False
+
+
+def test_nan_inf_rows_with_screen():
+    from oracle import knn as ok
+    rng = np.random.default_rng(9)
+    X = rng.standard_normal((3000, 32), dtype=np.float32)
+    X[17, 3] = np.nan
+    X[100, 0] = np.inf
+    X[200, 5] = -np.inf
+    Q = rng.standard_normal((6, 32), dtype=np.float32)
+    a, b = _pair(X)
+    Da, Ia = a.search_batch(Q, 20)
+    Do, Io = ok.knn(X, Q, 20)
+    assert np.array_equal(Ia, Io) and np.array_equal(Da, Do, equal_nan=True)
