@@ -53,8 +53,9 @@ def test_tie_heavy_data_falls_back_and_stays_exact():
     flagged and recomputed by the exact scan (lower id wins ties)."""
     from oracle import knn as ok
     rng = np.random.default_rng(11)
-    X = rng.integers(-1, 2, (40000, 16)).astype(np.float32)
-    Q = rng.integers(-1, 2, (21, 16)).astype(np.float32)
+    X = rng.integers(0, 2, (40000, 16)).astype(np.float32)  # scores are integers 0..16: thousands of rows tie at the k-th
+    Q = rng.integers(0, 2, (21, 16)).astype(np.float32)
+    Q[0] = 1.0
     a, _ = _pair(X)
     D, I = a.search_batch(Q, 100)
     Do, Io = ok.knn(X, Q, 100)

@@ -990,7 +990,8 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         if (ev_scan_end) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_end, st));
     }
     // 2.-4. candidates -> exact scores -> exact top-k
-    hipLaunchKernelGGL(cand_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin, ovf, nq, g.S, k, cand, ccount);
+    hipLaunchKernelGGL(cand_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin,
+                       (const unsigned*)(ws + g.off_gthr), ovf, nq, g.S, k, cand, ccount);
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq, RMAX / 64), dim3(256), 0, st, rowmajor_dev, q_rm, d, cand, ccount, ckeys);
     MQ_HIP(hipGetLastError());
