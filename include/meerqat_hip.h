@@ -140,6 +140,13 @@ int mq_topk_merge_f32(const float *Ds_dev, const int64_t *Is_dev, int nshards, i
 int mq_gemm_nt_f32(const float *A_dev, const float *W_dev, const float *bias_dev, const float *residual_dev,
                    float *C_dev, int M, int N, int K, int epilogue, void *stream);
 
+/* Split-bf16 variant of mq_gemm_nt_f32: W is given as two bf16 matrices Wh + Wl (mq_split_bf16_f32, once per
+ * weight), A stays fp32 and is split in registers; C ~= Ah.Wh + Al.Wh + Ah.Wl with fp32 accumulation --
+ * relative error ~1e-5 (fp32-class) at 3/16 of the fp32-MFMA cycles.  K must be a multiple of 32. */
+int mq_split_bf16_f32(const float *src_dev, int64_t n, uint16_t *hi_dev, uint16_t *lo_dev, void *stream);
+int mq_gemm_nt_bf16x3_f32(const float *A_dev, const uint16_t *Wh_dev, const uint16_t *Wl_dev, const float *bias_dev,
+                          const float *residual_dev, float *C_dev, int M, int N, int K, int epilogue, void *stream);
+
 /* nn.LayerNorm over the last dimension (C <= 1024); X and Y may alias. */
 int mq_layernorm_f32(const float *X_dev, const float *gamma_dev, const float *beta_dev, float *Y_dev, int M, int C,
                      float eps, void *stream);

@@ -43,6 +43,34 @@ def test_gemm_epilogues_vs_torch(M, N, K, epi):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err  # fp32 accumulation over K <= 3072
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (800, 768, 768), (37, 100, 96), (300, 2304, 768), (513, 128, 3072)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_split_bf16_gemm_is_fp32_class_accurate(M, N, K, epi):
+    """3-product split-bf16 GEMM vs float64: relative error ~1e-5 (plain bf16 would be ~4e-3)."""
+    from viquae_amd import encoders as E
+    g = torch.Generator(device="cuda").manual_seed(7 * M + N + K + epi)
+    a = torch.randn((M, K), generator=g, device="cuda")
+    w = torch.randn((N, K), generator=g, device="cuda") * 0.05
+    b = torch.randn((N,), generator=g, device="cuda")
+    r = torch.randn((M, N), generator=g, device="cuda")
+    hi, lo = E.split_bf16(w)
+    rec = hi.view(torch.bfloat16).float() + lo.view(torch.bfloat16).float()
+    assert (rec - w).abs().max().item() <= 2.0 ** -17 * w.abs().max().item()
+    out = E.gemm_nt(a, w, b if epi else None, r if epi == 4 else None, epi, wsplit=(hi, lo))
+    ref = (a.double() @ w.double().T)
+    if epi:
+        ref = ref + b.double()
+    if epi == 2:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 3:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if epi == 4:
+        ref = ref + r.double()
+    scale = (a.double().abs() @ w.double().abs().T).max().item()  # sum |a_k w_k|: what the error is relative to
+    err = (out.double() - ref).abs().max().item()
+    assert err < 3e-5 * scale, (err, scale)
+
+
 def test_gemm_is_transpose_sensitive_identity_check():
     """A = I with an ASYMMETRIC W: catches a transposed or mis-tiled C write."""
     from viquae_amd import encoders as E

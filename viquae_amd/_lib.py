@@ -38,6 +38,8 @@ SIGNATURES = {
     "mq_knn_screen_stats": (c_int, [c_i64, c_int, c_int, c_int, c_ptr, ctypes.POINTER(c_i64), c_ptr]),
     "mq_knn_launch_info": (c_int, [c_i64, c_int, c_int, c_int, ctypes.POINTER(c_i64)]),
     "mq_gemm_nt_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "mq_split_bf16_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
+    "mq_gemm_nt_bf16x3_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "mq_layernorm_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, ctypes.c_float, c_ptr]),
     "mq_bert_embed_ln_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int,
                                      ctypes.c_float, c_ptr]),

@@ -180,6 +180,177 @@ __global__ __launch_bounds__(1024) void gemm_nt_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-bf16 GEMM: fp32-class accuracy on the bf16 matrix pipe.
+//   A = Ah + Al (+ r, |r| <= 2^-18 |A|), W = Wh + Wl (bf16 each);  C ~= Ah.Wh + Al.Wh + Ah.Wl  (fp32 accumulate)
+// drops only Al.Wl and the r terms: relative error ~ 3 * 2^-18 per product, i.e. ~1e-5 on a GEMM output,
+// two orders below the 1e-3 parity bar of the encoders, for 3/16 of the fp32-MFMA cycles.
+// W is split once when the model is loaded (mq_split_bf16_f32); A stays fp32 in HBM and LDS and is split
+// in registers right before the MFMAs (v_cvt_pk_bf16_f32), so no producer kernel changes.
+// Tile 256x256, BK 32, 2-stage LDS: per stage A fp32 [256][32] (128-B rows, chunks swizzled by (r>>1)&7)
+// + Wh, Wl bf16 [256][32] (64-B rows, chunks swizzled by (r>>2)&3) = 64 KiB.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int XBK = 32;
+constexpr int X_A_BYTES = GT * XBK * 4;   // 32 KiB
+constexpr int X_W_BYTES = GT * XBK * 2;   // 16 KiB
+constexpr int X_STAGE = X_A_BYTES + 2 * X_W_BYTES;
+constexpr int X_LDS_BYTES = 2 * X_STAGE;  // 128 KiB
+
+__device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8_t& hi, bf16x8_t& lo) {
+    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)x[e];
+        hi[e] = h;
+        lo[e] = (__bf16)(x[e] - (float)h);
+    }
+}
+
+__global__ void split_bf16_kernel(const float* __restrict__ src, long long n, unsigned short* __restrict__ hi,
+                                  unsigned short* __restrict__ lo) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float x = src[e];
+    const __bf16 h = (__bf16)x;
+    const __bf16 l = (__bf16)(x - (float)h);
+    hi[e] = __builtin_bit_cast(unsigned short, h);
+    lo[e] = __builtin_bit_cast(unsigned short, l);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(1024) void gemm_nt_x3_kernel(const float* __restrict__ A, const unsigned short* __restrict__ Wh,
+                                                          const unsigned short* __restrict__ Wl, const float* __restrict__ bias,
+                                                          const float* __restrict__ R, float* __restrict__ C, int M, int N, int K,
+                                                          int ntm, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    int mt, nt;
+    {
+        const int b = blockIdx.x;
+        if ((ntm & 7) == 0) {
+            const int xcd = b & 7, j = b >> 3;
+            mt = (j / ntn) * 8 + xcd;
+            nt = j % ntn;
+        } else {
+            mt = b / ntn;
+            nt = b % ntn;
+        }
+    }
+    mt = __builtin_amdgcn_readfirstlane(mt);
+    nt = __builtin_amdgcn_readfirstlane(nt);
+    const int m0 = mt * GT, n0 = nt * GT;
+
+    // DMA: wave w moves rows [16w, 16w+16) of A (two instructions of 8 rows x 128 B) and of Wh, Wl (one
+    // instruction of 16 rows x 64 B each)
+    unsigned a_voff[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = 16 * w + 8 * u + (lane >> 3);
+        int am = m0 + r; if (am > M - 1) am = M - 1;
+        a_voff[u] = (unsigned)(((size_t)(am - m0) * K + (size_t)(((lane & 7) ^ ((r >> 1) & 7)) * 4)) * 4);
+    }
+    unsigned w_voff;
+    {
+        const int r = 16 * w + (lane >> 2);
+        int wn = n0 + r; if (wn > N - 1) wn = N - 1;
+        w_voff = (unsigned)(((size_t)(wn - n0) * K + (size_t)(((lane & 3) ^ ((r >> 2) & 3)) * 8)) * 2);
+    }
+    const char* const abase = reinterpret_cast<const char*>(A + (size_t)m0 * K);
+    const char* const whbase = reinterpret_cast<const char*>(Wh + (size_t)n0 * K);
+    const char* const wlbase = reinterpret_cast<const char*>(Wl + (size_t)n0 * K);
+    const unsigned lds_a = __builtin_amdgcn_readfirstlane(lds_addr_of(smem + 16 * w * 128));
+    const unsigned lds_wh = __builtin_amdgcn_readfirstlane(lds_addr_of(smem + X_A_BYTES + 16 * w * 64));
+    const unsigned lds_wl = lds_wh + X_W_BYTES;
+    auto issue = [&](int kb, int stg) __attribute__((always_inline)) {
+        const unsigned so = stg * X_STAGE;
+        dma16s(abase + (size_t)kb * (XBK * 4), a_voff[0], lds_a + so);
+        dma16s(abase + (size_t)kb * (XBK * 4), a_voff[1], lds_a + so + 1024);
+        dma16s(whbase + (size_t)kb * (XBK * 2), w_voff, lds_wh + so);
+        dma16s(wlbase + (size_t)kb * (XBK * 2), w_voff, lds_wl + so);
+    };
+
+    const int i = lane & 31, kg = lane >> 5;
+    const int swa = (i >> 1) & 7, sww = (i >> 2) & 3;
+    const char* ard = smem + (64 * wr + i) * 128;
+    const char* hrd = smem + X_A_BYTES + (64 * wc + i) * 64;
+    const char* lrd = hrd + X_W_BYTES;
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    const int nk = K / XBK;
+    issue(0, 0);
+    int stage = 0;
+    for (int kb = 0; kb < nk; ++kb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kb + 1 < nk) issue(kb + 1, stage ^ 1);
+        const char* as = ard + stage * X_STAGE;
+        const char* hs = hrd + stage * X_STAGE;
+        const char* ls = lrd + stage * X_STAGE;
+#pragma unroll
+        for (int m = 0; m < XBK / 16; ++m) {
+            const int wo = ((2 * m + kg) ^ sww) * 16;
+            const bf16x8_t h0 = *reinterpret_cast<const bf16x8_t*>(hs + wo);
+            const bf16x8_t h1 = *reinterpret_cast<const bf16x8_t*>(hs + 32 * 64 + wo);
+            const bf16x8_t l0 = *reinterpret_cast<const bf16x8_t*>(ls + wo);
+            const bf16x8_t l1 = *reinterpret_cast<const bf16x8_t*>(ls + 32 * 64 + wo);
+            const int ca = 4 * m + 2 * kg;
+            const int ao0 = (ca ^ swa) * 16, ao1 = ((ca + 1) ^ swa) * 16;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float4 u = *reinterpret_cast<const float4*>(as + a * 32 * 128 + ao0);
+                const float4 v = *reinterpret_cast<const float4*>(as + a * 32 * 128 + ao1);
+                bf16x8_t ah, al;
+                split8(u, v, ah, al);
+                if (a == 0) {
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, h0, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, h1, acc01, 0, 0, 0);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, l0, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, l1, acc01, 0, 0, 0);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, h0, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, h1, acc01, 0, 0, 0);
+                } else {
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, h0, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, h1, acc11, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, l0, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, l1, acc11, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, h0, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, h1, acc11, 0, 0, 0);
+                }
+            }
+        }
+        stage ^= 1;
+    }
+
+    // epilogue (same C/D map as gemm_nt_kernel)
+    const int nb0 = n0 + 64 * wc + i, nb1 = nb0 + 32;
+    float bias0 = 0.f, bias1 = 0.f;
+    if (EPI != EPI_NONE) {
+        if (nb0 < N) bias0 = bias[nb0];
+        if (nb1 < N) bias1 = bias[nb1];
+    }
+    const int mbase = m0 + 64 * wr + 4 * kg;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int mr0 = mbase + (reg & 3) + 8 * (reg >> 2), mr1 = mr0 + 32;
+        float v00 = acc00[reg] + bias0, v01 = acc01[reg] + bias1, v10 = acc10[reg] + bias0, v11 = acc11[reg] + bias1;
+        if (EPI == EPI_BIAS_GELU) { v00 = gelu_erf(v00); v01 = gelu_erf(v01); v10 = gelu_erf(v10); v11 = gelu_erf(v11); }
+        if (EPI == EPI_BIAS_QUICKGELU) { v00 = quick_gelu(v00); v01 = quick_gelu(v01); v10 = quick_gelu(v10); v11 = quick_gelu(v11); }
+        if (mr0 < M) {
+            if (nb0 < N) { if (EPI == EPI_BIAS_RESIDUAL) v00 += R[(size_t)mr0 * N + nb0]; C[(size_t)mr0 * N + nb0] = v00; }
+            if (nb1 < N) { if (EPI == EPI_BIAS_RESIDUAL) v01 += R[(size_t)mr0 * N + nb1]; C[(size_t)mr0 * N + nb1] = v01; }
+        }
+        if (mr1 < M) {
+            if (nb0 < N) { if (EPI == EPI_BIAS_RESIDUAL) v10 += R[(size_t)mr1 * N + nb0]; C[(size_t)mr1 * N + nb0] = v10; }
+            if (nb1 < N) { if (EPI == EPI_BIAS_RESIDUAL) v11 += R[(size_t)mr1 * N + nb1]; C[(size_t)mr1 * N + nb1] = v11; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LayerNorm family: one wave per row, row held in registers (C <= 1024)
 // ------------------------------------------------------------------------------------------------
 constexpr int LN_MAXPER = 16;
@@ -359,6 +530,44 @@ int mq_gemm_nt_f32(const float* A_dev, const float* W_dev, const float* bias_dev
     case E:                                                                                                           \
         ENC_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES)); \
         hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, block, G_LDS_BYTES, st, A_dev, W_dev, bias_dev, residual_dev, C_dev, M, N, K, ntm, ntn); \
+        break;
+    switch (epilogue) {
+        MQ_LAUNCH(EPI_NONE)
+        MQ_LAUNCH(EPI_BIAS)
+        MQ_LAUNCH(EPI_BIAS_GELU)
+        MQ_LAUNCH(EPI_BIAS_QUICKGELU)
+        MQ_LAUNCH(EPI_BIAS_RESIDUAL)
+    }
+#undef MQ_LAUNCH
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_split_bf16_f32(const float* src_dev, int64_t n, uint16_t* hi_dev, uint16_t* lo_dev, void* stream) {
+    if (n == 0) return MQ_OK;
+    if (!src_dev || !hi_dev || !lo_dev || n < 0) return MQ_EINVAL;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src_dev, (long long)n,
+                       (unsigned short*)hi_dev, (unsigned short*)lo_dev);
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_gemm_nt_bf16x3_f32(const float* A_dev, const uint16_t* Wh_dev, const uint16_t* Wl_dev, const float* bias_dev,
+                          const float* residual_dev, float* C_dev, int M, int N, int K, int epilogue, void* stream) {
+    if (M == 0 || N == 0) return MQ_OK;
+    if (!A_dev || !Wh_dev || !Wl_dev || !C_dev || M < 0 || N < 0 || K <= 0 || (K % XBK) != 0) return MQ_EINVAL;
+    if (epilogue < EPI_NONE || epilogue > EPI_BIAS_RESIDUAL) return MQ_EINVAL;
+    if (epilogue != EPI_NONE && !bias_dev) return MQ_EINVAL;
+    if (epilogue == EPI_BIAS_RESIDUAL && !residual_dev) return MQ_EINVAL;
+    if (((uintptr_t)A_dev | (uintptr_t)Wh_dev | (uintptr_t)Wl_dev) & 15) return MQ_EINVAL;
+    const int ntm = (M + GT - 1) / GT, ntn = (N + GT - 1) / GT;
+    const dim3 grid((unsigned)(ntm * ntn)), block(1024);
+    hipStream_t st = (hipStream_t)stream;
+#define MQ_LAUNCH(E)                                                                                                  \
+    case E:                                                                                                           \
+        ENC_HIP(hipFuncSetAttribute((const void*)gemm_nt_x3_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES)); \
+        hipLaunchKernelGGL(gemm_nt_x3_kernel<E>, grid, block, X_LDS_BYTES, st, A_dev, (const unsigned short*)Wh_dev,    \
+                           (const unsigned short*)Wl_dev, bias_dev, residual_dev, C_dev, M, N, K, ntm, ntn);           \
         break;
     switch (epilogue) {
         MQ_LAUNCH(EPI_NONE)

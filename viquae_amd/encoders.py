@@ -50,19 +50,42 @@ def _check_cuda(*ts):
                                        "(no CPU fallback)")
 
 
-def gemm_nt(a, w, bias=None, residual=None, epilogue=EPI_NONE, out=None):
-    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T)."""
+def split_bf16(w):
+    """(hi, lo) bf16 halves of an fp32 CUDA tensor, as int16 tensors: w ~= hi + lo to 2^-18 relative."""
+    _check_cuda(w)
+    lib = _lib.load()
+    w = w.contiguous()
+    hi = torch.empty(w.shape, dtype=torch.int16, device=w.device)
+    lo = torch.empty(w.shape, dtype=torch.int16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.mq_split_bf16_f32(w.data_ptr(), w.numel(), hi.data_ptr(), lo.data_ptr(), _stream(w)), "mq_split_bf16_f32")
+    return hi, lo
+
+
+def gemm_nt(a, w, bias=None, residual=None, epilogue=EPI_NONE, out=None, wsplit=None):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T).  ``wsplit`` = (hi, lo) from :func:`split_bf16` selects the
+    split-bf16 kernel (fp32-class accuracy on the bf16 matrix pipe; K must be a multiple of 32)."""
     _check_cuda(a, w)
     lib = _lib.load()
     M, K = a.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    b = bias.data_ptr() if bias is not None else None
+    r = residual.data_ptr() if residual is not None else None
     with torch.cuda.device(a.device):
-        _lib.check(lib.mq_gemm_nt_f32(a.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                      residual.data_ptr() if residual is not None else None, out.data_ptr(), M, N, K,
-                                      epilogue, _stream(a)), "mq_gemm_nt_f32")
+        if wsplit is not None and K % 32 == 0:
+            _lib.check(lib.mq_gemm_nt_bf16x3_f32(a.data_ptr(), wsplit[0].data_ptr(), wsplit[1].data_ptr(), b, r, out.data_ptr(),
+                                                 M, N, K, epilogue, _stream(a)), "mq_gemm_nt_bf16x3_f32")
+        else:
+            _lib.check(lib.mq_gemm_nt_f32(a.data_ptr(), w.data_ptr(), b, r, out.data_ptr(), M, N, K, epilogue, _stream(a)),
+                       "mq_gemm_nt_f32")
     return out
+
+
+def _gemm_mode():
+    """MQ_ENC_GEMM = split_bf16 (default) | f32"""
+    return os.environ.get("MQ_ENC_GEMM", "split_bf16")
 
 
 def layernorm(x, g, b, eps, out=None):
@@ -117,6 +140,17 @@ class _HipEncoder(nn.Module):
     def _reg(self, name, tensor):
         self.register_buffer(name.replace(".", "_"), _t(tensor), persistent=False)
         return getattr(self, name.replace(".", "_"))
+
+    def _ws(self, name):
+        """(hi, lo) bf16 split of weight buffer `name`, built once per device (None in f32 mode)."""
+        if _gemm_mode() != "split_bf16":
+            return None
+        w = getattr(self, name)
+        cache = self.__dict__.setdefault("_split_cache", {})
+        key = (name, w.device, w.data_ptr())
+        if key not in cache:
+            cache[key] = split_bf16(w)
+        return cache[key]
 
 
 # --------------------------------------------------------------------------------------------------
@@ -180,12 +214,13 @@ class BertEncoderHIP(_HipEncoder):
         scale = 1.0 / math.sqrt(H // self.heads)
         for i in range(self.layers):
             w = lambda n: getattr(self, f"l{i}_{n}")  # noqa: E731
-            qkv = gemm_nt(h, w("wqkv"), w("bqkv"), None, EPI_BIAS)
+            sp = lambda n: self._ws(f"l{i}_{n}")  # noqa: E731
+            qkv = gemm_nt(h, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
             ctx = attention(qkv, mask, B, L, self.heads, scale)
-            a = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL)
+            a = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, wsplit=sp("wo"))
             h1 = layernorm(a, w("g1"), w("b1"), self.eps, out=a)
-            f = gemm_nt(h1, w("wi"), w("bi"), None, EPI_BIAS_GELU)
-            o = gemm_nt(f, w("w2"), w("b2"), h1, EPI_BIAS_RESIDUAL)
+            f = gemm_nt(h1, w("wi"), w("bi"), None, EPI_BIAS_GELU, wsplit=sp("wi"))
+            o = gemm_nt(f, w("w2"), w("b2"), h1, EPI_BIAS_RESIDUAL, wsplit=sp("w2"))
             h = layernorm(o, w("g2"), w("b2n"), self.eps, out=o)
             if output_hidden_states:
                 hidden.append(h.view(B, L, H))
@@ -308,7 +343,7 @@ class CLIPModel(_HipEncoder):
         with torch.cuda.device(dev):
             _lib.check(lib.mq_clip_patchify_f32(px.data_ptr(), patches.data_ptr(), B, C, S, self.patch, _stream(px)),
                        "mq_clip_patchify_f32")
-            pe = gemm_nt(patches, self.wpe, None, None, EPI_NONE)
+            pe = gemm_nt(patches, self.wpe, None, None, EPI_NONE, wsplit=self._ws("wpe"))
             _lib.check(lib.mq_clip_assemble_ln_f32(pe.data_ptr(), self.cls.data_ptr(), self.pos.data_ptr(), self.pre_g.data_ptr(),
                                                    self.pre_b.data_ptr(), h.data_ptr(), B, T, H, self.eps, _stream(px)),
                        "mq_clip_assemble_ln_f32")
@@ -316,14 +351,15 @@ class CLIPModel(_HipEncoder):
         for i in range(self.layers):
             w = lambda n: getattr(self, f"l{i}_{n}")  # noqa: E731
             y = layernorm(h, w("g1"), w("b1"), self.eps)
-            qkv = gemm_nt(y, w("wqkv"), w("bqkv"), None, EPI_BIAS)
+            sp = lambda n: self._ws(f"l{i}_{n}")  # noqa: E731
+            qkv = gemm_nt(y, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
             ctx = attention(qkv, None, B, T, self.heads, scale)
-            h = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, out=h)
+            h = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("wo"))
             y = layernorm(h, w("g2"), w("b2n"), self.eps, out=y)
-            f = gemm_nt(y, w("w1"), w("bb1"), None, self.act)
-            h = gemm_nt(f, w("w2"), w("bb2"), h, EPI_BIAS_RESIDUAL, out=h)
+            f = gemm_nt(y, w("w1"), w("bb1"), None, self.act, wsplit=sp("w1"))
+            h = gemm_nt(f, w("w2"), w("bb2"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("w2"))
         pooled = layernorm(h.view(B, T, H)[:, 0, :].contiguous(), self.post_g, self.post_b, self.eps)
-        return gemm_nt(pooled, self.wproj, None, None, EPI_NONE)
+        return gemm_nt(pooled, self.wproj, None, None, EPI_NONE, wsplit=self._ws("wproj"))
 
 
 HIP_CLASSES = {"DPRContextEncoder": DPRContextEncoder, "DPRQuestionEncoder": DPRQuestionEncoder, "CLIPModel": CLIPModel}
