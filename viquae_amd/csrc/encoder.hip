@@ -511,6 +511,111 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA attention (fp32): one workgroup (4 waves) per (sequence, head, block of 128 queries).
+// S^T = K . Q^T with K as the A operand, so each lane column is ONE query: the softmax over keys is a
+// per-lane reduction + one exchange with lane^32.  The probabilities then feed the P.V MFMAs as the
+// B operand straight from the accumulator registers (lanes 0-31 hold keys = 0..3 mod 8, lanes 32-63
+// keys = 4..7 mod 8, which is exactly a 2-deep k pair), with V^T rows as the A operand.
+// ------------------------------------------------------------------------------------------------
+template <int NKT>  // key tiles of 32: L <= 32 * NKT
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, const long long* __restrict__ mask,
+                                                             float* __restrict__ out, int L, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NK = 32 * NKT;
+    float* Ks = reinterpret_cast<float*>(smem);        // [NK][65]
+    float* Vs = Ks + NK * 65;                           // [NK][64]
+    float* addm = Vs + NK * 64;                         // [NK] 0 or -inf
+    const int bi = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int H = heads * DH, ld = 3 * H;
+    const float* base = qkv + (size_t)bi * L * ld + h * DH;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int e = tid; e < NK * (DH / 4); e += 256) {
+        const int j = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
+        float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
+        if (j < L) {
+            kf = *reinterpret_cast<const float4*>(base + (size_t)j * ld + H + c4);
+            vf = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * H + c4);
+        }
+        float* kd = Ks + j * 65 + c4;
+        kd[0] = kf.x; kd[1] = kf.y; kd[2] = kf.z; kd[3] = kf.w;
+        *reinterpret_cast<float4*>(Vs + j * 64 + c4) = vf;
+    }
+    for (int j = tid; j < NK; j += 256) addm[j] = (j < L && (!mask || mask[(size_t)bi * L + j] != 0)) ? 0.f : -INFINITY;
+    __syncthreads();
+
+    const int i = lane & 31, kh = lane >> 5;
+    const int qrow = blockIdx.y * 128 + 32 * w + i;   // this lane's query
+    float qreg[32];
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) qreg[kk] = (qrow < L) ? base[(size_t)qrow * ld + 2 * kk + kh] : 0.f;
+
+    f32x16 sacc[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) sacc[t] = (f32x16){0};
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            const float a = Ks[(32 * t + i) * 65 + 2 * kk + kh];
+            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[kk], sacc[t], 0, 0, 0);
+        }
+    }
+    // sacc[t][reg] = <k_key, q_query>, key = 32 t + (reg&3) + 8 (reg>>2) + 4 kh, query = this lane's column
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int key = 32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            const float sv = sacc[t][reg] * scale + addm[key];
+            sacc[t][reg] = sv;
+            mx = fmaxf(mx, sv);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float den = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const float p = (sacc[t][reg] == -INFINITY) ? 0.f : expf(sacc[t][reg] - mx);
+            sacc[t][reg] = p;
+            den += p;
+        }
+    }
+    den += __shfl_xor(den, 32);
+
+    f32x16 oacc0 = {0}, oacc1 = {0};
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int key = 32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            const float p = sacc[t][reg];
+            oacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * 64 + i], p, oacc0, 0, 0, 0);
+            oacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * 64 + 32 + i], p, oacc1, 0, 0, 0);
+        }
+    }
+    // oacc{0,1}[reg] = sum_key p V[key][d], d = 32 dt + (reg&3) + 8 (reg>>2) + 4 kh, for this lane's query.
+    // Transpose through LDS (K/V are dead) so that every query row is stored as 256 contiguous bytes.
+    __syncthreads();
+    float* Ot = reinterpret_cast<float*>(smem) + w * (32 * 65);   // [32 queries][65]
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int d = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+        Ot[i * 65 + d] = oacc0[reg] * inv;
+        Ot[i * 65 + 32 + d] = oacc1[reg] * inv;
+    }
+    __syncthreads();
+    for (int e = lane; e < 32 * 64; e += 64) {
+        const int r = e >> 6, c = e & 63;
+        const int qr = blockIdx.y * 128 + 32 * w + r;
+        if (qr < L) out[((size_t)bi * L + qr) * H + h * DH + c] = Ot[r * 65 + c];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -612,11 +717,19 @@ int mq_attention_f32(const float* qkv_dev, const int64_t* attention_mask_dev, fl
     if (B == 0 || L == 0) return MQ_OK;
     if (!qkv_dev || !out_dev || B < 0 || L < 0 || heads <= 0) return MQ_EINVAL;
     if (head_dim != DH || L > 256) return MQ_EUNSUPPORTED;
-    const size_t lds = (size_t)L * DH * 4 * 2 + (size_t)L * 4;
-    const int threads = (L + 63) / 64 * 64;
-    ENC_HIP(hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * heads)), dim3(threads), lds, (hipStream_t)stream, qkv_dev,
-                       (const long long*)attention_mask_dev, out_dev, L, heads, scale);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(B * heads), (unsigned)((L + 127) / 128));
+#define MQ_ATT(NKT)                                                                                                   \
+    {                                                                                                                 \
+        const size_t lds = (size_t)(32 * NKT) * (65 + 64 + 1) * 4 > (size_t)4 * 32 * 65 * 4 ? (size_t)(32 * NKT) * (65 + 64 + 1) * 4 : (size_t)4 * 32 * 65 * 4; \
+        ENC_HIP(hipFuncSetAttribute((const void*)attention_mfma_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(attention_mfma_kernel<NKT>, grid, dim3(256), lds, st, qkv_dev, (const long long*)attention_mask_dev,    \
+                           out_dev, L, heads, scale);                                                                 \
+    }
+    if (L <= 64) MQ_ATT(2)
+    else if (L <= 128) MQ_ATT(4)
+    else MQ_ATT(8)
+#undef MQ_ATT
     ENC_HIP(hipGetLastError());
     return MQ_OK;
 }
