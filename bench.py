@@ -122,15 +122,21 @@ def main():
         raise SystemExit("bench.py needs an MI355X: viquae_amd has no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # MQ_BENCH_FORCE_DIST=1: go through the RCCL all-gather + shard merge even with one rank (exercises the
+    # N > 1 code path on a 1-GPU box)
+    force_dist = os.environ.get("MQ_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
     lib = _lib.load()
 
     rows, nq, k = args.rows, args.nq, TOPK
     local = MI355XFlatIndex(device=local_rank, string_factory="Flat", metric_type=0, id_offset=rank * rows, screen=True)
     build_shard(local, rows, seed=rank, device=device)
-    index = ShardedFlatIndex(string_factory="Flat", metric_type=0, local_index=local) if world > 1 else None
+    index = ShardedFlatIndex(string_factory="Flat", metric_type=0, local_index=local) if (world > 1 or force_dist) else None
     if index is not None:
         index.ntotal = rows * world
     g = torch.Generator(device=device)
@@ -163,7 +169,7 @@ def main():
 
     def step(ev0=None, ev1=None):
         Dl, Il = local_step(ev0, ev1)
-        if world == 1:
+        if world == 1 and not force_dist:
             return Dl, Il
         Ds = torch.empty((world * nq, k), dtype=Dl.dtype, device=device)
         Is = torch.empty((world * nq, k), dtype=Il.dtype, device=device)
@@ -318,7 +324,7 @@ def main():
             except Exception as e:
                 rec["secondary"] = {"error": repr(e)}
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 
