@@ -710,7 +710,7 @@ struct Geometry {
     size_t off_qp, off_qn, off_qtmp, off_lists, total;
     // screened path extras
     int dp;
-    size_t off_qb, off_margin, off_pcount, off_ovf, off_gthr, off_cand, off_ckeys, off_ccount;
+    size_t off_qb, off_margin, off_pcount, off_ovf, off_gthr, off_squant, off_cand, off_ckeys, off_ccount;
 };
 
 Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
@@ -755,6 +755,7 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
     g.off_pcount = o; o += (size_t)g.nqt * g.S * TQ * 4;
     g.off_ovf = o;    o += (size_t)round_up((int64_t)g.nqt * 4, 256);
     g.off_gthr = o;   o += (size_t)g.nqpad * 4;
+    g.off_squant = o; o += (size_t)2 * g.nqt * g.S * TQ * 4;
     g.off_cand = o;   o += nq1 * RMAX * 4;
     g.off_ckeys = o;  o += nq1 * RMAX * 8;
     g.off_ccount = o; o += (size_t)round_up((int64_t)nq1 * 4, 256);
@@ -980,7 +981,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     // 1. bf16 screening scan
     {
         ScreenArgs a;
-        a.Xb = bf16_dev; a.Qb = Qb; a.margin = margin; a.pools = pools; a.pcount = pcount; a.ovf = ovf; a.gthr = (unsigned*)(ws + g.off_gthr);
+        a.Xb = bf16_dev; a.Qb = Qb; a.margin = margin; a.pools = pools; a.pcount = pcount; a.ovf = ovf; a.gthr = (unsigned*)(ws + g.off_gthr); a.squant = (unsigned*)(ws + g.off_squant);
         a.dbg = getenv("MQ_DBG_PTR") ? (unsigned long long*)strtoull(getenv("MQ_DBG_PTR"), nullptr, 0) : nullptr;
         a.N = N; a.dp = g.dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx; a.nchunks = g.nchunks;
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
@@ -991,7 +992,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     }
     // 2.-4. candidates -> exact scores -> exact top-k
     hipLaunchKernelGGL(cand_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin,
-                       (const unsigned*)(ws + g.off_gthr), ovf, nq, g.S, k, cand, ccount);
+                       (const unsigned*)(ws + g.off_gthr), (const unsigned*)(ws + g.off_squant), g.nqt, ovf, nq, g.S, k, cand, ccount);
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq, RMAX / 64), dim3(256), 0, st, rowmajor_dev, q_rm, d, cand, ccount, ckeys);
     MQ_HIP(hipGetLastError());
