@@ -1,0 +1,207 @@
+"""Mirror of ``meerqat.ir.search.Searcher`` / ``dataset_search`` for dense (FAISS-kind) indexes
+(SURVEY.md section 8 f.1): ``Searcher.__init__`` (meerqat/ir/search.py:332-399), ``Searcher.__call__``
+(:401-459), ``dataset_search`` (:462-524).
+
+What is the same: constructor arguments, the ``runs[index_name][q_id][doc_id] = score`` layout (doc ids are
+strings), the article->passage fan-out through ``index_mapping`` with the 1e-8 penalty per passage
+(:421-427) or ``many2one: "max"`` (:429-431), the cut at ``k`` entries per query (:439-440), the on-the-fly
+relevance judgement of retrieved passages against the reference KB (:442-457, ``find_relevant`` =
+meerqat/ir/metrics.py:79-124 for string answers).
+What differs: no Elasticsearch client is constructed (sparse kinds are outside this build); ``ranx`` is
+optional -- without it ``dataset_search`` returns plain dicts and skips the metric report; numerical
+(InfoSeek) question types are not judged here.
+
+The reference builds the run with a Python triple loop per batch (256 x 100 dict inserts); here the
+[nq, k] arrays of one batch are expanded with numpy (CSR gather over ``index_mapping``) before the single
+pass that fills the dicts.
+"""
+import json
+import re
+import string
+import warnings
+from pathlib import Path
+
+import numpy as np
+
+from .search import KnowledgeBase
+
+
+def answer_preprocess(answer):
+    """Lower-case, drop punctuation, articles and extra whitespace (meerqat/data/loading.py:152-164)."""
+    answer = "".join(ch for ch in answer.lower() if ch not in set(string.punctuation))
+    answer = re.sub(r"\b(a|an|the)\b", " ", answer)
+    return " ".join(answer.split())
+
+
+def find_relevant(retrieved, original_answer, alternative_answers, kb, reference_key="passage", question_type="String"):
+    """Which retrieved passages contain the answer (or one of its aliases) as whole words."""
+    if question_type not in ("String", None):
+        raise NotImplementedError("numerical / time question types (InfoSeek) are not judged by this mirror")
+    original_relevant, relevant = [], []
+    answer0 = answer_preprocess(original_answer)
+    aliases = [answer_preprocess(a) for a in alternative_answers]
+    for i in retrieved:
+        i = int(i)
+        passage = answer_preprocess(kb[i][reference_key])
+        if re.search(rf"\b{answer0}\b", passage) is not None:
+            original_relevant.append(i)
+            relevant.append(i)
+            continue
+        for answer in aliases:
+            if re.search(rf"\b{answer}\b", passage) is not None:
+                relevant.append(i)
+                break
+    return original_relevant, relevant
+
+
+class _Mapping:
+    """index_mapping (dict article -> list of passage ids) as CSR arrays for vectorised fan-out."""
+
+    def __init__(self, mapping):
+        keys = sorted(mapping)
+        self.lookup = {k: n for n, k in enumerate(keys)}
+        lens = np.array([len(mapping[k]) for k in keys], dtype=np.int64)
+        self.offsets = np.concatenate([[0], np.cumsum(lens)])
+        self.values = np.concatenate([np.asarray(mapping[k], dtype=np.int64) for k in keys]) if keys else np.zeros(0, np.int64)
+
+    def expand(self, indices, scores, many2one):
+        """(passage ids, scores) of one query's hits, in hit order."""
+        rows = np.array([self.lookup[int(i)] for i in indices], dtype=np.int64)
+        starts, ends = self.offsets[rows], self.offsets[rows + 1]
+        counts = ends - starts
+        pos = np.arange(counts.sum()) - np.repeat(np.cumsum(counts) - counts, counts)
+        ids = self.values[np.repeat(starts, counts) + pos]
+        sc = np.repeat(np.asarray(scores, dtype=np.float32), counts)
+        if many2one is None:
+            # penalty grows with the passage's rank inside its article.  `np.float32 score - python float penalty`
+            # is a float32 subtraction under NumPy >= 2 (what this container's reference run does; it was float64
+            # under NumPy 1.x): the penalty is cast to float32 first
+            sc = sc - (1e-8 * pos).astype(np.float32)
+        return ids, sc, np.cumsum(counts)
+
+
+class Searcher:
+    def __init__(self, kb_kwargs, k=100, reference_kb_path=None, reference_key="passage", qrels=None, request_timeout=1000,
+                 es_client_kwargs={}, fusion_kwargs={}, metrics_kwargs={}, do_fusion=None, qnonrels=None, kbs=None,
+                 reference_kb=None):
+        self.k = k
+        self.kbs = {}
+        self.qrels = {}
+        self.qnonrels = {}
+        if qrels is not None:
+            with open(qrels, "rt") as file:
+                self.qrels = json.load(file)
+        if qnonrels is not None:
+            with open(qnonrels, "rt") as file:
+                self.qnonrels = json.load(file)
+        self.runs = {}
+        resolved = {}
+        for kb_path, kb_kwarg in kb_kwargs.items():
+            real = Path(kb_path).expanduser().resolve()
+            if real in resolved:
+                raise ValueError(f"'{kb_path}' and '{resolved[real]}' resolve to the same path")
+            resolved[real] = kb_path
+            kb = kbs[kb_path] if kbs and kb_path in kbs else KnowledgeBase(kb_path, **kb_kwarg)
+            self.kbs[kb_path] = kb
+            assert not (kb.indexes.keys() & self.runs.keys()), "All KBs should have unique index names"
+            for index_name in kb.indexes:
+                self.runs[index_name] = {}
+        assert not ({"search", "fusion"} & self.runs.keys()), "'search', 'fusion' are reserved names"
+        self.do_fusion = True if (do_fusion is None and len(self.runs) > 1) else do_fusion
+        if self.do_fusion:
+            assert len(self.runs) > 1
+        if reference_kb is not None:
+            self.reference_kb = reference_kb
+        elif reference_kb_path is None:
+            assert qrels is not None
+            warnings.warn("Didn't get a reference KB -> will not be able to extend the annotation coverage "
+                          "so results should be interpreted carefully.\n")
+            self.reference_kb = None
+        else:
+            from datasets import load_from_disk
+            ref = load_from_disk(reference_kb_path)
+            self.reference_kb = ref.remove_columns([c for c in ref.column_names if c != reference_key])
+        self.reference_key = reference_key
+        self.fusion_kwargs = fusion_kwargs
+        self.metrics_kwargs = dict(metrics=["mrr@100", "precision@1", "precision@20", "hit_rate@20"])
+        self.metrics_kwargs.update(metrics_kwargs)
+        self._csr = {}
+
+    def _fill_run(self, kb, run_q, scores, indices):
+        """One query's hits -> run dict, cut at k entries (reference: search.py:413-440)."""
+        if kb.index_mapping is None:
+            for score, i in zip(scores, indices):
+                run_q[str(i)] = score
+                if len(run_q) >= self.k:
+                    break
+            return
+        csr = self._csr.setdefault(id(kb), _Mapping(kb.index_mapping))
+        ids, sc, ends = csr.expand(indices, scores, kb.many2one)
+        hit = 0
+        for n, (j, s) in enumerate(zip(ids.tolist(), sc.tolist())):
+            j = str(j)
+            if kb.many2one is None:
+                run_q[j] = s
+            elif kb.many2one == "max":
+                if j not in run_q or run_q[j] < s:
+                    run_q[j] = s
+            else:
+                raise ValueError(f"Invalid value for many2one: '{kb.many2one}'. Choose from {{None, 'max'}}")
+            # the reference tests the cut after each HIT (all passages of an article are inserted first)
+            while hit < len(ends) and n + 1 == ends[hit]:
+                hit += 1
+                if len(run_q) >= self.k:
+                    return
+
+    def __call__(self, batch):
+        question_types = batch.get("question_type", ["String"] * len(batch["id"]))
+        for kb in self.kbs.values():
+            for index_name, index in kb.indexes.items():
+                queries = batch[index.key]
+                if any(query is None for query in queries):
+                    scores_batch, indices_batch = kb.search_batch_if_not_None(index_name, queries, k=self.k)
+                else:
+                    scores_batch, indices_batch = kb.search_batch(index_name, queries, k=self.k)
+                for q_id, scores, indices, gt, question_type in zip(batch["id"], scores_batch, indices_batch, batch["output"],
+                                                                    question_types):
+                    run_q = self.runs[index_name].setdefault(q_id, {})
+                    scores = np.asarray(scores).tolist()
+                    indices = np.asarray(indices).tolist()
+                    self._fill_run(kb, run_q, scores, indices)
+                    if self.reference_kb is not None:
+                        self.qrels.setdefault(q_id, {})
+                        self.qnonrels.setdefault(q_id, {})
+                        retrieved = run_q.keys() - (self.qrels[q_id].keys() | self.qnonrels[q_id].keys())
+                        _, relevant = find_relevant(retrieved, gt["original_answer"], gt["answer"], self.reference_kb,
+                                                    reference_key=self.reference_key, question_type=question_type)
+                        self.qrels[q_id].update({str(i): 1 for i in relevant})
+                        self.qnonrels[q_id].update({i: 0 for i in retrieved - self.qrels[q_id].keys()})
+        return batch
+
+
+def dataset_search(dataset, k=100, metric_save_path=None, map_kwargs={}, **kwargs):
+    """Searcher over ``dataset.map``; saves qrels / runs (JSON) under ``metric_save_path``; with ``ranx`` installed
+    also computes and saves the metric report like the reference."""
+    searcher = Searcher(k=k, **kwargs)
+    dataset = dataset.map(searcher, batched=True, **map_kwargs)
+    if metric_save_path is not None:
+        metric_save_path = Path(metric_save_path)
+        metric_save_path.mkdir(exist_ok=True)
+        with open(metric_save_path / "qrels.json", "wt") as file:
+            json.dump(searcher.qrels, file)
+        with open(metric_save_path / "qnonrels.json", "wt") as file:
+            json.dump(searcher.qnonrels, file)
+        for index_name, run in searcher.runs.items():
+            with open(metric_save_path / f"{index_name}.json", "wt") as file:
+                json.dump(run, file)
+    try:
+        import ranx
+    except ImportError:
+        return searcher
+    qrels = ranx.Qrels(searcher.qrels)
+    runs = [ranx.Run(run, name=name) for name, run in searcher.runs.items()]
+    report = ranx.compare(qrels, runs=runs, **searcher.metrics_kwargs)
+    print(report)
+    if metric_save_path is not None:
+        report.save(metric_save_path / "metrics.json")
+    return searcher
