@@ -193,7 +193,8 @@ class BertEncoderHIP(_HipEncoder):
             self._reg(f"l{i}_b2n", g(p + "output.LayerNorm.bias"))
 
     @torch.no_grad()
-    def forward(self, input_ids, token_type_ids=None, attention_mask=None, output_hidden_states=False):
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, output_hidden_states=False, cls_only=False):
+        cls_only = cls_only and not output_hidden_states
         _check_cuda(input_ids, self.w_word)
         lib = _lib.load()
         B, L = input_ids.shape
@@ -217,6 +218,11 @@ class BertEncoderHIP(_HipEncoder):
             sp = lambda n: self._ws(f"l{i}_{n}")  # noqa: E731
             qkv = gemm_nt(h, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
             ctx = attention(qkv, mask, B, L, self.heads, scale)
+            if cls_only and i == self.layers - 1:
+                # DPR reads only last_hidden_state[:, 0]: after the last attention, the output projection, both
+                # LayerNorms and the FFN are row-wise, so run them on the [CLS] rows alone (same numbers, 1/L of the rows)
+                ctx = ctx.view(B, L, H)[:, 0, :].contiguous()
+                h = h.view(B, L, H)[:, 0, :].contiguous()
             a = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, wsplit=sp("wo"))
             h1 = layernorm(a, w("g1"), w("b1"), self.eps, out=a)
             f = gemm_nt(h1, w("wi"), w("bi"), None, EPI_BIAS_GELU, wsplit=sp("wi"))
@@ -224,6 +230,8 @@ class BertEncoderHIP(_HipEncoder):
             h = layernorm(o, w("g2"), w("b2n"), self.eps, out=o)
             if output_hidden_states:
                 hidden.append(h.view(B, L, H))
+        if cls_only:
+            return h.view(B, 1, H), hidden
         return h.view(B, L, H), hidden
 
 
@@ -249,7 +257,7 @@ class _DPREncoder(_HipEncoder):
 
     @torch.no_grad()
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, output_hidden_states=False, **unused):
-        last, hidden = self.bert_model(input_ids, token_type_ids, attention_mask, output_hidden_states)
+        last, hidden = self.bert_model(input_ids, token_type_ids, attention_mask, output_hidden_states, cls_only=True)
         out = ModelOutput(pooler_output=last[:, 0, :].contiguous())
         if output_hidden_states:
             out["hidden_states"] = tuple(hidden)
