@@ -173,6 +173,33 @@ int mq_clip_assemble_ln_f32(const float *patch_emb_dev, const float *class_emb_d
                             const float *gamma_dev, const float *beta_dev, float *out_dev, int B, int tokens, int H,
                             float eps, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Late fusion of several runs on the device: replaces, for integer document
+ * ids, `default_minimum` (meerqat/ir/fuse.py:129-146), `gzmuv_norm` (:86-126) and ranx's
+ * `fuse(runs, norm, method="wsum", params={"weights": ...})` as called by `Fusion.test` (:215-236) from
+ * `dataset_search` (meerqat/ir/search.py:514-524).
+ *   ids_dev    [n_runs, nq, K] int64   document ids, -1 = empty slot; unique within one (run, query);
+ *                                      0 <= id < 2^58; every run lists the same nq queries
+ *   scores_dev [n_runs, nq, K] f64
+ *   weights_host [n_runs] f64 (HOST memory), n_runs <= MQ_FUSE_MAX_RUNS, n_runs*K <= 4096
+ *   norm       MQ_FUSE_NORM_NONE | _GZMUV (one mean/std per run over all its queries, population std,
+ *              denominator max(std, 1e-9)) | _ZMUV (ranx "zmuv": the same per query)
+ *   defmin     != 0: before normalising, every run that has results for a query receives the documents
+ *              only other runs retrieved, at its own minimum score for that query
+ *   out_ids_dev [nq, n_runs*K] int64 / out_scores_dev [nq, n_runs*K] f64: the fused run, best first,
+ *              equal scores by ascending id, (-1, 0.0) after out_count_dev[q] entries
+ * Fused score of a document = ((0.0 + w0*s0) + w1*s1) + ... over the runs that hold it, in run order,
+ * f64 without contraction (what ranx's comb_sum computes).  ws_dev: mq_fuse_workspace_bytes().
+ * ------------------------------------------------------------------------------------------- */
+#define MQ_FUSE_MAX_RUNS 32
+#define MQ_FUSE_NORM_NONE 0
+#define MQ_FUSE_NORM_GZMUV 1
+#define MQ_FUSE_NORM_ZMUV 2
+size_t mq_fuse_workspace_bytes(int n_runs, int nq, int K);
+int mq_fuse_wsum_f64(const int64_t *ids_dev, const double *scores_dev, int n_runs, int nq, int K,
+                     const double *weights_host, int norm, int defmin, int64_t *out_ids_dev, double *out_scores_dev,
+                     int32_t *out_count_dev, void *ws_dev, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

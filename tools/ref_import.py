@@ -93,6 +93,22 @@ class _PreTransformStandIn:
         return self.index.search(ok.l2norm_rows(np.asarray(q, np.float32)), k)
 
 
+class _RunStandIn:
+    """ranx.Run stand-in: just the two attributes meerqat/ir/fuse.py touches (``run``, ``name``)."""
+
+    def __init__(self, run=None, name=None):
+        self.run = {} if run is None else run
+        self.name = name
+
+
+class _TypedDictStandIn(dict):
+    """numba.typed.Dict stand-in (``Dict.empty(key_type, value_type)`` -> plain dict)."""
+
+    @classmethod
+    def empty(cls, key_type=None, value_type=None):
+        return cls()
+
+
 def _index_factory(d, description, metric=1):
     parts = description.split(",")
     if parts == ["Flat"]:
@@ -111,7 +127,7 @@ def install_stubs():
     if "docopt" not in sys.modules:
         _module("docopt", docopt=lambda *a, **k: {})
     if "ranx" not in sys.modules:
-        _module("ranx", Run=_Any, Qrels=_Any, compare=_Any(), fuse=_Any(), optimize_fusion=_Any())
+        _module("ranx", Run=_RunStandIn, Qrels=_Any, compare=_Any(), fuse=_Any(), optimize_fusion=_Any())
     if "spacy" not in sys.modules:
         sp = _module("spacy", Language=type("Language", (), {}), load=_Any())
         _module("spacy.lang")
@@ -122,7 +138,7 @@ def install_stubs():
     if "numba" not in sys.modules:
         ident = lambda *a, **k: (a[0] if a and callable(a[0]) and not k else (lambda f: f))  # noqa: E731
         nb = _module("numba", njit=ident, jit=ident, prange=range, types=_Any(), config=_Any())
-        _module("numba.typed", List=list, Dict=dict)
+        _module("numba.typed", List=list, Dict=_TypedDictStandIn)
         nb.typed = sys.modules["numba.typed"]
     if "torchvision" not in sys.modules:
         tv = _module("torchvision")
@@ -145,6 +161,15 @@ def import_reference_search():
         warnings.simplefilter("ignore")
         import meerqat.ir.search as ref_search
     return ref_search
+
+
+def import_reference_fuse():
+    install_stubs()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import meerqat.ir.fuse as ref_fuse
+    return ref_fuse
 
 
 def import_reference_embedding():

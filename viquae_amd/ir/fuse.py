@@ -1,0 +1,169 @@
+"""Mirror of ``meerqat.ir.fuse`` for the configuration the shipped experiments use:
+``Fusion(qrels, runs, norm="gzmuv", method="wsum", output, defmin=True).test(best_params={"weights": [...]})``
+(meerqat/ir/fuse.py:158-186,215-236; experiments/ir/viquae/dpr+clip/config.json:38-45), called by
+``dataset_search`` (meerqat/ir/search.py:514-524).
+
+The arithmetic -- ``default_minimum`` (:129-146), ``gzmuv_norm`` (:86-126), ranx's ``zmuv`` norm and ``wsum``
+fusion -- runs on the MI355X (``viquae_amd/csrc/fuse.hip`` through ``mq_fuse_wsum_f64``): runs are laid out as
+padded ``[n_runs, nq, K]`` tables of (integer document id, f64 score), one workgroup fuses one query.  There is
+no CPU fallback: without the HIP library and a GPU the call raises.
+
+What differs from the reference: ``fit`` (ranx's ``optimize_fusion`` grid search driven by a ranx metric) is
+evaluation tooling outside this build and needs ``ranx``; ``method`` other than ``"wsum"`` and ranx norms other
+than ``None`` / ``"zmuv"`` are not implemented; documents with EQUAL fused scores are ordered by ascending
+document id (the reference leaves that order to ranx's sort).  Results are plain ``{q_id: {doc_id: score}}``
+dicts, best first (wrapped in ``ranx.Run`` when ranx is importable).
+"""
+import ctypes
+import json
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+NORM_CODES = {None: 0, "gzmuv": 1, "zmuv": 2}
+MAX_ENTRIES = 4096  # n_runs * K limit of the kernel (include/meerqat_hip.h)
+
+
+def fuse_tables(ids, scores, weights, norm="gzmuv", defmin=False):
+    """Device-resident fusion.  ``ids`` int64 / ``scores`` f64 ``[n_runs, nq, K]`` on a GPU (-1 = empty slot) ->
+    ``(fused_ids [nq, n_runs*K], fused_scores, counts [nq] int32)``, best first."""
+    if norm not in NORM_CODES:
+        raise NotImplementedError(f"norm '{norm}': only None, 'gzmuv' and 'zmuv' run on the device")
+    lib = _lib.load()
+    _lib.require_gpu()
+    if ids.dim() != 3 or ids.shape != scores.shape:
+        raise ValueError("ids and scores must both be [n_runs, nq, K]")
+    if not ids.is_cuda or not scores.is_cuda:
+        raise ValueError("fuse_tables works on device tensors")
+    n_runs, nq, K = ids.shape
+    if len(weights) != n_runs:
+        raise ValueError(f"{len(weights)} weights for {n_runs} runs")
+    ids = ids.to(torch.int64).contiguous()
+    scores = scores.to(torch.float64).contiguous()
+    dev = ids.device
+    out_ids = torch.empty((nq, n_runs * K), dtype=torch.int64, device=dev)
+    out_scores = torch.empty((nq, n_runs * K), dtype=torch.float64, device=dev)
+    counts = torch.empty((nq,), dtype=torch.int32, device=dev)
+    if nq == 0:
+        return out_ids, out_scores, counts
+    ws_bytes = lib.mq_fuse_workspace_bytes(n_runs, nq, K)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    w = (ctypes.c_double * n_runs)(*[float(x) for x in weights])
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.mq_fuse_wsum_f64(ids.data_ptr(), scores.data_ptr(), n_runs, nq, K, w, NORM_CODES[norm],
+                                        int(bool(defmin)), out_ids.data_ptr(), out_scores.data_ptr(),
+                                        counts.data_ptr(), ws.data_ptr(), ws_bytes, stream), "mq_fuse_wsum_f64")
+    return out_ids, out_scores, counts
+
+
+def _as_dict(run):
+    if isinstance(run, (str, Path)):
+        with open(run, "rt") as file:
+            return json.load(file)
+    if hasattr(run, "to_dict"):
+        return run.to_dict()
+    if hasattr(run, "run"):
+        return {q: dict(results) for q, results in run.run.items()}
+    return run
+
+
+def runs_to_tables(runs, device="cuda:0"):
+    """``[{q_id: {doc_id: score}}]`` -> ``(q_ids, doc_names, ids, scores)`` with ids / scores ``[n_runs, nq, K]`` on
+    ``device``.  Document ids that are all decimal strings keep their integer value; otherwise they are numbered
+    in sorted order and ``doc_names`` holds the inverse."""
+    q_ids = list(runs[0].keys())
+    for run in runs[1:]:
+        if run.keys() != runs[0].keys():
+            raise ValueError("all runs must hold the same queries (Searcher fills every index for every question)")
+    docs = set()
+    for run in runs:
+        for results in run.values():
+            docs |= results.keys()
+    numeric = all(isinstance(d, str) and d.isdecimal() for d in docs)
+    doc_names = None
+    if numeric:
+        to_int = int
+    else:
+        doc_names = sorted(docs, key=str)
+        lookup = {d: i for i, d in enumerate(doc_names)}
+        to_int = lookup.__getitem__
+    K = max([1] + [len(results) for run in runs for results in run.values()])
+    if len(runs) * K > MAX_ENTRIES:
+        raise ValueError(f"{len(runs)} runs x {K} results per query exceed the kernel's {MAX_ENTRIES} entries")
+    ids = np.full((len(runs), len(q_ids), K), -1, dtype=np.int64)
+    scores = np.zeros((len(runs), len(q_ids), K), dtype=np.float64)
+    for r, run in enumerate(runs):
+        for q, q_id in enumerate(q_ids):
+            results = run[q_id]
+            n = len(results)
+            if n:
+                ids[r, q, :n] = [to_int(d) for d in results.keys()]
+                scores[r, q, :n] = list(results.values())
+    return q_ids, doc_names, torch.from_numpy(ids).to(device), torch.from_numpy(scores).to(device)
+
+
+def tables_to_run(q_ids, doc_names, fused_ids, fused_scores, counts):
+    fused_ids, fused_scores, counts = fused_ids.cpu().numpy(), fused_scores.cpu().numpy(), counts.cpu().numpy()
+    run = {}
+    for q, q_id in enumerate(q_ids):
+        n = int(counts[q])
+        names = fused_ids[q, :n].tolist()
+        names = [str(i) for i in names] if doc_names is None else [doc_names[i] for i in names]
+        run[q_id] = dict(zip(names, fused_scores[q, :n].tolist()))
+    return run
+
+
+def fuse_runs(runs, weights, norm="gzmuv", defmin=False, device="cuda:0"):
+    """dict runs in, fused dict run out; the arithmetic happens in ``fuse_tables``."""
+    runs = [_as_dict(run) for run in runs]
+    q_ids, doc_names, ids, scores = runs_to_tables(runs, device)
+    return tables_to_run(q_ids, doc_names, *fuse_tables(ids, scores, weights, norm=norm, defmin=defmin))
+
+
+class Fusion:
+    """Same constructor as the reference's (meerqat/ir/fuse.py:158-186).  ``runs``: dicts, ranx ``Run`` objects or
+    paths to JSON runs; ``qrels`` is only used by the ranx-backed metric report / ``fit``."""
+
+    def __init__(self, qrels=None, runs=None, norm="zmuv", method="wsum", output=None, defmin=False, device="cuda:0"):
+        self.qrels = qrels
+        self.runs = [_as_dict(run) for run in runs]
+        self.norm = norm
+        self.method = method
+        self.defmin = defmin
+        self.device = device
+        if output is not None:
+            output = Path(output)
+            output.mkdir(exist_ok=True)
+        self.output = output
+
+    def fit(self, metric="mrr@100"):
+        try:
+            import ranx  # noqa: F401
+        except ImportError as e:
+            raise ImportError("Fusion.fit is ranx.optimize_fusion (a metric-driven grid search over the weights); "
+                              "it is evaluation tooling outside this build and needs ranx installed") from e
+        raise NotImplementedError("Fusion.fit: run the reference's fit, then pass best_params to Fusion.test here")
+
+    def test(self, best_params, metrics=None):
+        if self.method != "wsum":
+            raise NotImplementedError(f"method '{self.method}': only 'wsum' (the shipped configs' method) is implemented")
+        weights = best_params["weights"]
+        fused = fuse_runs(self.runs, weights, norm=self.norm, defmin=self.defmin, device=self.device)
+        if self.output is not None:
+            with open(self.output / "test_run.json", "wt") as file:
+                json.dump(fused, file)
+        try:
+            import ranx
+        except ImportError:
+            return fused
+        combined = ranx.Run(fused, name="fusion")
+        if self.qrels is not None:
+            if metrics is None:
+                metrics = ["mrr@100", "precision@1", "precision@20", "hit_rate@20"]
+            qrels = self.qrels if isinstance(self.qrels, ranx.Qrels) else ranx.Qrels(_as_dict(self.qrels))
+            print(ranx.evaluate(qrels, combined, metrics))
+        return combined

@@ -9,7 +9,8 @@ relevance judgement of retrieved passages against the reference KB (:442-457, ``
 meerqat/ir/metrics.py:79-124 for string answers).
 What differs: no Elasticsearch client is constructed (sparse kinds are outside this build); ``ranx`` is
 optional -- without it ``dataset_search`` returns plain dicts and skips the metric report; numerical
-(InfoSeek) question types are not judged here.
+(InfoSeek) question types are not judged here.  With several indexes the runs are fused like the reference
+does (:514-524) through ``viquae_amd.ir.fuse.Fusion`` (HIP kernels); the fused run is ``searcher.fusion``.
 
 The reference builds the run with a Python triple loop per batch (256 x 100 dict inserts); here the
 [nq, k] arrays of one batch are expanded with numpy (CSR gather over ``index_mapping``) before the single
@@ -197,11 +198,20 @@ def dataset_search(dataset, k=100, metric_save_path=None, map_kwargs={}, **kwarg
     try:
         import ranx
     except ImportError:
-        return searcher
-    qrels = ranx.Qrels(searcher.qrels)
-    runs = [ranx.Run(run, name=name) for name, run in searcher.runs.items()]
-    report = ranx.compare(qrels, runs=runs, **searcher.metrics_kwargs)
-    print(report)
-    if metric_save_path is not None:
-        report.save(metric_save_path / "metrics.json")
+        ranx = None
+    if ranx is not None:
+        qrels = ranx.Qrels(searcher.qrels)
+        runs = [ranx.Run(run, name=name) for name, run in searcher.runs.items()]
+        report = ranx.compare(qrels, runs=runs, **searcher.metrics_kwargs)
+        print(report)
+        if metric_save_path is not None:
+            report.save(metric_save_path / "metrics.json")
+    # late fusion of the searches (reference: search.py:514-524), on the device
+    if searcher.do_fusion:
+        from .fuse import Fusion
+        fusion_kwargs = dict(searcher.fusion_kwargs)
+        subcommand = fusion_kwargs.pop("subcommand")
+        subcommand_kwargs = fusion_kwargs.pop("subcommand_kwargs", {})
+        fuser = Fusion(qrels=searcher.qrels, runs=list(searcher.runs.values()), output=metric_save_path, **fusion_kwargs)
+        searcher.fusion = getattr(fuser, subcommand)(**subcommand_kwargs)
     return searcher
