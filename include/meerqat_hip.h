@@ -173,6 +173,19 @@ int mq_clip_assemble_ln_f32(const float *patch_emb_dev, const float *class_emb_d
                             const float *gamma_dev, const float *beta_dev, float *out_dev, int B, int tokens, int H,
                             float eps, void *stream);
 
+/* CLIPModel.get_text_features (the `call` of experiments/ir/viquae/clip/config.json:15):
+ * mq_attention_causal_f32 = mq_attention_f32 with the text tower's causal mask (key <= query) on top of the
+ * optional padding mask; mq_clip_text_embed_f32 = token + position embeddings -> out [B*L, H];
+ * mq_clip_eos_pool_ln_f32 = final LayerNorm of the hidden state at the end-of-text token of each sequence
+ * (eos_token_id == 2, the published checkpoints' legacy config: position of the largest id; otherwise the first
+ * position equal to eos_token_id) -> out [B, H]. */
+int mq_attention_causal_f32(const float *qkv_dev, const int64_t *attention_mask_dev, float *out_dev, int B, int L, int heads,
+                            int head_dim, float scale, int causal, void *stream);
+int mq_clip_text_embed_f32(const int64_t *input_ids_dev, const float *token_emb_dev, const float *pos_emb_dev, float *out_dev,
+                           int B, int L, int H, void *stream);
+int mq_clip_eos_pool_ln_f32(const float *hidden_dev, const int64_t *input_ids_dev, int64_t eos_token_id, const float *gamma_dev,
+                            const float *beta_dev, float *out_dev, int B, int L, int H, float eps, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Late fusion of several runs on the device: replaces, for integer document
  * ids, `default_minimum` (meerqat/ir/fuse.py:129-146), `gzmuv_norm` (:86-126) and ranx's

@@ -37,6 +37,13 @@ CLIP_VITB32 = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12
                    image_size=224, patch_size=32, num_channels=3, projection_dim=512, layer_norm_eps=1e-5)
 CLIP_TINY = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
                  image_size=64, patch_size=32, num_channels=3, projection_dim=64, layer_norm_eps=1e-5)
+# CLIP text tower of clip-vit-base-patch32 (experiments/ir/viquae/clip/config.json); eos_token_id 2 is what the
+# published checkpoint's config.json carries (HF's legacy "EOT = largest id" pooling)
+CLIP_TEXT_VITB32 = dict(vocab_size=49408, hidden_size=512, num_hidden_layers=12, num_attention_heads=8,
+                        intermediate_size=2048, max_position_embeddings=77, projection_dim=512, layer_norm_eps=1e-5,
+                        eos_token_id=2)
+CLIP_TEXT_TINY = dict(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                      max_position_embeddings=24, projection_dim=64, layer_norm_eps=1e-5, eos_token_id=2)
 
 
 def bert_param_shapes(cfg, prefix="ctx_encoder.bert_model."):
@@ -78,6 +85,29 @@ def clip_vision_param_shapes(cfg):
     }
     for i in range(cfg["num_hidden_layers"]):
         p = f"vision_model.encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[p + f"self_attn.{n}.weight"] = (H, H)
+            s[p + f"self_attn.{n}.bias"] = (H,)
+        for n in ("layer_norm1", "layer_norm2"):
+            s[p + n + ".weight"] = (H,)
+            s[p + n + ".bias"] = (H,)
+        s[p + "mlp.fc1.weight"] = (I, H)
+        s[p + "mlp.fc1.bias"] = (I,)
+        s[p + "mlp.fc2.weight"] = (H, I)
+        s[p + "mlp.fc2.bias"] = (H,)
+    return s
+
+
+def clip_text_param_shapes(cfg):
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    s = {
+        "text_model.embeddings.token_embedding.weight": (cfg["vocab_size"], H),
+        "text_model.embeddings.position_embedding.weight": (cfg["max_position_embeddings"], H),
+        "text_model.final_layer_norm.weight": (H,), "text_model.final_layer_norm.bias": (H,),
+        "text_projection.weight": (cfg["projection_dim"], H),
+    }
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"text_model.encoder.layers.{i}."
         for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
             s[p + f"self_attn.{n}.weight"] = (H, H)
             s[p + f"self_attn.{n}.bias"] = (H,)
@@ -215,4 +245,40 @@ def clip_vision_forward(state, cfg, pixel_values, return_hidden=False):
         hidden.append(h)
     pooled = layer_norm(h[:, 0, :], state["vision_model.post_layernorm.weight"], state["vision_model.post_layernorm.bias"], eps)
     out = linear(pooled, state["visual_projection.weight"])
+    return (out, hidden) if return_hidden else out
+
+
+def clip_text_forward(state, cfg, input_ids, attention_mask=None, return_hidden=False):
+    """CLIPModel.get_text_features: text_projection(final_layer_norm(encoder(tok + pos, causal & padding mask))[EOT]).
+    Follows transformers' CLIPTextModel.forward (modeling_clip.py): pre-LN blocks, quick_gelu, q scaled by dh^-0.5,
+    EOT row = argmax of the ids when eos_token_id == 2 (legacy configs), else the first eos_token_id."""
+    ids = np.asarray(input_ids, dtype=np.int64)
+    B, L = ids.shape
+    H, heads, eps = cfg["hidden_size"], cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    h = (state["text_model.embeddings.token_embedding.weight"][ids]
+         + state["text_model.embeddings.position_embedding.weight"][None, :L]).astype(F32)
+    allowed = np.tril(np.ones((L, L), dtype=bool))[None, None]
+    if attention_mask is not None:
+        allowed = allowed & (np.asarray(attention_mask) != 0)[:, None, None, :]
+    add_mask = np.where(allowed, F32(0), F32(-np.inf)).astype(F32)
+    hidden = [h]
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"text_model.encoder.layers.{i}."
+        r = h
+        y = layer_norm(h, state[p + "layer_norm1.weight"], state[p + "layer_norm1.bias"], eps)
+        q = linear(y, state[p + "self_attn.q_proj.weight"], state[p + "self_attn.q_proj.bias"])
+        k = linear(y, state[p + "self_attn.k_proj.weight"], state[p + "self_attn.k_proj.bias"])
+        v = linear(y, state[p + "self_attn.v_proj.weight"], state[p + "self_attn.v_proj.bias"])
+        ctx = mha(q, k, v, heads, add_mask, scale_q=True)
+        h = r + linear(ctx, state[p + "self_attn.out_proj.weight"], state[p + "self_attn.out_proj.bias"])
+        r = h
+        y = layer_norm(h, state[p + "layer_norm2.weight"], state[p + "layer_norm2.bias"], eps)
+        y = quick_gelu(linear(y, state[p + "mlp.fc1.weight"], state[p + "mlp.fc1.bias"]))
+        h = (r + linear(y, state[p + "mlp.fc2.weight"], state[p + "mlp.fc2.bias"])).astype(F32)
+        hidden.append(h)
+    eos = cfg.get("eos_token_id", 2)
+    at = ids.astype(np.int32).argmax(axis=1) if eos == 2 else (ids == eos).astype(np.int32).argmax(axis=1)
+    pooled = layer_norm(h[np.arange(B), at], state["text_model.final_layer_norm.weight"],
+                        state["text_model.final_layer_norm.bias"], eps)
+    out = linear(pooled, state["text_projection.weight"])
     return (out, hidden) if return_hidden else out

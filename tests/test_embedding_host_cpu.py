@@ -147,3 +147,23 @@ def test_encoder_oracle_matches_hf_goldens(name, cfgname, kind):
         state = oe.seeded_state(oe.clip_vision_param_shapes(cfg), int(z["seed"]))
         out = oe.clip_vision_forward(state, cfg, z["pixel_values"].astype(np.float32))
         assert np.abs(out - z["image_features"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("name,eos", [("clip_text_tiny", 2), ("clip_text_tiny_eos", 299)])
+def test_clip_text_oracle_matches_hf_goldens(name, eos):
+    """CLIP text tower: numpy oracle vs HF CLIPModel.get_text_features driven through the reference's embed()."""
+    from oracle import encoders as oe
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{name}.npz"))
+    cfg = dict(oe.CLIP_TEXT_TINY, eos_token_id=eos)
+    state = oe.seeded_state(oe.clip_text_param_shapes(cfg), int(z["seed"]))
+    out = oe.clip_text_forward(state, cfg, z["input_ids"], z["attention_mask"])
+    assert out.shape == z["text_features"].shape
+    assert np.abs(out - z["text_features"]).max() < 2e-5
+    # causal: the pooled EOT state does not depend on what follows it
+    ids2 = z["input_ids"].copy()
+    lens = z["attention_mask"].sum(axis=1)
+    if eos == 2:
+        for b, n in enumerate(lens):
+            ids2[b, n:] = 5
+        out2 = oe.clip_text_forward(state, cfg, ids2, None)
+        assert np.abs(out2 - out).max() < 1e-6

@@ -181,3 +181,96 @@ def test_from_pretrained_reads_hf_checkpoint_dir(tmp_path):
     got = model(input_ids=_cuda(ids))["pooler_output"].cpu().numpy()
     ref = oe.bert_forward(state, cfg, ids, prefix="question_encoder.bert_model.")
     assert np.abs(got - ref).max() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------
+# CLIP text tower (experiments/ir/viquae/clip/config.json: call = get_text_features)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,L,heads", [(3, 19, 2), (2, 77, 8), (1, 130, 1), (2, 200, 2)])
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_causal_attention_vs_torch(B, L, heads, with_mask):
+    from viquae_amd import encoders as E
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + L + heads)
+    H = heads * 64
+    qkv = torch.randn((B * L, 3 * H), generator=g, device="cuda")
+    mask = None
+    if with_mask:
+        lens = torch.randint(1, L + 1, (B,), generator=g, device="cuda")
+        mask = (torch.arange(L, device="cuda")[None] < lens[:, None]).to(torch.int64)
+    out = E.attention(qkv, mask, B, L, heads, 0.125, causal=True)
+    q, k, v = [t.reshape(B, L, heads, 64).transpose(1, 2).double() for t in qkv.view(B, L, 3 * H).split(H, dim=2)]
+    s = q @ k.transpose(-1, -2) * 0.125
+    allowed = torch.tril(torch.ones((L, L), dtype=torch.bool, device="cuda"))[None, None]
+    if mask is not None:
+        allowed = allowed & (mask != 0)[:, None, None, :]
+    s = s.masked_fill(~allowed, float("-inf"))
+    ref = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B * L, H)
+    assert (out.double() - ref).abs().max().item() < 2e-5   # fp32 softmax / accumulation over <= 200 keys
+
+
+def test_clip_text_embed_and_eos_pool_ops():
+    from viquae_amd import _lib
+    from viquae_amd.encoders import _stream, layernorm
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, L, H, V = 9, 21, 192, 500
+    tok = torch.randn((V, H), generator=g, device="cuda")
+    pos = torch.randn((L + 3, H), generator=g, device="cuda")
+    ids = torch.randint(3, V - 1, (B, L), generator=g, device="cuda")
+    ids[:, 5] = V - 1
+    ids[0, 17] = V - 1           # a second maximum: the first one counts
+    ids[1, 2] = 7
+    ids[1, 9] = 7                # eos = 7: first occurrence is position 2
+    out = torch.empty((B * L, H), device="cuda")
+    _lib.check(lib.mq_clip_text_embed_f32(ids.data_ptr(), tok.data_ptr(), pos.data_ptr(), out.data_ptr(), B, L, H, _stream(out)))
+    assert torch.equal(out.view(B, L, H), tok[ids] + pos[None, :L])
+    gam, bet = torch.randn(H, generator=g, device="cuda"), torch.randn(H, generator=g, device="cuda")
+    pooled = torch.empty((B, H), device="cuda")
+    for eos, want_at in [(2, ids.to(torch.int32).argmax(dim=1)), (7, (ids == 7).int().argmax(dim=1))]:
+        _lib.check(lib.mq_clip_eos_pool_ln_f32(out.data_ptr(), ids.data_ptr(), eos, gam.data_ptr(), bet.data_ptr(),
+                                               pooled.data_ptr(), B, L, H, 1e-5, _stream(out)))
+        rows = out.view(B, L, H)[torch.arange(B, device="cuda"), want_at].contiguous()
+        assert torch.equal(pooled, layernorm(rows, gam, bet, 1e-5))
+        assert (pooled - torch.nn.functional.layer_norm(rows, (H,), gam, bet, 1e-5)).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("name,cfgname,eos", [("clip_text_tiny", "CLIP_TEXT_TINY", 2), ("clip_text_tiny_eos", "CLIP_TEXT_TINY", 299),
+                                              ("clip_text_vitb32_4", "CLIP_TEXT_VITB32", 2)])
+def test_clip_text_matches_hf_golden(name, cfgname, eos):
+    from oracle import encoders as oe
+    from viquae_amd.encoders import CLIPModel
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    cfg = dict(getattr(oe, cfgname), eos_token_id=eos)
+    state = oe.seeded_state(oe.clip_text_param_shapes(cfg), int(z["seed"]))
+    model = CLIPModel.from_state_dict({"text_config": dict(cfg, hidden_act="quick_gelu")}, state).to("cuda").eval()
+    got = model.get_text_features(input_ids=_cuda(z["input_ids"]), attention_mask=_cuda(z["attention_mask"]))
+    assert isinstance(got, torch.Tensor) and got.shape == z["text_features"].shape
+    assert np.abs(got.cpu().numpy() - z["text_features"]).max() < TOL
+    # without the padding mask the causal mask alone already isolates the EOT row
+    got2 = model.get_text_features(input_ids=_cuda(z["input_ids"]))
+    assert np.abs(got2.cpu().numpy() - z["text_features"]).max() < TOL
+    with pytest.raises(NotImplementedError):
+        model.get_image_features(pixel_values=torch.zeros((1, 3, 32, 32), device="cuda"))
+    with pytest.raises(ValueError):
+        model.get_text_features(input_ids=torch.ones((1, cfg["max_position_embeddings"] + 1), dtype=torch.long, device="cuda"))
+
+
+def test_clip_text_through_embed_mirror_like_reference_config():
+    """experiments/ir/viquae/clip/config.json: key wikipedia_title, call get_text_features, no output_key."""
+    from oracle import encoders as oe
+    from viquae_amd.encoders import CLIPModel
+    from viquae_amd.ir import embedding as IE
+    z = np.load(os.path.join(GOLDEN, "clip_text_tiny.npz"))
+    cfg = oe.CLIP_TEXT_TINY
+    state = oe.seeded_state(oe.clip_text_param_shapes(cfg), int(z["seed"]))
+    model = CLIPModel.from_state_dict({"text_config": cfg}, state).to("cuda").eval()
+
+    class Tok:
+        def __call__(self, texts, **kw):
+            assert kw.get("return_tensors") == "pt"
+            return {"input_ids": torch.from_numpy(z["input_ids"]), "attention_mask": torch.from_numpy(z["attention_mask"])}
+    batch = {"wikipedia_title": ["t"] * len(z["input_ids"])}
+    out = IE.embed(batch, model, Tok(), tokenization_kwargs={"return_tensors": "pt", "max_length": 77, "padding": "longest"},
+                   key="wikipedia_title",
+                   save_as="title_clip", call="get_text_features")
+    assert np.abs(np.asarray(out["title_clip"]) - z["text_features"]).max() < TOL

@@ -55,6 +55,29 @@ def random_clip_state(cfg, seed):
     return st
 
 
+CLIP_TEXT_VITB32 = dict(vocab_size=49408, hidden_size=512, num_hidden_layers=12, num_attention_heads=8, intermediate_size=2048,
+                        max_position_embeddings=77, projection_dim=512, layer_norm_eps=1e-5, eos_token_id=2)
+
+
+def random_clip_text_state(cfg, seed):
+    g = torch.Generator().manual_seed(seed)
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    r = lambda *s: torch.randn(*s, generator=g) * 0.02  # noqa: E731
+    st = {"text_model.embeddings.token_embedding.weight": r(cfg["vocab_size"], H),
+          "text_model.embeddings.position_embedding.weight": r(cfg["max_position_embeddings"], H),
+          "text_model.final_layer_norm.weight": 1 + r(H), "text_model.final_layer_norm.bias": r(H),
+          "text_projection.weight": r(cfg["projection_dim"], H)}
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"text_model.encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            st[p + f"self_attn.{n}.weight"], st[p + f"self_attn.{n}.bias"] = r(H, H), r(H)
+        for n in ("layer_norm1", "layer_norm2"):
+            st[p + n + ".weight"], st[p + n + ".bias"] = 1 + r(H), r(H)
+        st[p + "mlp.fc1.weight"], st[p + "mlp.fc1.bias"] = r(I, H), r(I)
+        st[p + "mlp.fc2.weight"], st[p + "mlp.fc2.bias"] = r(H, I), r(H)
+    return st
+
+
 def time_it(fn, steps, warmup=1):
     for _ in range(warmup):
         fn()
@@ -85,5 +108,19 @@ def clip_throughput(B=3072, steps=2, device="cuda"):
     return {"images_per_s": B / t, "ms_per_batch": t * 1e3, "batch": B, "tflops": 8.82e9 * B / t / 1e12}
 
 
+def clip_text_throughput(B=2048, L=77, steps=2, device="cuda"):
+    """experiments/ir/viquae/clip/config.json: batches of 2048 titles, at most 77 tokens (worst case: all 77 long)."""
+    cfg = CLIP_TEXT_VITB32
+    model = CLIPModel.from_state_dict({"text_config": dict(cfg)}, random_clip_text_state(cfg, 0)).to(device).eval()
+    g = torch.Generator(device=device).manual_seed(3)
+    ids = torch.randint(3, cfg["vocab_size"] - 2, (B, L), generator=g, device=device)
+    ids[:, 0], ids[:, -1] = cfg["vocab_size"] - 2, cfg["vocab_size"] - 1
+    mask = torch.ones((B, L), dtype=torch.int64, device=device)
+    t = time_it(lambda: model.get_text_features(input_ids=ids, attention_mask=mask), steps)
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    flops = cfg["num_hidden_layers"] * (2 * L * (4 * H * H + 2 * H * I) + 4 * L * L * H) * B
+    return {"titles_per_s": B / t, "ms_per_batch": t * 1e3, "batch": B, "seq_len": L, "tflops": flops / t / 1e12}
+
+
 if __name__ == "__main__":
-    print(json.dumps({"dpr": dpr_throughput(), "clip": clip_throughput()}))
+    print(json.dumps({"dpr": dpr_throughput(), "clip": clip_throughput(), "clip_text": clip_text_throughput()}))

@@ -73,6 +73,69 @@ def _clip(cfg, seed, pixels):
     return out.numpy().astype(np.float32), state
 
 
+def _clip_text(cfg, seed, ids, mask):
+    """HF CLIPModel.get_text_features (the `call` of experiments/ir/viquae/clip/config.json:15) on seeded weights,
+    driven through the REFERENCE's embed() like the DPR goldens."""
+    from transformers import CLIPConfig, CLIPModel, CLIPVisionConfig, CLIPTextConfig
+    t = CLIPTextConfig(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], num_hidden_layers=cfg["num_hidden_layers"],
+                       num_attention_heads=cfg["num_attention_heads"], intermediate_size=cfg["intermediate_size"],
+                       max_position_embeddings=cfg["max_position_embeddings"], projection_dim=cfg["projection_dim"],
+                       layer_norm_eps=cfg["layer_norm_eps"], hidden_act="quick_gelu", eos_token_id=cfg["eos_token_id"],
+                       bos_token_id=0, pad_token_id=1)
+    v = CLIPVisionConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=64, image_size=32,
+                         patch_size=16, projection_dim=cfg["projection_dim"])
+    model = CLIPModel(CLIPConfig(text_config=t.to_dict(), vision_config=v.to_dict(), projection_dim=cfg["projection_dim"])).eval()
+    state = oe.seeded_state(oe.clip_text_param_shapes(cfg), seed)
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v_) for k, v_ in state.items()}, strict=False)
+    assert not unexpected, unexpected
+    assert all(m.startswith(("vision_model", "visual_projection", "logit_scale")) or "position_ids" in m for m in missing), missing
+    from tools import ref_import
+    ref = ref_import.import_reference_embedding()
+    enc = {"input_ids": ids, "attention_mask": mask}
+    batch = {"title": ["x"] * len(ids)}
+    out = ref.embed(batch, model, _FakeTokenizer(enc), key="title", save_as="emb", call="get_text_features",
+                    output_key="pooler_output")
+    return np.asarray(out["emb"], dtype=np.float32), state
+
+
+def _titles(rng, B, L, vocab, eos, pad, legacy):
+    """Token ids shaped like CLIPTokenizer output: <bos> words <eos> <pad>...; with the legacy config (eos_token_id 2)
+    the EOT token must be the largest id of the row, as in the published vocabulary (49407)."""
+    ids = np.full((B, L), pad, dtype=np.int64)
+    mask = np.zeros((B, L), dtype=np.int64)
+    lens = rng.integers(3, L + 1, B)
+    lens[0], lens[-1] = L, 3
+    eot = vocab - 1 if legacy else eos
+    for b, n in enumerate(lens):
+        ids[b, 0] = vocab - 2 if legacy else 0
+        ids[b, 1:n - 1] = rng.integers(3, vocab - 2, n - 2)
+        ids[b, n - 1] = eot
+        mask[b, :n] = 1
+    return ids, mask
+
+
+def main_clip_text():
+    rng = np.random.default_rng(9)
+    cfg = oe.CLIP_TEXT_TINY
+    ids, mask = _titles(rng, 7, 19, cfg["vocab_size"], cfg["eos_token_id"], 1, legacy=True)
+    out, state = _clip_text(cfg, 31, ids, mask)
+    print("clip text tiny |oracle - HF| max", np.abs(oe.clip_text_forward(state, cfg, ids, mask) - out).max())
+    np.savez_compressed(os.path.join(GOLDEN, "clip_text_tiny.npz"), input_ids=ids, attention_mask=mask, text_features=out, seed=31)
+    # current-style config: pooling at the FIRST eos_token_id (pad may equal eos)
+    cfg2 = dict(cfg, eos_token_id=299)
+    ids, mask = _titles(rng, 6, 24, cfg2["vocab_size"], 299, 299, legacy=False)
+    out, state = _clip_text(cfg2, 32, ids, mask)
+    print("clip text tiny (eos 299) |oracle - HF| max", np.abs(oe.clip_text_forward(state, cfg2, ids, mask) - out).max())
+    np.savez_compressed(os.path.join(GOLDEN, "clip_text_tiny_eos.npz"), input_ids=ids, attention_mask=mask, text_features=out,
+                        seed=32, eos_token_id=299)
+    cfg = oe.CLIP_TEXT_VITB32
+    ids, mask = _titles(rng, 4, 77, cfg["vocab_size"], cfg["eos_token_id"], 1, legacy=True)
+    out, state = _clip_text(cfg, 33, ids, mask)
+    print("clip text vitb32 |oracle - HF| max", np.abs(oe.clip_text_forward(state, cfg, ids, mask) - out).max())
+    np.savez_compressed(os.path.join(GOLDEN, "clip_text_vitb32_4.npz"), input_ids=ids, attention_mask=mask, text_features=out,
+                        seed=33)
+
+
 def main():
     rng = np.random.default_rng(7)
     # ---- DPR tiny: ragged attention masks, token types, via the reference's embed()
@@ -117,4 +180,6 @@ def main():
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
-    main()
+    if "--clip-text-only" not in sys.argv:
+        main()
+    main_clip_text()

@@ -520,7 +520,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 template <int NKT>  // key tiles of 32: L <= 32 * NKT
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, const long long* __restrict__ mask,
-                                                             float* __restrict__ out, int L, int heads, float scale) {
+                                                             float* __restrict__ out, int L, int heads, float scale,
+                                                             int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NK = 32 * NKT;
     float* Ks = reinterpret_cast<float*>(smem);        // [NK][65]
@@ -568,7 +569,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int key = 32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-            const float sv = sacc[t][reg] * scale + addm[key];
+            float sv = sacc[t][reg] * scale + addm[key];
+            if (causal && key > qrow) sv = -INFINITY;   // CLIP text tower: a token attends to itself and the past
             sacc[t][reg] = sv;
             mx = fmaxf(mx, sv);
         }
@@ -614,6 +616,48 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         const int qr = blockIdx.y * 128 + 32 * w + r;
         if (qr < L) out[((size_t)bi * L + qr) * H + h * DH + c] = Ot[r * 65 + c];
     }
+}
+
+// CLIP text tower input: token embedding + position embedding (no LayerNorm, no token types)
+__global__ __launch_bounds__(256) void clip_text_embed_kernel(const long long* __restrict__ ids, const float* __restrict__ tok,
+                                                              const float* __restrict__ pos, float* __restrict__ out, int M,
+                                                              int L, int H) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const long long id = ids[row];
+    const int t_pos = row % L;
+    for (int c = lane; c < H; c += 64) out[(size_t)row * H + c] = tok[(size_t)id * H + c] + pos[(size_t)t_pos * H + c];
+}
+
+// CLIP text pooling: the hidden state at the end-of-text token, through the final LayerNorm (LayerNorm is row-wise,
+// so normalising only the pooled row equals HF's "normalise everything, then gather").  eos_token_id == 2 is the
+// legacy config of the published checkpoints: the EOT token is the LARGEST id of the sequence (first occurrence);
+// otherwise the first position holding eos_token_id (position 0 if there is none, like torch's argmax of zeros).
+__global__ __launch_bounds__(256) void clip_eos_pool_ln_kernel(const float* __restrict__ X, const long long* __restrict__ ids,
+                                                               long long eos, const float* __restrict__ g,
+                                                               const float* __restrict__ b, float* __restrict__ out, int B,
+                                                               int L, int H, float eps) {
+    const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (seq >= B) return;
+    long long best = -0x7fffffffffffffffLL - 1;
+    int at = 0x7fffffff;
+    for (int j = lane; j < L; j += 64) {
+        const long long id = ids[(size_t)seq * L + j];
+        const long long val = (eos == 2) ? (long long)(int)id : (long long)(id == eos);   // HF casts the ids to int32
+        if (val > best) { best = val; at = j; }   // ascending j per lane: keeps the first occurrence
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long ob = __shfl_xor(best, o);
+        const int oa = __shfl_xor(at, o);
+        if (ob > best || (ob == best && oa < at)) { best = ob; at = oa; }
+    }
+    const size_t row = (size_t)seq * L + at;
+    float v[LN_MAXPER];
+#pragma unroll
+    for (int t = 0; t < LN_MAXPER; ++t) { const int c = lane + 64 * t; v[t] = (c < H) ? X[row * H + c] : 0.f; }
+    ln_store(v, H, lane, g, b, eps, out + (size_t)seq * H);
 }
 
 }  // namespace
@@ -714,6 +758,11 @@ int mq_bert_embed_ln_f32(const int64_t* input_ids_dev, const int64_t* token_type
 
 int mq_attention_f32(const float* qkv_dev, const int64_t* attention_mask_dev, float* out_dev, int B, int L, int heads,
                      int head_dim, float scale, void* stream) {
+    return mq_attention_causal_f32(qkv_dev, attention_mask_dev, out_dev, B, L, heads, head_dim, scale, 0, stream);
+}
+
+int mq_attention_causal_f32(const float* qkv_dev, const int64_t* attention_mask_dev, float* out_dev, int B, int L, int heads,
+                            int head_dim, float scale, int causal, void* stream) {
     if (B == 0 || L == 0) return MQ_OK;
     if (!qkv_dev || !out_dev || B < 0 || L < 0 || heads <= 0) return MQ_EINVAL;
     if (head_dim != DH || L > 256) return MQ_EUNSUPPORTED;
@@ -724,12 +773,34 @@ int mq_attention_f32(const float* qkv_dev, const int64_t* attention_mask_dev, fl
         const size_t lds = (size_t)(32 * NKT) * (65 + 64 + 1) * 4 > (size_t)4 * 32 * 65 * 4 ? (size_t)(32 * NKT) * (65 + 64 + 1) * 4 : (size_t)4 * 32 * 65 * 4; \
         ENC_HIP(hipFuncSetAttribute((const void*)attention_mfma_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(attention_mfma_kernel<NKT>, grid, dim3(256), lds, st, qkv_dev, (const long long*)attention_mask_dev,    \
-                           out_dev, L, heads, scale);                                                                 \
+                           out_dev, L, heads, scale, causal ? 1 : 0);                                                 \
     }
     if (L <= 64) MQ_ATT(2)
     else if (L <= 128) MQ_ATT(4)
     else MQ_ATT(8)
 #undef MQ_ATT
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_clip_text_embed_f32(const int64_t* input_ids_dev, const float* token_emb_dev, const float* pos_emb_dev, float* out_dev,
+                           int B, int L, int H, void* stream) {
+    if (B == 0 || L == 0) return MQ_OK;
+    if (!input_ids_dev || !token_emb_dev || !pos_emb_dev || !out_dev || B < 0 || L < 0 || H <= 0) return MQ_EINVAL;
+    const int M = B * L;
+    hipLaunchKernelGGL(clip_text_embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)input_ids_dev, token_emb_dev, pos_emb_dev, out_dev, M, L, H);
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_clip_eos_pool_ln_f32(const float* hidden_dev, const int64_t* input_ids_dev, int64_t eos_token_id, const float* gamma_dev,
+                            const float* beta_dev, float* out_dev, int B, int L, int H, float eps, void* stream) {
+    if (B == 0) return MQ_OK;
+    if (!hidden_dev || !input_ids_dev || !gamma_dev || !beta_dev || !out_dev || B < 0 || L <= 0 || H <= 0) return MQ_EINVAL;
+    if (H > 64 * LN_MAXPER) return MQ_EUNSUPPORTED;
+    hipLaunchKernelGGL(clip_eos_pool_ln_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, hidden_dev,
+                       (const long long*)input_ids_dev, (long long)eos_token_id, gamma_dev, beta_dev, out_dev, B, L, H, eps);
     ENC_HIP(hipGetLastError());
     return MQ_OK;
 }

@@ -100,14 +100,15 @@ def layernorm(x, g, b, eps, out=None):
     return out
 
 
-def attention(qkv, mask, B, L, heads, scale):
+def attention(qkv, mask, B, L, heads, scale, causal=False):
     _check_cuda(qkv)
     lib = _lib.load()
     H = qkv.shape[1] // 3
     out = torch.empty((B * L, H), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        _lib.check(lib.mq_attention_f32(qkv.data_ptr(), mask.data_ptr() if mask is not None else None, out.data_ptr(), B, L,
-                                        heads, H // heads, float(scale), _stream(qkv)), "mq_attention_f32")
+        _lib.check(lib.mq_attention_causal_f32(qkv.data_ptr(), mask.data_ptr() if mask is not None else None, out.data_ptr(),
+                                               B, L, heads, H // heads, float(scale), int(bool(causal)), _stream(qkv)),
+                   "mq_attention_causal_f32")
     return out
 
 
@@ -278,13 +279,23 @@ class DPRQuestionEncoder(_DPREncoder):
 # CLIP vision tower
 # --------------------------------------------------------------------------------------------------
 class CLIPModel(_HipEncoder):
-    """transformers.CLIPModel restricted to ``get_image_features`` (the ``call`` of
-    experiments/image_embedding/clip/vit_config.json:18): ViT vision tower + visual projection."""
+    """transformers.CLIPModel restricted to the two calls the reference makes: ``get_image_features``
+    (experiments/image_embedding/clip/vit_config.json:18: ViT vision tower + visual projection) and
+    ``get_text_features`` (experiments/ir/viquae/clip/config.json:15: causal text tower, EOT pooling, text projection).
+    Either tower may be absent from the checkpoint; calling the missing one raises."""
     config_class = dict
 
     def __init__(self, config, state):
         super().__init__()
         self.config = dict(config)
+        self.has_vision = "vision_model.embeddings.class_embedding" in state
+        self.has_text = "text_model.embeddings.token_embedding.weight" in state
+        if not (self.has_vision or self.has_text):
+            raise ValueError("the checkpoint holds neither a CLIP vision tower nor a CLIP text tower")
+        if self.has_text:
+            self._init_text(config, state)
+        if not self.has_vision:
+            return
         v = dict(config.get("vision_config", config))
         self.hidden = int(v["hidden_size"])
         self.layers = int(v["num_hidden_layers"])
@@ -322,6 +333,41 @@ class CLIPModel(_HipEncoder):
             self._reg(f"l{i}_w2", s[p + "mlp.fc2.weight"])
             self._reg(f"l{i}_bb2", s[p + "mlp.fc2.bias"])
 
+    def _init_text(self, config, state):
+        t = dict(config.get("text_config", config))
+        self.t_hidden = int(t["hidden_size"])
+        self.t_layers = int(t["num_hidden_layers"])
+        self.t_heads = int(t["num_attention_heads"])
+        self.t_eps = float(t.get("layer_norm_eps", 1e-5))
+        self.t_eos = int(t.get("eos_token_id", 2))
+        self.t_max_pos = int(t.get("max_position_embeddings", 77))
+        act = t.get("hidden_act", "quick_gelu")
+        if act not in ("quick_gelu", "gelu"):
+            raise NotImplementedError(f"CLIP activation {act}")
+        self.t_act = EPI_BIAS_QUICKGELU if act == "quick_gelu" else EPI_BIAS_GELU
+        if self.t_hidden // self.t_heads != 64:
+            raise NotImplementedError("attention head size must be 64")
+        s = state
+        self._reg("t_tok", s["text_model.embeddings.token_embedding.weight"])
+        self._reg("t_pos", s["text_model.embeddings.position_embedding.weight"])
+        self._reg("t_fin_g", s["text_model.final_layer_norm.weight"])
+        self._reg("t_fin_b", s["text_model.final_layer_norm.bias"])
+        self._reg("t_wproj", s["text_projection.weight"])
+        for i in range(self.t_layers):
+            p = f"text_model.encoder.layers.{i}."
+            self._reg(f"t{i}_wqkv", torch.cat([_t(s[p + f"self_attn.{n}.weight"]) for n in ("q_proj", "k_proj", "v_proj")]))
+            self._reg(f"t{i}_bqkv", torch.cat([_t(s[p + f"self_attn.{n}.bias"]) for n in ("q_proj", "k_proj", "v_proj")]))
+            self._reg(f"t{i}_wo", s[p + "self_attn.out_proj.weight"])
+            self._reg(f"t{i}_bo", s[p + "self_attn.out_proj.bias"])
+            self._reg(f"t{i}_g1", s[p + "layer_norm1.weight"])
+            self._reg(f"t{i}_b1", s[p + "layer_norm1.bias"])
+            self._reg(f"t{i}_g2", s[p + "layer_norm2.weight"])
+            self._reg(f"t{i}_b2n", s[p + "layer_norm2.bias"])
+            self._reg(f"t{i}_w1", s[p + "mlp.fc1.weight"])
+            self._reg(f"t{i}_bb1", s[p + "mlp.fc1.bias"])
+            self._reg(f"t{i}_w2", s[p + "mlp.fc2.weight"])
+            self._reg(f"t{i}_bb2", s[p + "mlp.fc2.bias"])
+
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, **kwargs):
         config, state = read_checkpoint(pretrained_model_name_or_path)
@@ -332,11 +378,56 @@ class CLIPModel(_HipEncoder):
         return cls(config, state)
 
     def forward(self, *a, **k):
-        raise NotImplementedError("only get_image_features is on the reference's hot path "
-                                  "(experiments/image_embedding/clip/vit_config.json:18)")
+        raise NotImplementedError("only get_image_features / get_text_features are on the reference's path "
+                                  "(experiments/image_embedding/clip/vit_config.json:18, experiments/ir/viquae/clip/config.json:15)")
+
+    @torch.no_grad()
+    def get_text_features(self, input_ids=None, attention_mask=None, position_ids=None, **unused):
+        """-> f32 [B, projection_dim] tensor, like ``get_image_features`` and like the transformers releases the reference
+        pins (its config has no ``output_key``; ``embed`` ignores ``output_key`` for tensor outputs)."""
+        if not self.has_text:
+            raise NotImplementedError("this checkpoint has no text tower (text_model.* tensors)")
+        if position_ids is not None:
+            raise NotImplementedError("explicit position_ids")
+        _check_cuda(input_ids, self.t_tok)
+        lib = _lib.load()
+        ids = input_ids.to(torch.int64).contiguous()
+        if ids.dim() != 2:
+            raise ValueError("input_ids must be [batch, length]")
+        B, L = ids.shape
+        if L > self.t_max_pos:
+            raise ValueError(f"Sequence length must be less than max_position_embeddings (got `sequence length`: {L} "
+                             f"and max_position_embeddings: {self.t_max_pos}")
+        if B and (int(ids.min()) < 0 or int(ids.max()) >= self.t_tok.shape[0]):
+            raise IndexError("input_ids outside the vocabulary")
+        mask = attention_mask.to(torch.int64).contiguous() if attention_mask is not None else None
+        dev, H = ids.device, self.t_hidden
+        h = torch.empty((B * L, H), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mq_clip_text_embed_f32(ids.data_ptr(), self.t_tok.data_ptr(), self.t_pos.data_ptr(), h.data_ptr(),
+                                                  B, L, H, _stream(h)), "mq_clip_text_embed_f32")
+        scale = (H // self.t_heads) ** -0.5
+        for i in range(self.t_layers):
+            w = lambda n: getattr(self, f"t{i}_{n}")  # noqa: E731
+            sp = lambda n: self._ws(f"t{i}_{n}")  # noqa: E731
+            y = layernorm(h, w("g1"), w("b1"), self.t_eps)
+            qkv = gemm_nt(y, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
+            ctx = attention(qkv, mask, B, L, self.t_heads, scale, causal=True)
+            h = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("wo"))
+            y = layernorm(h, w("g2"), w("b2n"), self.t_eps, out=y)
+            f = gemm_nt(y, w("w1"), w("bb1"), None, self.t_act, wsplit=sp("w1"))
+            h = gemm_nt(f, w("w2"), w("bb2"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("w2"))
+        pooled = torch.empty((B, H), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mq_clip_eos_pool_ln_f32(h.data_ptr(), ids.data_ptr(), self.t_eos, self.t_fin_g.data_ptr(),
+                                                   self.t_fin_b.data_ptr(), pooled.data_ptr(), B, L, H, self.t_eps, _stream(h)),
+                       "mq_clip_eos_pool_ln_f32")
+        return gemm_nt(pooled, self.t_wproj, None, None, EPI_NONE, wsplit=self._ws("t_wproj"))
 
     @torch.no_grad()
     def get_image_features(self, pixel_values=None, **unused):
+        if not self.has_vision:
+            raise NotImplementedError("this checkpoint has no vision tower (vision_model.* tensors)")
         _check_cuda(pixel_values, self.cls)
         lib = _lib.load()
         px = pixel_values.to(torch.float32).contiguous()
