@@ -12,13 +12,21 @@ g = torch.Generator(device=dev); g.manual_seed(0)
 for s in range(0, N, 1 << 16):
     idx.add(torch.randn((min(1 << 16, N - s), d), generator=g, device=dev), total_hint=N)
 Q = torch.randn((nq, d), generator=g, device=dev)
-dbg = torch.zeros(256 * 16 * 4, dtype=torch.int64, device=dev)
+SCREEN = os.environ.get("SCREEN", "0") == "1"
+NS = 8 if SCREEN else 4
+dbg = torch.zeros(256 * 16 * NS, dtype=torch.int64, device=dev)
 os.environ["MQ_DBG_PTR"] = str(dbg.data_ptr())
 idx.search_device(Q, k); torch.cuda.synchronize()
 dbg.zero_()
 idx.search_device(Q, k); torch.cuda.synchronize()
-t = dbg.view(256, 16, 4).double()
+t = dbg.view(256, 16, NS).double()
 tot = t.sum(-1)
 print("per-wave total cycles: mean %.3e min %.3e max %.3e" % (tot.mean(), tot.min(), tot.max()))
-for i, name in enumerate(["K loop", "scan+append", "barrier", "compaction"]):
+names = (["K loop", "max16+publish", "appends", "barrier A", "refresh", "barrier B", "compaction", "need-check"] if SCREEN
+         else ["K loop", "scan+append", "barrier", "compaction"])
+if SCREEN:
+    print("compaction rounds per workgroup: mean %.1f max %.0f" % (t[..., 1].mean(), t[..., 1].max()))
+    t[..., 1] = 0
+    tot = t.sum(-1)
+for i, name in enumerate(names):
     print(f"{name:12s} mean {t[..., i].mean():.3e} ({100 * t[..., i].mean() / tot.mean():.2f} %)  max-wave {t[..., i].max():.3e}")

@@ -710,7 +710,8 @@ struct Geometry {
     size_t off_qp, off_qn, off_qtmp, off_lists, total;
     // screened path extras
     int dp;
-    size_t off_qb, off_margin, off_pcount, off_ovf, off_gthr, off_squant, off_cand, off_ckeys, off_ccount;
+    size_t off_qb, off_margin, off_pcount, off_ovf, off_gthr, off_squant, off_cand, off_ckeys, off_ccount, off_smax;
+    int ms;  // stripe-maxima slots per query
 };
 
 Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
@@ -759,6 +760,8 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
     g.off_cand = o;   o += nq1 * RMAX * 4;
     g.off_ckeys = o;  o += nq1 * RMAX * 8;
     g.off_ccount = o; o += (size_t)round_up((int64_t)nq1 * 4, 256);
+    g.ms = g.S * 16 < SMAX_SLOTS ? g.S * 16 : SMAX_SLOTS;
+    g.off_smax = o;   o += (size_t)g.nqpad * g.ms * 4;
     g.total = round_up((int64_t)o, 256);
     return g;
 }
@@ -967,6 +970,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
     MQ_HIP(hipMemsetAsync(Qb, 0, (size_t)g.nqpad * g.dp * 2, st));
     MQ_HIP(hipMemsetAsync(ovf, 0, (size_t)round_up((int64_t)g.nqt * 4, 256) + (size_t)g.nqpad * 4, st));  // ovf + gthr
+    MQ_HIP(hipMemsetAsync(ws + g.off_smax, 0, (size_t)g.nqpad * g.ms * 4, st));
     hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((nq + PANEL - 1) / PANEL)), dim3(256), 0, st, q_rm, (int64_t)nq, d,
                        g.dpad, (int64_t)0, 0, Qp, qn);
     MQ_HIP(hipGetLastError());
@@ -982,6 +986,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     {
         ScreenArgs a;
         a.Xb = bf16_dev; a.Qb = Qb; a.margin = margin; a.pools = pools; a.pcount = pcount; a.ovf = ovf; a.gthr = (unsigned*)(ws + g.off_gthr); a.squant = (unsigned*)(ws + g.off_squant);
+        a.smax = (unsigned*)(ws + g.off_smax); a.ms = g.ms;
         a.dbg = getenv("MQ_DBG_PTR") ? (unsigned long long*)strtoull(getenv("MQ_DBG_PTR"), nullptr, 0) : nullptr;
         a.N = N; a.dp = g.dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx; a.nchunks = g.nchunks;
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
