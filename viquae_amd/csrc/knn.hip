@@ -710,8 +710,8 @@ struct Geometry {
     size_t off_qp, off_qn, off_qtmp, off_lists, total;
     // screened path extras
     int dp;
-    size_t off_qb, off_margin, off_pcount, off_ovf, off_gthr, off_squant, off_cand, off_ckeys, off_ccount, off_smax;
-    int ms;  // stripe-maxima slots per query
+    size_t off_qb, off_margin, off_pcount, off_ovf, off_gthr, off_cand, off_ckeys, off_ccount, off_smax;
+    int ms, sps;  // stripe-maxima slots per query / per slab
 };
 
 Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
@@ -753,14 +753,14 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
     const size_t nq1 = (size_t)(nq > 0 ? nq : 1);
     g.off_qb = o;     o += (size_t)round_up((int64_t)g.nqpad * g.dp * 2, 256);
     g.off_margin = o; o += (size_t)g.nqpad * 4;
-    g.off_pcount = o; o += (size_t)g.nqt * g.S * TQ * 4;
+    g.off_pcount = o; o += (size_t)g.nqt * g.S * TQ * NSL * 4;
     g.off_ovf = o;    o += (size_t)round_up((int64_t)g.nqt * 4, 256);
     g.off_gthr = o;   o += (size_t)g.nqpad * 4;
-    g.off_squant = o; o += (size_t)2 * g.nqt * g.S * TQ * 4;
     g.off_cand = o;   o += nq1 * RMAX * 4;
     g.off_ckeys = o;  o += nq1 * RMAX * 8;
     g.off_ccount = o; o += (size_t)round_up((int64_t)nq1 * 4, 256);
-    g.ms = g.S * 16 < SMAX_SLOTS ? g.S * 16 : SMAX_SLOTS;
+    g.sps = g.S <= SMAX_SLOTS / 16 ? 16 : (SMAX_SLOTS / g.S > 0 ? SMAX_SLOTS / g.S : 1);
+    g.ms = g.S * g.sps < SMAX_SLOTS ? g.S * g.sps : SMAX_SLOTS;
     g.off_smax = o;   o += (size_t)g.nqpad * g.ms * 4;
     g.total = round_up((int64_t)o, 256);
     return g;
@@ -985,8 +985,8 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     // 1. bf16 screening scan
     {
         ScreenArgs a;
-        a.Xb = bf16_dev; a.Qb = Qb; a.margin = margin; a.pools = pools; a.pcount = pcount; a.ovf = ovf; a.gthr = (unsigned*)(ws + g.off_gthr); a.squant = (unsigned*)(ws + g.off_squant);
-        a.smax = (unsigned*)(ws + g.off_smax); a.ms = g.ms;
+        a.Xb = bf16_dev; a.Qb = Qb; a.margin = margin; a.pools = pools; a.pcount = pcount; a.ovf = ovf; a.gthr = (unsigned*)(ws + g.off_gthr);
+        a.smax = (unsigned*)(ws + g.off_smax); a.ms = g.ms; a.sps = g.sps;
         a.dbg = getenv("MQ_DBG_PTR") ? (unsigned long long*)strtoull(getenv("MQ_DBG_PTR"), nullptr, 0) : nullptr;
         a.N = N; a.dp = g.dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx; a.nchunks = g.nchunks;
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
@@ -997,7 +997,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     }
     // 2.-4. candidates -> exact scores -> exact top-k
     hipLaunchKernelGGL(cand_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin,
-                       (const unsigned*)(ws + g.off_gthr), (const unsigned*)(ws + g.off_squant), g.nqt, ovf, nq, g.S, k, cand, ccount);
+                       (const unsigned*)(ws + g.off_gthr), (const unsigned*)(ws + g.off_smax), g.ms, ovf, nq, g.S, k, cand, ccount);
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq, RMAX / 64), dim3(256), 0, st, rowmajor_dev, q_rm, d, cand, ccount, ckeys);
     MQ_HIP(hipGetLastError());
@@ -1026,7 +1026,7 @@ int mq_knn_screen_stats(int64_t N, int d, int nq, int k, const void* ws_dev, int
     if (!ws_dev || !out || nq <= 0) return MQ_EINVAL;
     const Geometry g = geometry(N, d, nq, k, num_cus());
     MQ_HIP(hipStreamSynchronize((hipStream_t)stream));
-    const size_t npc = (size_t)g.nqt * g.S * TQ;
+    const size_t npc = (size_t)g.nqt * g.S * TQ * NSL;
     int* ovf = (int*)malloc((size_t)g.nqt * 4);
     int* cc = (int*)malloc((size_t)nq * 4);
     int* pc = (int*)malloc(npc * 4);
@@ -1039,7 +1039,12 @@ int mq_knn_screen_stats(int64_t N, int d, int nq, int k, const void* ws_dev, int
     for (int i = 0; i < 8; ++i) out[i] = 0;
     for (int i = 0; i < g.nqt; ++i) out[0] += ovf[i] != 0;
     for (int i = 0; i < nq; ++i) { out[1] += cc[i]; if (cc[i] > out[2]) out[2] = cc[i]; }
-    for (size_t i = 0; i < npc; ++i) { out[4] += pc[i]; if (pc[i] > out[3]) out[3] = pc[i]; }
+    for (size_t i = 0; i < npc; i += NSL) {  // one pool = NSL slices
+        int64_t n = 0;
+        for (int z = 0; z < NSL; ++z) n += pc[i + z];
+        out[4] += n;
+        if (n > out[3]) out[3] = n;
+    }
     float mm = 0.f;
     for (int i = 0; i < nq; ++i) if (mg[i] > mm || mg[i] != mg[i]) mm = mg[i];
     out[5] = (int64_t)(mm * 1e6f);  /* max margin in 1e-6 units */
