@@ -95,3 +95,46 @@ def test_nan_inf_rows_with_screen():
     Da, Ia = a.search_batch(Q, 20)
     Do, Io = ok.knn(X, Q, 20)
     assert np.array_equal(Ia, Io) and np.array_equal(Da, Do, equal_nan=True)
+
+
+@pytest.mark.parametrize("kind", ["gauss", "midpoints", "wide_range"])
+def test_margin_dominates_the_measured_screening_error(kind):
+    """The lossless argument needs |S~ - S| <= margin / 2 for every (query, row).  S~ is recomputed here as the exact
+    (float64) product of the bf16-rounded operands and S as the exact float64 product; the kernel's largest margin
+    (screen_stats) must dominate twice the largest deviation, and must itself equal the documented formula
+    2 (||q|| max||x - x~|| + ||q - q~|| max||x~|| + dp 2.98e-7 ||q|| max||x||) up to its slack factors."""
+    import torch
+    from viquae_amd.index import MI355XFlatIndex
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n, d, nq, k = 6000, 200, 300, 10
+    if kind == "gauss":
+        X = torch.randn((n, d), generator=g, device="cuda")
+        Q = torch.randn((nq, d), generator=g, device="cuda")
+    elif kind == "midpoints":
+        # every element sits exactly half way between two bf16 values: the worst case of the rounding
+        m = torch.randint(128, 256, (n, d), generator=g, device="cuda").float()
+        X = (m + 0.5) / 128.0 * torch.where(torch.rand((n, d), generator=g, device="cuda") < 0.5, -1.0, 1.0)
+        mq = torch.randint(128, 256, (nq, d), generator=g, device="cuda").float()
+        Q = (mq + 0.5) / 128.0
+    else:
+        X = torch.randn((n, d), generator=g, device="cuda") * torch.exp(4 * torch.randn((n, 1), generator=g, device="cuda"))
+        Q = torch.randn((nq, d), generator=g, device="cuda") * torch.exp(4 * torch.randn((nq, 1), generator=g, device="cuda"))
+    idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
+    idx.add(X)
+    D, I = idx.search_device(Q, k)
+    ex = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=False)
+    ex.add(X)
+    D2, I2 = ex.search_device(Q, k)
+    assert torch.equal(D, D2) and torch.equal(I, I2)
+    stats = idx.screen_stats(nq, k)
+    Xb, Qb = X.to(torch.bfloat16).double(), Q.to(torch.bfloat16).double()
+    dev = ((Q.double() @ X.double().T) - (Qb @ Xb.T)).abs().amax(dim=1)          # per query, over all rows
+    qn, dqn = Q.double().norm(dim=1), (Q.double() - Qb).norm(dim=1)
+    xn, dxn = X.double().norm(dim=1).max(), (X.double() - Xb).norm(dim=1).max()
+    dp = (d + 63) // 64 * 64
+    eps = qn * dxn + dqn * Xb.norm(dim=1).max() + dp * 2.98e-7 * qn * xn
+    assert torch.all(dev <= eps), float((dev / eps).max())
+    kernel_max_margin = stats[5] * 1e-6
+    assert kernel_max_margin >= 2 * float(dev.max()) * 0.999
+    assert 2 * float(eps.max()) * 0.99 <= kernel_max_margin * (1 + 1e-3) + 1e-6
+    assert kernel_max_margin <= 2 * float(eps.max()) * 1.02 + 2e-6   # slack factors stay within 2 %

@@ -915,9 +915,10 @@ size_t mq_knn_screen_bytes(int64_t n_rows, int d) {
 }
 
 int mq_knn_screen_prepare(const float* packed_dev, int64_t capacity_rows, int d, int64_t row_offset, int64_t n,
-                          float* rowmajor_dev, uint16_t* bf16_dev, void* stream) {
+                          float* rowmajor_dev, uint16_t* bf16_dev, float* xstats_dev, void* stream) {
     if (n == 0) return MQ_OK;
-    if (!packed_dev || !rowmajor_dev || !bf16_dev || n < 0 || d <= 0 || row_offset < 0 || row_offset + n > capacity_rows)
+    if (!packed_dev || !rowmajor_dev || !bf16_dev || !xstats_dev || n < 0 || d <= 0 || row_offset < 0 ||
+        row_offset + n > capacity_rows)
         return MQ_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int dpad = mq_padded_dim(d), dp = (int)round_up(d, SBK);
@@ -929,15 +930,18 @@ int mq_knn_screen_prepare(const float* packed_dev, int64_t capacity_rows, int d,
     hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, rm, n, d, dp,
                        (unsigned short*)bf16_dev + (size_t)row_offset * dp);
     MQ_HIP(hipGetLastError());
+    hipLaunchKernelGGL(row_err_stats_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, rm,
+                       (const unsigned short*)bf16_dev + (size_t)row_offset * dp, n, d, dp, (unsigned*)xstats_dev);
+    MQ_HIP(hipGetLastError());
     return MQ_OK;
 }
 
 int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev, const float* rowmajor_dev,
-                               const uint16_t* bf16_dev, const float* xmax2_dev, int64_t N, int d, const float* queries_dev,
+                               const uint16_t* bf16_dev, const float* xstats_dev, int64_t N, int d, const float* queries_dev,
                                int nq, int k, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev, void* ws_dev,
                                size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
     if (nq == 0) return MQ_OK;
-    if (!packed_dev || !sqnorm_dev || !rowmajor_dev || !bf16_dev || !xmax2_dev || !queries_dev || !D_dev || !I_dev || !ws_dev)
+    if (!packed_dev || !sqnorm_dev || !rowmajor_dev || !bf16_dev || !xstats_dev || !queries_dev || !D_dev || !I_dev || !ws_dev)
         return MQ_EINVAL;
     if (N <= 0 || d <= 0 || nq < 0 || k <= 0) return MQ_EINVAL;
     if (k > MQ_KNN_MAX_K) return MQ_EUNSUPPORTED;
@@ -978,8 +982,8 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         const int64_t quads = (int64_t)nq * (g.dp / 4);
         hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, q_rm, (int64_t)nq, d, g.dp, Qb);
         MQ_HIP(hipGetLastError());
-        hipLaunchKernelGGL(screen_margin_kernel, dim3((unsigned)((g.nqpad + 255) / 256)), dim3(256), 0, st, qn, xmax2_dev, nq,
-                           (int)g.nqpad, g.dp, margin);
+        hipLaunchKernelGGL(screen_margin_kernel, dim3((unsigned)((g.nqpad + 63) / 64)), dim3(64), 0, st, q_rm, Qb, xstats_dev, nq,
+                           (int)g.nqpad, d, g.dp, margin);
         MQ_HIP(hipGetLastError());
     }
     // 1. bf16 screening scan

@@ -117,7 +117,7 @@ class MI355XFlatIndex(BaseIndex):
         self.screen = bool(screen) and self.metric_type == METRIC_INNER_PRODUCT
         self._rowmajor = None  # torch.float32 [capacity, d] (screened path only)
         self._bf16 = None      # torch.uint8 bf16 copy
-        self._xmax2 = None     # torch.float32 [1]: max ||x||^2
+        self._xmax2 = None     # torch.float32 [2]: max ||x||^2, max ||x - bf16(x)||^2 (kept by mq_knn_screen_prepare)
 
     # ------------------------------------------------------------------ construction
     def _ensure_capacity(self, n_total, d):
@@ -184,10 +184,12 @@ class MI355XFlatIndex(BaseIndex):
                                                 self._packed.data_ptr(), self._capacity, self._sqnorm.data_ptr(),
                                                 stream), "mq_pack_rows_f32")
                 if self.screen:
+                    if self._xmax2 is None:
+                        self._xmax2 = torch.zeros(2, dtype=torch.float32, device=self._torch_device)
                     _lib.check(lib.mq_knn_screen_prepare(self._packed.data_ptr(), self._capacity, self.d, self.ntotal,
-                                                         dev.shape[0], self._rowmajor.data_ptr(), self._bf16.data_ptr(), stream),
+                                                         dev.shape[0], self._rowmajor.data_ptr(), self._bf16.data_ptr(),
+                                                         self._xmax2.data_ptr(), stream),
                                "mq_knn_screen_prepare")
-                    self._xmax2 = None
                 self.ntotal += dev.shape[0]
                 # `dev` must outlive the kernel: synchronise before it is released
                 torch.cuda.current_stream(self._torch_device).synchronize()
@@ -256,8 +258,6 @@ class MI355XFlatIndex(BaseIndex):
                 ws = self._workspace(nb)
                 Dq, Iq = D[s:s + _QUERY_CHUNK], I[s:s + _QUERY_CHUNK]
                 if self.screen:
-                    if self._xmax2 is None:
-                        self._xmax2 = torch.nan_to_num(self._sqnorm[: self.ntotal], nan=0.0, posinf=0.0).max().reshape(1).contiguous()
                     _lib.check(lib.mq_knn_search_screened_f32(
                         self._packed.data_ptr(), self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(),
                         self._xmax2.data_ptr(), self.ntotal, self.d, q.data_ptr(), q.shape[0], k, int(self.do_l2norm),
