@@ -233,7 +233,7 @@ def main():
         value = units / elapsed
         flops = 2.0 * nq * rows * DIM  # algorithmic FLOPs of one scan launch (2.304 GFLOP/query)
         achieved = flops / (scan_ms * 1e-3) / 1e12
-        info = (ctypes_i64 * 6)()
+        info = (ctypes_i64 * 8)()
         lib.mq_knn_launch_info(rows, DIM, nq, k, info)
         workload = f"{rows}x{DIM} fp32 KB per GPU, {nq} queries, exact IP top-{k}"
         if mode == "screened":
@@ -266,7 +266,8 @@ def main():
                 "sharding": "single GPU" if world == 1 else f"row-sharded x{world}, RCCL all-gather of per-shard top-{k} + merge",
                 "unit_definition": "one query's exact top-100 over one 1.5M x 768 shard",
                 "global_queries_per_s": round(nq * args.steps / elapsed, 1),
-                "scan_launch": {"workgroups": int(info[0]), "threads": int(info[1]), "lds_bytes": int(info[2]),
+                "scan_launch": {"workgroups": int(info[0]), "threads": int(info[6] if mode == "screened" else info[1]),
+                                "lds_bytes": int(info[7] if mode == "screened" else info[2]),
                                 "query_tiles": int(info[3]), "kb_slabs": int(info[4]), "kb_chunks": int(info[5])},
             },
             "roofline": {

@@ -115,9 +115,9 @@ int mq_knn_search_screened_f32(const float *packed_dev, const float *sqnorm_dev,
 int mq_knn_screen_stats(int64_t N, int d, int nq, int k, const void *ws_dev, int64_t out[8], void *stream);
 
 /* Name and launch geometry of the scan kernel for the given problem (for bench.py / profiles):
- * out[0]=workgroups, out[1]=threads per workgroup, out[2]=LDS bytes, out[3]=query tiles,
- * out[4]=KB slabs, out[5]=KB chunks (256 rows each). */
-int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[6]);
+ * out[0]=workgroups, out[1]=threads per workgroup, out[2]=LDS bytes (exact scan), out[3]=query tiles,
+ * out[4]=KB slabs, out[5]=KB chunks (256 rows each), out[6]/out[7]=threads / LDS bytes of the screening scan. */
+int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[8]);
 
 /* Merge per-shard results after the all-gather (new step; no reference
  * counterpart): Ds/Is [nshards, nq, k] with GLOBAL ids -> the k best per query. */

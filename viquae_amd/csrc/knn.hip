@@ -830,7 +830,7 @@ size_t mq_knn_workspace_bytes(int64_t N, int d, int nq, int k) {
     return geometry(N, d, nq, k, num_cus()).total;
 }
 
-int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[6]) {
+int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[8]) {
     if (!out || N < 0 || d <= 0 || nq < 0 || k <= 0 || k > MQ_KNN_MAX_K) return MQ_EINVAL;
     const Geometry g = geometry(N, d, nq, k, num_cus());
     out[0] = (int64_t)g.nqt * g.S;
@@ -839,6 +839,8 @@ int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[6]) {
     out[3] = g.nqt;
     out[4] = g.S;
     out[5] = g.nchunks;
+    out[6] = 1024;         // screening scan: threads per workgroup
+    out[7] = S_LDS_TOTAL;  // screening scan: LDS bytes
     return MQ_OK;
 }
 
@@ -930,7 +932,7 @@ int mq_knn_screen_prepare(const float* packed_dev, int64_t capacity_rows, int d,
     hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, rm, n, d, dp,
                        (unsigned short*)bf16_dev + (size_t)row_offset * dp);
     MQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(row_err_stats_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, rm,
+    hipLaunchKernelGGL(row_err_stats_kernel, dim3((unsigned)((n + 3) / 4 < 2048 ? (n + 3) / 4 : 2048)), dim3(256), 0, st, rm,
                        (const unsigned short*)bf16_dev + (size_t)row_offset * dp, n, d, dp, (unsigned*)xstats_dev);
     MQ_HIP(hipGetLastError());
     return MQ_OK;
@@ -982,7 +984,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         const int64_t quads = (int64_t)nq * (g.dp / 4);
         hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, q_rm, (int64_t)nq, d, g.dp, Qb);
         MQ_HIP(hipGetLastError());
-        hipLaunchKernelGGL(screen_margin_kernel, dim3((unsigned)((g.nqpad + 63) / 64)), dim3(64), 0, st, q_rm, Qb, xstats_dev, nq,
+        hipLaunchKernelGGL(screen_margin_kernel, dim3((unsigned)((g.nqpad + 3) / 4)), dim3(256), 0, st, q_rm, Qb, xstats_dev, nq,
                            (int)g.nqpad, d, g.dp, margin);
         MQ_HIP(hipGetLastError());
     }
