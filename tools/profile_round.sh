@@ -1,0 +1,22 @@
+#!/bin/bash
+# Profiles of one round on the GPU box (run through gpurun):  tools/profile_round.sh <tag>
+#   kernel trace + stats of the default bench, then one PMC pass per counter group (never combined with tracing),
+#   every rocprofv3 run bounded by `timeout`, python3 directly after `--`.
+# Outputs: gpurun_out/<tag>/{kt,fetch,write,sq,tcc}/... ; summarise with tools/summarize_profiles.py <tag>.
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-encoders"
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- $B > $O/kt.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- $B > $O/fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- $B > $O/write.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT -d $O/sq --output-format csv -- $B > $O/sq.log 2>&1
+timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/tcc --output-format csv -- $B > $O/tcc.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/enc --output-format csv -- python3 $R/tools/bench_encoders.py > $O/enc.log 2>&1
+cd $R
+timeout 900 python3 bench.py > $O/bench.json 2> $O/bench.err
+timeout 600 python3 bench.py --mode exact_f32 --no-encoders --no-other-path > $O/bench_exact.json 2>> $O/bench.err
+ls $O

@@ -1,0 +1,71 @@
+"""Condenses gpurun_out/<tag>/ (written by tools/profile_round.sh) into the tracked files under profiles/:
+  <tag>_kernel_stats.csv, <tag>_encoders_kernel_stats.csv   rocprofv3 --kernel-trace --stats summaries
+  <tag>_pmc.json                                            per kernel and counter: calls, max and mean per launch
+  knn_traffic.json                                          what bench.py reports as roofline.traffic
+  <tag>_bench_screened.json / <tag>_bench_exact_f32.json    the bench lines of that run
+usage: python tools/summarize_profiles.py <tag>"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
+
+
+def first(pattern):
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    return hits[0] if hits else None
+
+
+for sub, name in (("kt", f"{tag}_kernel_stats.csv"), ("enc", f"{tag}_encoders_kernel_stats.csv")):
+    f = first(f"{sub}/**/*kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(dst, name))
+pmc = {}
+for sub in ("fetch", "write", "sq", "tcc"):
+    f = first(f"{sub}/**/*counter_collection.csv")
+    if not f:
+        continue
+    for row in csv.DictReader(open(f)):
+        kernel = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+        if kernel.startswith("at::") or "rocclr" in kernel or "elementwise" in kernel:
+            continue
+        c = pmc.setdefault(kernel, {}).setdefault(row["Counter_Name"], {})
+        c.setdefault("by_dispatch", {}).setdefault(row["Dispatch_Id"], 0.0)
+        c["by_dispatch"][row["Dispatch_Id"]] += float(row["Counter_Value"])
+for kernel, counters in pmc.items():
+    for name, c in counters.items():
+        vals = list(c.pop("by_dispatch").values())
+        c.update(calls=len(vals), max_per_launch=max(vals), mean=sum(vals) / len(vals))
+json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
+
+
+def traffic(kernel):
+    c = pmc.get(kernel, {})
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        return None
+    fetch_kb, write_kb = c["FETCH_SIZE"]["max_per_launch"], c["WRITE_SIZE"]["max_per_launch"]
+    # MI355X_MICROARCH.md (HBM section): FETCH_SIZE is in KB and reports half of a 16 B/lane coalesced stream on gfx950
+    return {"kernel": kernel, "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024), "fetch_kb_raw": fetch_kb,
+            "write_kb_raw": write_kb}
+
+
+out = {"_note": "L2<->fabric bytes per full-size launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH "
+                "doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams; Infinity-Cache hits are included, so this is "
+                f"an upper bound of HBM bytes.  Raw counters: profiles/{tag}_pmc.json."}
+for key, kernel in (("screened_1500000x768_nq4096_k100", "screen_scan_kernel"), ("exact_f32_1500000x768_nq4096_k100", "knn_scan_kernel<0>")):
+    t = traffic(kernel)
+    if t:
+        out[key] = t
+if len(out) > 1:
+    json.dump(out, open(os.path.join(dst, "knn_traffic.json"), "w"), indent=1)
+for a, b in (("bench.json", f"{tag}_bench_screened.json"), ("bench_exact.json", f"{tag}_bench_exact_f32.json")):
+    f = os.path.join(src, a)
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, b))
+print(json.dumps({k: {n: round(c["max_per_launch"], 1) for n, c in v.items()} for k, v in pmc.items()
+                  if k in ("screen_scan_kernel", "knn_scan_kernel<0>", "rescore_kernel", "cand_select_kernel")}, indent=1))
