@@ -311,6 +311,7 @@ def main():
                 import bench_encoders
                 d = bench_encoders.dpr_throughput(B=2048, L=100, steps=2)
                 c = bench_encoders.clip_throughput(B=3072, steps=2)
+                tt = bench_encoders.clip_text_throughput(B=2048, L=77, steps=2)
                 rec["secondary"] = {
                     "kb_passages_encoded_per_s": round(d["passages_per_s"], 1),
                     "gemm_arithmetic": os.environ.get("MQ_ENC_GEMM", "split_bf16") + " (split_bf16 = 3 bf16 MFMA products per fp32 product, fp32-class accuracy; parity <= 1e-3 vs HF goldens)",
@@ -321,6 +322,9 @@ def main():
                     "clip": {"workload": "CLIP ViT-B/32, 3072 x 224x224 synthetic images per batch", "ms_per_batch": round(c["ms_per_batch"], 2),
                              "algorithmic_tflops": round(c["tflops"], 2), "x_f32_mfma_peak": round(c["tflops"] / PEAK_F32_MFMA_TFLOPS, 3),
                              "executed_bf16_mfma_frac": round(3 * c["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)},
+                    "titles_encoded_per_s": round(tt["titles_per_s"], 1),
+                    "clip_text": {"workload": "CLIP ViT-B/32 text tower, 2048 x 77 synthetic tokens per batch (causal)",
+                                  "ms_per_batch": round(tt["ms_per_batch"], 2), "algorithmic_tflops": round(tt["tflops"], 2)},
                 }
             except Exception as e:
                 rec["secondary"] = {"error": repr(e)}
