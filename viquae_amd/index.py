@@ -41,6 +41,7 @@ MAX_K = 128
 _MAGIC = b"MQFLAT01"
 _UPLOAD_ROWS = 1 << 16  # rows per host->device staging copy (multiple of 64)
 _QUERY_CHUNK = 1 << 14
+_SCREEN_QUERY_CHUNK = 1 << 12
 
 
 def parse_string_factory(string_factory):
@@ -252,11 +253,13 @@ class MI355XFlatIndex(BaseIndex):
         I = torch.empty((nq, k), dtype=torch.int64, device=self._torch_device)
         stream = torch.cuda.current_stream(self._torch_device).cuda_stream
         with torch.cuda.device(self._torch_device):
-            for s in range(0, nq, _QUERY_CHUNK):
-                q = queries[s:s + _QUERY_CHUNK]
+            # screened path: 16 query tiles x 16 KB slabs per call keep 256 stripe maxima per query (tightest thresholds)
+            chunk = _SCREEN_QUERY_CHUNK if self.screen else _QUERY_CHUNK
+            for s in range(0, nq, chunk):
+                q = queries[s:s + chunk]
                 nb = int(lib.mq_knn_workspace_bytes(self.ntotal, self.d, q.shape[0], k))
                 ws = self._workspace(nb)
-                Dq, Iq = D[s:s + _QUERY_CHUNK], I[s:s + _QUERY_CHUNK]
+                Dq, Iq = D[s:s + chunk], I[s:s + chunk]
                 if self.screen:
                     _lib.check(lib.mq_knn_search_screened_f32(
                         self._packed.data_ptr(), self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(),
@@ -294,9 +297,12 @@ class MI355XFlatIndex(BaseIndex):
 
     # ------------------------------------------------------------------ persistence
     def screen_stats(self, nq, k):
-        """(query tiles recomputed exactly, candidates re-scored, max per query) of the last screened search."""
+        """(query tiles recomputed exactly, candidates re-scored, max per query, ...) of the LAST C-ABI call of the last
+        screened search (a search of more than 4096 queries is several calls)."""
         import ctypes
         lib = _lib.load()
+        if nq > _SCREEN_QUERY_CHUNK:
+            nq = nq % _SCREEN_QUERY_CHUNK or _SCREEN_QUERY_CHUNK
         out = (ctypes.c_int64 * 8)()
         _lib.check(lib.mq_knn_screen_stats(self.ntotal, self.d, nq, k, self._ws.data_ptr(), out,
                                            __import__("torch").cuda.current_stream(self._torch_device).cuda_stream))
