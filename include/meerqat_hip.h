@@ -187,6 +187,26 @@ int mq_clip_text_embed_f32(const int64_t *input_ids_dev, const float *token_emb_
 int mq_clip_eos_pool_ln_f32(const float *hidden_dev, const int64_t *input_ids_dev, int64_t eos_token_id, const float *gamma_dev,
                             const float *beta_dev, float *out_dev, int B, int L, int H, float eps, void *stream);
 
+/* Split activations: a tensor that only feeds GEMMs is kept as its (hi, lo) bf16 pair (hi = bf16(x), lo = bf16(x - hi),
+ * two uint16 arrays of the tensor's shape), written by the kernel that produces it, so that the consuming GEMM streams
+ * bf16 operands and converts nothing in its MFMA loop.  Results are bit-identical to the fp32-activation entry points.
+ *   mq_gemm_nt_bf16x3s_f32     mq_gemm_nt_bf16x3_f32 with A given as (Ah, Al); output EITHER fp32 C OR the pair (Ch, Cl)
+ *   mq_layernorm_split_f32     mq_layernorm_f32 writing Y (fp32, may be NULL) and/or the pair (Yh, Yl)
+ *   mq_bert_embed_ln_split_f32 mq_bert_embed_ln_f32 writing fp32 and, optionally, the pair
+ *   mq_attention_split_f32     mq_attention_causal_f32 writing fp32 (may be NULL) and/or the pair
+ * Pair outputs need an even feature count. */
+int mq_gemm_nt_bf16x3s_f32(const uint16_t *Ah_dev, const uint16_t *Al_dev, const uint16_t *Wh_dev, const uint16_t *Wl_dev,
+                           const float *bias_dev, const float *residual_dev, float *C_dev, uint16_t *Ch_dev, uint16_t *Cl_dev,
+                           int M, int N, int K, int epilogue, void *stream);
+int mq_layernorm_split_f32(const float *X_dev, const float *gamma_dev, const float *beta_dev, float *Y_dev, uint16_t *Yh_dev,
+                           uint16_t *Yl_dev, int M, int C, float eps, void *stream);
+int mq_bert_embed_ln_split_f32(const int64_t *input_ids_dev, const int64_t *token_type_ids_dev, const float *word_dev,
+                               const float *pos_dev, const float *type_dev, const float *gamma_dev, const float *beta_dev,
+                               float *out_dev, uint16_t *out_h_dev, uint16_t *out_l_dev, int B, int L, int H, float eps,
+                               void *stream);
+int mq_attention_split_f32(const float *qkv_dev, const int64_t *attention_mask_dev, float *out_dev, uint16_t *out_h_dev,
+                           uint16_t *out_l_dev, int B, int L, int heads, int head_dim, float scale, int causal, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Late fusion of several runs on the device: replaces, for integer document
  * ids, `default_minimum` (meerqat/ir/fuse.py:129-146), `gzmuv_norm` (:86-126) and ranx's

@@ -274,3 +274,79 @@ def test_clip_text_through_embed_mirror_like_reference_config():
                    key="wikipedia_title",
                    save_as="title_clip", call="get_text_features")
     assert np.abs(np.asarray(out["title_clip"]) - z["text_features"]).max() < TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# split activations: producers write (hi, lo) bf16 pairs, the GEMM consumes them -- bit-identical to the fp32 path
+# ---------------------------------------------------------------------------------------------------
+def _pair_of(x):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi.view(torch.int16), lo.view(torch.int16)
+
+
+@pytest.mark.parametrize("M,C", [(5, 128), (300, 768), (33, 512), (4, 1022)])
+def test_layernorm_split_outputs_are_the_split_of_the_fp32_output(M, C):
+    from viquae_amd import encoders as E
+    g = torch.Generator(device="cuda").manual_seed(M + C)
+    x = torch.randn((M, C), generator=g, device="cuda") * 3 + 1
+    gam, bet = torch.randn(C, generator=g, device="cuda"), torch.randn(C, generator=g, device="cuda")
+    y = E.layernorm(x, gam, bet, 1e-5)
+    y2, sp = E.layernorm_split(x, gam, bet, 1e-5)
+    assert torch.equal(y, y2)
+    hi, lo = _pair_of(y)
+    assert torch.equal(sp.hi, hi) and torch.equal(sp.lo, lo)
+    none, sp2 = E.layernorm_split(x, gam, bet, 1e-5, want_f32=False)
+    assert none is None and torch.equal(sp2.hi, hi) and torch.equal(sp2.lo, lo)
+    assert (sp.float() - y).abs().max().item() <= 2.0 ** -16 * y.abs().max().item()
+
+
+@pytest.mark.parametrize("B,L,heads,causal", [(3, 19, 2, False), (2, 100, 12, False), (2, 77, 8, True), (1, 130, 1, False)])
+def test_attention_split_output_is_the_split_of_the_fp32_output(B, L, heads, causal):
+    from viquae_amd import encoders as E
+    g = torch.Generator(device="cuda").manual_seed(B + L + heads)
+    qkv = torch.randn((B * L, 3 * heads * 64), generator=g, device="cuda")
+    lens = torch.randint(1, L + 1, (B,), generator=g, device="cuda")
+    mask = (torch.arange(L, device="cuda")[None] < lens[:, None]).to(torch.int64)
+    out = E.attention(qkv, mask, B, L, heads, 0.125, causal=causal)
+    sp = E.attention(qkv, mask, B, L, heads, 0.125, causal=causal, split=True)
+    hi, lo = _pair_of(out)
+    assert torch.equal(sp.hi, hi) and torch.equal(sp.lo, lo)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (800, 768, 768), (37, 100, 96), (300, 2304, 768), (513, 128, 3072)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_split_activation_gemm_is_bit_identical_to_the_in_loop_split(M, N, K, epi):
+    from viquae_amd import encoders as E
+    g = torch.Generator(device="cuda").manual_seed(11 * M + N + K + epi)
+    a = torch.randn((M, K), generator=g, device="cuda")
+    w = torch.randn((N, K), generator=g, device="cuda") * 0.05
+    b = torch.randn((N,), generator=g, device="cuda")
+    r = torch.randn((M, N), generator=g, device="cuda")
+    ws = E.split_bf16(w)
+    ref = E.gemm_nt(a, w, b if epi else None, r if epi == 4 else None, epi, wsplit=ws)
+    sa = E.SplitAct(*_pair_of(a))
+    out = E.gemm_nt(sa, w, b if epi else None, r if epi == 4 else None, epi, wsplit=ws)
+    assert torch.equal(out, ref)
+    sp = E.gemm_nt(sa, w, b if epi else None, r if epi == 4 else None, epi, wsplit=ws, out_split=True)
+    hi, lo = _pair_of(ref)
+    assert torch.equal(sp.hi, hi) and torch.equal(sp.lo, lo)
+
+
+def test_split_and_fp32_activation_paths_agree_end_to_end(monkeypatch):
+    """The whole DPR / CLIP forward in split-activation mode equals the forward with MQ_ENC_GEMM=f32-activation
+    GEMMs bit for bit?  No -- f32 mode uses the fp32 MFMA kernel.  What must hold: split mode == the same model run
+    with split activations disabled (in-loop split), bit for bit."""
+    from oracle import encoders as oe
+    from viquae_amd import encoders as E
+    cfg = oe.BERT_TINY
+    state = oe.seeded_state(oe.bert_param_shapes(cfg), 3)
+    model = E.DPRContextEncoder.from_state_dict(cfg, state).to("cuda").eval()
+    ids = torch.randint(1, 1000, (5, 41), device="cuda")
+    mask = (torch.arange(41, device="cuda")[None] < torch.tensor([41, 3, 17, 41, 30], device="cuda")[:, None]).long()
+    a = model(input_ids=ids, attention_mask=mask, output_hidden_states=True)
+    monkeypatch.setattr(E, "_use_split", lambda *k: False)
+    b = model(input_ids=ids, attention_mask=mask, output_hidden_states=True)
+    assert torch.equal(a["pooler_output"], b["pooler_output"])
+    for x, y in zip(a["hidden_states"], b["hidden_states"]):
+        assert torch.equal(x, y)

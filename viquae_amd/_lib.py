@@ -50,6 +50,13 @@ SIGNATURES = {
     "mq_attention_causal_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, ctypes.c_float, c_int, c_ptr]),
     "mq_clip_text_embed_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
     "mq_clip_eos_pool_ln_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, ctypes.c_float, c_ptr]),
+    "mq_gemm_nt_bf16x3s_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int,
+                                       c_ptr]),
+    "mq_layernorm_split_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, ctypes.c_float, c_ptr]),
+    "mq_bert_embed_ln_split_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int,
+                                           c_int, ctypes.c_float, c_ptr]),
+    "mq_attention_split_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, ctypes.c_float, c_int,
+                                       c_ptr]),
     "mq_topk_merge_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "mq_fuse_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "mq_fuse_wsum_f64": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_sz,

@@ -7,7 +7,7 @@
 //                         v_mfma_f32_32x32x2_f32, 256x256x16 tiles, LDS-DMA double buffer
 //   layernorm_kernel      row LayerNorm (one wave per row)
 //   bert_embed_ln_kernel  word + token-type + position gather, LayerNorm
-//   attention_kernel      softmax(q k^T * scale + mask) v per (sequence, head), keys/values in LDS
+//   attention_mfma_kernel softmax(q k^T * scale + padding/causal mask) v per (sequence, head, 128 queries) on fp32 MFMA
 //   clip_patchify_kernel  NCHW pixels -> [B*patches, C*P*P] rows (the conv-as-GEMM operand)
 //   clip_assemble_ln_kernel  [CLS | patch embeddings] + position embeddings, pre-LayerNorm
 //
@@ -197,6 +197,12 @@ constexpr int X_STAGE = X_A_BYTES + 2 * X_W_BYTES;
 constexpr int X_LDS_BYTES = 2 * X_STAGE;  // 128 KiB
 
 __device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8_t& hi, bf16x8_t& lo) {
+#ifdef MQ_ABL_NOSPLIT  // timing ablation only (wrong results): what the in-loop conversions cost
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    hi = __builtin_bit_cast(bf16x8_t, (u32x4){__float_as_uint(u.x), __float_as_uint(u.y), __float_as_uint(u.z), __float_as_uint(u.w)});
+    lo = __builtin_bit_cast(bf16x8_t, (u32x4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)});
+    return;
+#endif
     const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -215,6 +221,159 @@ __global__ void split_bf16_kernel(const float* __restrict__ src, long long n, un
     const __bf16 l = (__bf16)(x - (float)h);
     hi[e] = __builtin_bit_cast(unsigned short, h);
     lo[e] = __builtin_bit_cast(unsigned short, l);
+}
+
+// Split activations.  An activation tensor that only feeds GEMMs is kept as its (hi, lo) bf16 pair, written by the
+// kernel that PRODUCES it (LayerNorm, attention, the GELU epilogue): the consuming GEMM then streams bf16 operands
+// only and carries no conversions in its MFMA loop (measured: the in-loop split cost 18-22 % of encoder time).
+// hi = bf16(x), lo = bf16(x - hi): exactly what split8() computes, so both GEMM variants give identical results.
+// store_split_pair: lanes l and l^1 of a wave hold ADJACENT columns (even column in the even lane); after one DPP
+// exchange the even lane stores the packed hi pair, the odd lane the packed lo pair -- one 4-byte store per lane.
+__device__ __forceinline__ unsigned split_bits(float x) {
+    const __bf16 h = (__bf16)x;
+    const __bf16 l = (__bf16)(x - (float)h);
+    return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+__device__ __forceinline__ void store_split_pair(float x, bool valid, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                                 size_t even_col_index, int lane) {
+    const unsigned mine = split_bits(x);
+    const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, false);  // lane ^ 1
+    const bool odd = lane & 1;
+    const unsigned ev = odd ? other : mine, od = odd ? mine : other;  // the pair's even / odd column
+    const unsigned word = odd ? ((ev >> 16) | (od & 0xFFFF0000u)) : ((ev & 0xFFFFu) | (od << 16));
+    if (valid) *reinterpret_cast<unsigned*>((odd ? lo : hi) + even_col_index) = word;
+}
+
+constexpr int XS_STAGE = 4 * X_W_BYTES;      // Ah, Al, Wh, Wl: [256][32] bf16 each
+constexpr int XS_LDS_BYTES = 2 * XS_STAGE;   // 128 KiB
+
+// gemm_nt_x3s_kernel: gemm_nt_x3_kernel with A given as its (hi, lo) pair; SPLIT_OUT writes C as a pair as well.
+template <int EPI, bool SPLIT_OUT>
+__global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short* __restrict__ Ah, const unsigned short* __restrict__ Al,
+                                                           const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
+                                                           const float* __restrict__ bias, const float* __restrict__ R,
+                                                           float* __restrict__ C, unsigned short* __restrict__ Ch,
+                                                           unsigned short* __restrict__ Cl, int M, int N, int K, int ntm, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    int mt, nt;
+    {
+        const int b = blockIdx.x;
+        if ((ntm & 7) == 0) {
+            const int xcd = b & 7, j = b >> 3;
+            mt = (j / ntn) * 8 + xcd;
+            nt = j % ntn;
+        } else {
+            mt = b / ntn;
+            nt = b % ntn;
+        }
+    }
+    mt = __builtin_amdgcn_readfirstlane(mt);
+    nt = __builtin_amdgcn_readfirstlane(nt);
+    const int m0 = mt * GT, n0 = nt * GT;
+
+    // DMA: wave w moves rows [16w, 16w+16) of Ah, Al, Wh, Wl: one instruction of 16 rows x 64 B each
+    unsigned a_voff, w_voff;
+    {
+        const int r = 16 * w + (lane >> 2);
+        int am = m0 + r; if (am > M - 1) am = M - 1;
+        int wn = n0 + r; if (wn > N - 1) wn = N - 1;
+        const size_t chunk = (size_t)(((lane & 3) ^ ((r >> 2) & 3)) * 8);
+        a_voff = (unsigned)(((size_t)(am - m0) * K + chunk) * 2);
+        w_voff = (unsigned)(((size_t)(wn - n0) * K + chunk) * 2);
+    }
+    const char* const ahbase = reinterpret_cast<const char*>(Ah + (size_t)m0 * K);
+    const char* const albase = reinterpret_cast<const char*>(Al + (size_t)m0 * K);
+    const char* const whbase = reinterpret_cast<const char*>(Wh + (size_t)n0 * K);
+    const char* const wlbase = reinterpret_cast<const char*>(Wl + (size_t)n0 * K);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem + 16 * w * 64));
+    auto issue = [&](int kb, int stg) __attribute__((always_inline)) {
+        const unsigned so = lds0 + stg * XS_STAGE;
+        const size_t ko = (size_t)kb * (XBK * 2);
+        dma16s(ahbase + ko, a_voff, so);
+        dma16s(albase + ko, a_voff, so + X_W_BYTES);
+        dma16s(whbase + ko, w_voff, so + 2 * X_W_BYTES);
+        dma16s(wlbase + ko, w_voff, so + 3 * X_W_BYTES);
+    };
+
+    const int i = lane & 31, kg = lane >> 5;
+    const int sww = (i >> 2) & 3;
+    const char* ard = smem + (64 * wr + i) * 64;                    // Ah rows of this wave; Al at + X_W_BYTES
+    const char* wrd = smem + 2 * X_W_BYTES + (64 * wc + i) * 64;    // Wh rows of this wave; Wl at + X_W_BYTES
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    const int nk = K / XBK;
+    issue(0, 0);
+    int stage = 0;
+    for (int kb = 0; kb < nk; ++kb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kb + 1 < nk) issue(kb + 1, stage ^ 1);
+        const char* as = ard + stage * XS_STAGE;
+        const char* ws = wrd + stage * XS_STAGE;
+#pragma unroll
+        for (int m = 0; m < XBK / 16; ++m) {
+            const int o = ((2 * m + kg) ^ sww) * 16;
+            const bf16x8_t ah0 = *reinterpret_cast<const bf16x8_t*>(as + o);
+            const bf16x8_t ah1 = *reinterpret_cast<const bf16x8_t*>(as + 32 * 64 + o);
+            const bf16x8_t al0 = *reinterpret_cast<const bf16x8_t*>(as + X_W_BYTES + o);
+            const bf16x8_t al1 = *reinterpret_cast<const bf16x8_t*>(as + X_W_BYTES + 32 * 64 + o);
+            const bf16x8_t h0 = *reinterpret_cast<const bf16x8_t*>(ws + o);
+            const bf16x8_t h1 = *reinterpret_cast<const bf16x8_t*>(ws + 32 * 64 + o);
+            const bf16x8_t l0 = *reinterpret_cast<const bf16x8_t*>(ws + X_W_BYTES + o);
+            const bf16x8_t l1 = *reinterpret_cast<const bf16x8_t*>(ws + X_W_BYTES + 32 * 64 + o);
+            // same per-accumulator order as gemm_nt_x3_kernel (lo.hi, hi.lo, hi.hi): bit-identical sums
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, h0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, h1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, h0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, h1, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, l0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, l1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, l0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, l1, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, h0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, h1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, h0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, h1, acc11, 0, 0, 0);
+        }
+        stage ^= 1;
+    }
+
+    const int nb0 = n0 + 64 * wc + i, nb1 = nb0 + 32;
+    float bias0 = 0.f, bias1 = 0.f;
+    if (EPI != EPI_NONE) {
+        if (nb0 < N) bias0 = bias[nb0];
+        if (nb1 < N) bias1 = bias[nb1];
+    }
+    const int mbase = m0 + 64 * wr + 4 * kg;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int mr0 = mbase + (reg & 3) + 8 * (reg >> 2), mr1 = mr0 + 32;
+        float v00 = acc00[reg] + bias0, v01 = acc01[reg] + bias1, v10 = acc10[reg] + bias0, v11 = acc11[reg] + bias1;
+        if (EPI == EPI_BIAS_GELU) { v00 = gelu_erf(v00); v01 = gelu_erf(v01); v10 = gelu_erf(v10); v11 = gelu_erf(v11); }
+        if (EPI == EPI_BIAS_QUICKGELU) { v00 = quick_gelu(v00); v01 = quick_gelu(v01); v10 = quick_gelu(v10); v11 = quick_gelu(v11); }
+        if (EPI == EPI_BIAS_RESIDUAL) {
+            if (mr0 < M && nb0 < N) v00 += R[(size_t)mr0 * N + nb0];
+            if (mr0 < M && nb1 < N) v01 += R[(size_t)mr0 * N + nb1];
+            if (mr1 < M && nb0 < N) v10 += R[(size_t)mr1 * N + nb0];
+            if (mr1 < M && nb1 < N) v11 += R[(size_t)mr1 * N + nb1];
+        }
+        if (SPLIT_OUT) {  // N is even (checked by the host): a pair of columns is in or out together
+            store_split_pair(v00, mr0 < M && nb0 < N, Ch, Cl, (size_t)mr0 * N + (nb0 & ~1), lane);
+            store_split_pair(v01, mr0 < M && nb1 < N, Ch, Cl, (size_t)mr0 * N + (nb1 & ~1), lane);
+            store_split_pair(v10, mr1 < M && nb0 < N, Ch, Cl, (size_t)mr1 * N + (nb0 & ~1), lane);
+            store_split_pair(v11, mr1 < M && nb1 < N, Ch, Cl, (size_t)mr1 * N + (nb1 & ~1), lane);
+        } else {
+            if (mr0 < M && nb0 < N) C[(size_t)mr0 * N + nb0] = v00;
+            if (mr0 < M && nb1 < N) C[(size_t)mr0 * N + nb1] = v01;
+            if (mr1 < M && nb0 < N) C[(size_t)mr1 * N + nb0] = v10;
+            if (mr1 < M && nb1 < N) C[(size_t)mr1 * N + nb1] = v11;
+        }
+    }
 }
 
 template <int EPI>
@@ -362,8 +521,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // normalises v[] (this lane's elements c = lane + 64 t, t < nper) and stores
+// out (fp32 row, may be null) and/or oh, ol (the row's split pair, may be null; C even then)
 __device__ __forceinline__ void ln_store(float (&v)[LN_MAXPER], int C, int lane, const float* __restrict__ g,
-                                         const float* __restrict__ b, float eps, float* __restrict__ out) {
+                                         const float* __restrict__ b, float eps, float* __restrict__ out,
+                                         unsigned short* __restrict__ oh = nullptr, unsigned short* __restrict__ ol = nullptr) {
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < LN_MAXPER; ++t) { const int c = lane + 64 * t; if (c < C) s += v[t]; }
@@ -376,12 +537,15 @@ __device__ __forceinline__ void ln_store(float (&v)[LN_MAXPER], int C, int lane,
 #pragma unroll
     for (int t = 0; t < LN_MAXPER; ++t) {
         const int c = lane + 64 * t;
-        if (c < C) out[c] = (v[t] - mean) * inv * g[c] + b[c];
+        const float y = (c < C) ? (v[t] - mean) * inv * g[c] + b[c] : 0.f;
+        if (out && c < C) out[c] = y;
+        if (oh && 64 * t < C) store_split_pair(y, c < C, oh, ol, (size_t)(c & ~1), lane);  // wave-uniform guard
     }
 }
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ X, const float* __restrict__ g,
-                                                        const float* __restrict__ b, float* __restrict__ Y, int M, int C,
+                                                        const float* __restrict__ b, float* __restrict__ Y,
+                                                        unsigned short* __restrict__ Yh, unsigned short* __restrict__ Yl, int M, int C,
                                                         float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -389,14 +553,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float v[LN_MAXPER];
 #pragma unroll
     for (int t = 0; t < LN_MAXPER; ++t) { const int c = lane + 64 * t; v[t] = (c < C) ? X[(size_t)row * C + c] : 0.f; }
-    ln_store(v, C, lane, g, b, eps, Y + (size_t)row * C);
+    ln_store(v, C, lane, g, b, eps, Y ? Y + (size_t)row * C : nullptr, Yh ? Yh + (size_t)row * C : nullptr,
+             Yl ? Yl + (size_t)row * C : nullptr);
 }
 
 // BertEmbeddings (meerqat/models/bert.py:153-214): (word[id] + type[tt]) + pos[t], then LayerNorm
 __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const long long* __restrict__ ids, const long long* __restrict__ tts,
                                                             const float* __restrict__ word, const float* __restrict__ pos,
                                                             const float* __restrict__ type, const float* __restrict__ g,
-                                                            const float* __restrict__ b, float* __restrict__ out, int M,
+                                                            const float* __restrict__ b, float* __restrict__ out,
+                                                            unsigned short* __restrict__ oh, unsigned short* __restrict__ ol, int M,
                                                             int L, int H, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -410,7 +576,7 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const long long* __r
         const int c = lane + 64 * t;
         v[t] = (c < H) ? (word[(size_t)id * H + c] + type[(size_t)tt * H + c]) + pos[(size_t)t_pos * H + c] : 0.f;
     }
-    ln_store(v, H, lane, g, b, eps, out + (size_t)row * H);
+    ln_store(v, H, lane, g, b, eps, out + (size_t)row * H, oh ? oh + (size_t)row * H : nullptr, ol ? ol + (size_t)row * H : nullptr);
 }
 
 // CLIPVisionEmbeddings + pre_layrnorm: token 0 = class embedding, token 1+p = patch embedding p; + position
@@ -448,68 +614,8 @@ __global__ void clip_patchify_kernel(const float* __restrict__ px, float* __rest
     *reinterpret_cast<float4*>(out + e) = v;
 }
 
-// ------------------------------------------------------------------------------------------------
-// attention: one workgroup per (sequence, head); thread t owns query row t; K and V of the head in LDS
-// ------------------------------------------------------------------------------------------------
-constexpr int DH = 64;
+constexpr int DH = 64;  // attention head size
 
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, const long long* __restrict__ mask,
-                                                        float* __restrict__ out, int L, int heads, float scale) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Ks = reinterpret_cast<float*>(smem);   // [L][64]
-    float* Vs = Ks + (size_t)L * DH;              // [L][64]
-    int* keep = reinterpret_cast<int*>(Vs + (size_t)L * DH);  // [L]
-    const int bi = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int H = heads * DH, ld = 3 * H;
-    const float* base = qkv + (size_t)bi * L * ld + h * DH;
-    for (int e = threadIdx.x; e < L * (DH / 4); e += blockDim.x) {
-        const int j = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
-        *reinterpret_cast<float4*>(Ks + j * DH + c4) = *reinterpret_cast<const float4*>(base + (size_t)j * ld + H + c4);
-        *reinterpret_cast<float4*>(Vs + j * DH + c4) = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * H + c4);
-    }
-    for (int j = threadIdx.x; j < L; j += blockDim.x) keep[j] = mask ? (mask[(size_t)bi * L + j] != 0) : 1;
-    __syncthreads();
-    const int t = threadIdx.x;
-    if (t >= L) return;
-    float q[DH], o[DH];
-#pragma unroll
-    for (int c = 0; c < DH; c += 4) {
-        const float4 f = *reinterpret_cast<const float4*>(base + (size_t)t * ld + c);
-        q[c] = f.x; q[c + 1] = f.y; q[c + 2] = f.z; q[c + 3] = f.w;
-        o[c] = o[c + 1] = o[c + 2] = o[c + 3] = 0.f;
-    }
-    float mx = -INFINITY, den = 0.f;
-    for (int j = 0; j < L; ++j) {
-        if (!keep[j]) continue;  // additive finfo.min mask == weight exactly 0
-        const float* kr = Ks + j * DH;
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < DH; c += 4) {
-            const float4 f = *reinterpret_cast<const float4*>(kr + c);
-            s = fmaf(q[c], f.x, s); s = fmaf(q[c + 1], f.y, s); s = fmaf(q[c + 2], f.z, s); s = fmaf(q[c + 3], f.w, s);
-        }
-        s *= scale;
-        const float mn = fmaxf(mx, s);
-        const float corr = expf(mx - mn);  // 0 on the first key (mx = -inf)
-        const float p = expf(s - mn);
-        den = den * corr + p;
-        const float* vr = Vs + j * DH;
-#pragma unroll
-        for (int c = 0; c < DH; c += 4) {
-            const float4 f = *reinterpret_cast<const float4*>(vr + c);
-            o[c] = fmaf(p, f.x, o[c] * corr); o[c + 1] = fmaf(p, f.y, o[c + 1] * corr);
-            o[c + 2] = fmaf(p, f.z, o[c + 2] * corr); o[c + 3] = fmaf(p, f.w, o[c + 3] * corr);
-        }
-        mx = mn;
-    }
-    const float inv = 1.0f / den;
-    float* dst = out + ((size_t)bi * L + t) * H + h * DH;
-#pragma unroll
-    for (int c = 0; c < DH; c += 4) {
-        float4 f; f.x = o[c] * inv; f.y = o[c + 1] * inv; f.z = o[c + 2] * inv; f.w = o[c + 3] * inv;
-        *reinterpret_cast<float4*>(dst + c) = f;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // MFMA attention (fp32): one workgroup (4 waves) per (sequence, head, block of 128 queries).
@@ -520,7 +626,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 template <int NKT>  // key tiles of 32: L <= 32 * NKT
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, const long long* __restrict__ mask,
-                                                             float* __restrict__ out, int L, int heads, float scale,
+                                                             float* __restrict__ out, unsigned short* __restrict__ out_h,
+                                                             unsigned short* __restrict__ out_l, int L, int heads, float scale,
                                                              int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NK = 32 * NKT;
@@ -612,9 +719,12 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     }
     __syncthreads();
     for (int e = lane; e < 32 * 64; e += 64) {
-        const int r = e >> 6, c = e & 63;
+        const int r = e >> 6, c = e & 63;  // c = lane: lanes l, l^1 hold adjacent columns
         const int qr = blockIdx.y * 128 + 32 * w + r;
-        if (qr < L) out[((size_t)bi * L + qr) * H + h * DH + c] = Ot[r * 65 + c];
+        const size_t at = ((size_t)bi * L + qr) * H + h * DH;
+        const float val = Ot[r * 65 + c];
+        if (out && qr < L) out[at + c] = val;
+        if (out_h) store_split_pair(val, qr < L, out_h, out_l, at + (c & ~1), lane);
     }
 }
 
@@ -730,13 +840,58 @@ int mq_gemm_nt_bf16x3_f32(const float* A_dev, const uint16_t* Wh_dev, const uint
     return MQ_OK;
 }
 
+int mq_gemm_nt_bf16x3s_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const uint16_t* Wh_dev, const uint16_t* Wl_dev,
+                           const float* bias_dev, const float* residual_dev, float* C_dev, uint16_t* Ch_dev, uint16_t* Cl_dev,
+                           int M, int N, int K, int epilogue, void* stream) {
+    if (M == 0 || N == 0) return MQ_OK;
+    if (!Ah_dev || !Al_dev || !Wh_dev || !Wl_dev || M < 0 || N < 0 || K <= 0 || (K % XBK) != 0) return MQ_EINVAL;
+    if ((!C_dev) == (!Ch_dev) || (!Ch_dev != !Cl_dev)) return MQ_EINVAL;  // exactly one output form
+    if (epilogue < EPI_NONE || epilogue > EPI_BIAS_RESIDUAL) return MQ_EINVAL;
+    if (epilogue != EPI_NONE && !bias_dev) return MQ_EINVAL;
+    if (epilogue == EPI_BIAS_RESIDUAL && !residual_dev) return MQ_EINVAL;
+    if (((uintptr_t)Ah_dev | (uintptr_t)Al_dev | (uintptr_t)Wh_dev | (uintptr_t)Wl_dev) & 15) return MQ_EINVAL;
+    if (Ch_dev && (N & 1)) return MQ_EUNSUPPORTED;
+    const int ntm = (M + GT - 1) / GT, ntn = (N + GT - 1) / GT;
+    const dim3 grid((unsigned)(ntm * ntn)), block(1024);
+    hipStream_t st = (hipStream_t)stream;
+#define MQ_LAUNCH2(E, S)                                                                                              \
+    {                                                                                                                 \
+        ENC_HIP(hipFuncSetAttribute((const void*)gemm_nt_x3s_kernel<E, S>, hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS_BYTES)); \
+        hipLaunchKernelGGL((gemm_nt_x3s_kernel<E, S>), grid, block, XS_LDS_BYTES, st, (const unsigned short*)Ah_dev,    \
+                           (const unsigned short*)Al_dev, (const unsigned short*)Wh_dev, (const unsigned short*)Wl_dev, \
+                           bias_dev, residual_dev, C_dev, (unsigned short*)Ch_dev, (unsigned short*)Cl_dev, M, N, K, ntm, ntn); \
+    }
+#define MQ_LAUNCH(E)                                                                                                  \
+    case E:                                                                                                           \
+        if (Ch_dev) MQ_LAUNCH2(E, true) else MQ_LAUNCH2(E, false)                                                     \
+        break;
+    switch (epilogue) {
+        MQ_LAUNCH(EPI_NONE)
+        MQ_LAUNCH(EPI_BIAS)
+        MQ_LAUNCH(EPI_BIAS_GELU)
+        MQ_LAUNCH(EPI_BIAS_QUICKGELU)
+        MQ_LAUNCH(EPI_BIAS_RESIDUAL)
+    }
+#undef MQ_LAUNCH
+#undef MQ_LAUNCH2
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
 int mq_layernorm_f32(const float* X_dev, const float* gamma_dev, const float* beta_dev, float* Y_dev, int M, int C, float eps,
                      void* stream) {
+    if (!Y_dev) return M == 0 ? MQ_OK : MQ_EINVAL;
+    return mq_layernorm_split_f32(X_dev, gamma_dev, beta_dev, Y_dev, nullptr, nullptr, M, C, eps, stream);
+}
+
+int mq_layernorm_split_f32(const float* X_dev, const float* gamma_dev, const float* beta_dev, float* Y_dev, uint16_t* Yh_dev,
+                           uint16_t* Yl_dev, int M, int C, float eps, void* stream) {
     if (M == 0) return MQ_OK;
-    if (!X_dev || !gamma_dev || !beta_dev || !Y_dev || M < 0 || C <= 0) return MQ_EINVAL;
-    if (C > 64 * LN_MAXPER) return MQ_EUNSUPPORTED;
+    if (!X_dev || !gamma_dev || !beta_dev || M < 0 || C <= 0) return MQ_EINVAL;
+    if ((!Y_dev && !Yh_dev) || (!Yh_dev != !Yl_dev)) return MQ_EINVAL;
+    if (C > 64 * LN_MAXPER || (Yh_dev && (C & 1))) return MQ_EUNSUPPORTED;
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X_dev, gamma_dev,
-                       beta_dev, Y_dev, M, C, eps);
+                       beta_dev, Y_dev, (unsigned short*)Yh_dev, (unsigned short*)Yl_dev, M, C, eps);
     ENC_HIP(hipGetLastError());
     return MQ_OK;
 }
@@ -744,14 +899,23 @@ int mq_layernorm_f32(const float* X_dev, const float* gamma_dev, const float* be
 int mq_bert_embed_ln_f32(const int64_t* input_ids_dev, const int64_t* token_type_ids_dev, const float* word_dev,
                          const float* pos_dev, const float* type_dev, const float* gamma_dev, const float* beta_dev,
                          float* out_dev, int B, int L, int H, float eps, void* stream) {
+    return mq_bert_embed_ln_split_f32(input_ids_dev, token_type_ids_dev, word_dev, pos_dev, type_dev, gamma_dev, beta_dev, out_dev,
+                                      nullptr, nullptr, B, L, H, eps, stream);
+}
+
+int mq_bert_embed_ln_split_f32(const int64_t* input_ids_dev, const int64_t* token_type_ids_dev, const float* word_dev,
+                               const float* pos_dev, const float* type_dev, const float* gamma_dev, const float* beta_dev,
+                               float* out_dev, uint16_t* out_h_dev, uint16_t* out_l_dev, int B, int L, int H, float eps,
+                               void* stream) {
     if (B == 0 || L == 0) return MQ_OK;
     if (!input_ids_dev || !word_dev || !pos_dev || !type_dev || !gamma_dev || !beta_dev || !out_dev || B < 0 || L < 0 || H <= 0)
         return MQ_EINVAL;
-    if (H > 64 * LN_MAXPER) return MQ_EUNSUPPORTED;
+    if (!out_h_dev != !out_l_dev) return MQ_EINVAL;
+    if (H > 64 * LN_MAXPER || (out_h_dev && (H & 1))) return MQ_EUNSUPPORTED;
     const int M = B * L;
     hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const long long*)input_ids_dev, (const long long*)token_type_ids_dev, word_dev, pos_dev, type_dev,
-                       gamma_dev, beta_dev, out_dev, M, L, H, eps);
+                       gamma_dev, beta_dev, out_dev, (unsigned short*)out_h_dev, (unsigned short*)out_l_dev, M, L, H, eps);
     ENC_HIP(hipGetLastError());
     return MQ_OK;
 }
@@ -763,8 +927,14 @@ int mq_attention_f32(const float* qkv_dev, const int64_t* attention_mask_dev, fl
 
 int mq_attention_causal_f32(const float* qkv_dev, const int64_t* attention_mask_dev, float* out_dev, int B, int L, int heads,
                             int head_dim, float scale, int causal, void* stream) {
+    if (!out_dev) return (B == 0 || L == 0) ? MQ_OK : MQ_EINVAL;
+    return mq_attention_split_f32(qkv_dev, attention_mask_dev, out_dev, nullptr, nullptr, B, L, heads, head_dim, scale, causal, stream);
+}
+
+int mq_attention_split_f32(const float* qkv_dev, const int64_t* attention_mask_dev, float* out_dev, uint16_t* out_h_dev,
+                           uint16_t* out_l_dev, int B, int L, int heads, int head_dim, float scale, int causal, void* stream) {
     if (B == 0 || L == 0) return MQ_OK;
-    if (!qkv_dev || !out_dev || B < 0 || L < 0 || heads <= 0) return MQ_EINVAL;
+    if (!qkv_dev || (!out_dev && !out_h_dev) || (!out_h_dev != !out_l_dev) || B < 0 || L < 0 || heads <= 0) return MQ_EINVAL;
     if (head_dim != DH || L > 256) return MQ_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(B * heads), (unsigned)((L + 127) / 128));
@@ -773,7 +943,7 @@ int mq_attention_causal_f32(const float* qkv_dev, const int64_t* attention_mask_
         const size_t lds = (size_t)(32 * NKT) * (65 + 64 + 1) * 4 > (size_t)4 * 32 * 65 * 4 ? (size_t)(32 * NKT) * (65 + 64 + 1) * 4 : (size_t)4 * 32 * 65 * 4; \
         ENC_HIP(hipFuncSetAttribute((const void*)attention_mfma_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(attention_mfma_kernel<NKT>, grid, dim3(256), lds, st, qkv_dev, (const long long*)attention_mask_dev,    \
-                           out_dev, L, heads, scale, causal ? 1 : 0);                                                 \
+                           out_dev, (unsigned short*)out_h_dev, (unsigned short*)out_l_dev, L, heads, scale, causal ? 1 : 0); \
     }
     if (L <= 64) MQ_ATT(2)
     else if (L <= 128) MQ_ATT(4)

@@ -62,11 +62,65 @@ def split_bf16(w):
     return hi, lo
 
 
-def gemm_nt(a, w, bias=None, residual=None, epilogue=EPI_NONE, out=None, wsplit=None):
+class SplitAct:
+    """An activation kept as its (hi, lo) bf16 pair (two int16 tensors of the activation's [rows, features] shape):
+    what the kernels producing GEMM inputs write in split_bf16 mode, and what ``mq_gemm_nt_bf16x3s_f32`` consumes."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = hi, lo
+
+    @classmethod
+    def empty(cls, rows, features, device):
+        return cls(torch.empty((rows, features), dtype=torch.int16, device=device),
+                   torch.empty((rows, features), dtype=torch.int16, device=device))
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    @property
+    def device(self):
+        return self.hi.device
+
+    def first_rows(self, B, L):
+        """rows 0, L, 2L, ... (the first token of each of B sequences)"""
+        H = self.hi.shape[1]
+        return SplitAct(self.hi.view(B, L, H)[:, 0, :].contiguous(), self.lo.view(B, L, H)[:, 0, :].contiguous())
+
+    def float(self):
+        return self.hi.view(torch.bfloat16).float() + self.lo.view(torch.bfloat16).float()
+
+
+def _use_split(*feature_counts):
+    """split activations are used when every GEMM depth of the block is a multiple of the kernel's K step"""
+    return _gemm_mode() == "split_bf16" and all(k % 32 == 0 for k in feature_counts)
+
+
+def gemm_nt(a, w, bias=None, residual=None, epilogue=EPI_NONE, out=None, wsplit=None, out_split=False):
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T).  ``wsplit`` = (hi, lo) from :func:`split_bf16` selects the
-    split-bf16 kernel (fp32-class accuracy on the bf16 matrix pipe; K must be a multiple of 32)."""
-    _check_cuda(a, w)
+    split-bf16 kernels (fp32-class accuracy on the bf16 matrix pipe; K must be a multiple of 32).  ``a`` may be a
+    :class:`SplitAct` (no conversions in the GEMM loop); ``out_split`` returns the result as a :class:`SplitAct`."""
     lib = _lib.load()
+    if isinstance(a, SplitAct):
+        _check_cuda(a.hi, w)
+        if wsplit is None:
+            raise ValueError("a split activation needs split weights")
+        M, K = a.shape
+        N = w.shape[0]
+        b = bias.data_ptr() if bias is not None else None
+        r = residual.data_ptr() if residual is not None else None
+        res = SplitAct.empty(M, N, a.device) if out_split else (
+            out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device))
+        with torch.cuda.device(a.device):
+            _lib.check(lib.mq_gemm_nt_bf16x3s_f32(
+                a.hi.data_ptr(), a.lo.data_ptr(), wsplit[0].data_ptr(), wsplit[1].data_ptr(), b, r,
+                None if out_split else res.data_ptr(), res.hi.data_ptr() if out_split else None,
+                res.lo.data_ptr() if out_split else None, M, N, K, epilogue, _stream(a.hi)), "mq_gemm_nt_bf16x3s_f32")
+        return res
+    if out_split:
+        raise ValueError("out_split needs a split input activation")
+    _check_cuda(a, w)
     M, K = a.shape
     N = w.shape[0]
     if out is None:
@@ -100,10 +154,32 @@ def layernorm(x, g, b, eps, out=None):
     return out
 
 
-def attention(qkv, mask, B, L, heads, scale, causal=False):
+def layernorm_split(x, g, b, eps, f32_out=None, want_f32=True):
+    """LayerNorm writing the split pair of its output and, when ``want_f32``, the fp32 output too (into ``f32_out`` if
+    given).  -> (fp32 tensor or None, SplitAct)."""
+    _check_cuda(x)
+    lib = _lib.load()
+    M, C = x.shape
+    y = (f32_out if f32_out is not None else torch.empty_like(x)) if want_f32 else None
+    sp = SplitAct.empty(M, C, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.mq_layernorm_split_f32(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr() if y is not None else None,
+                                              sp.hi.data_ptr(), sp.lo.data_ptr(), M, C, float(eps), _stream(x)),
+                   "mq_layernorm_split_f32")
+    return y, sp
+
+
+def attention(qkv, mask, B, L, heads, scale, causal=False, split=False):
     _check_cuda(qkv)
     lib = _lib.load()
     H = qkv.shape[1] // 3
+    if split:
+        sp = SplitAct.empty(B * L, H, qkv.device)
+        with torch.cuda.device(qkv.device):
+            _lib.check(lib.mq_attention_split_f32(qkv.data_ptr(), mask.data_ptr() if mask is not None else None, None,
+                                                  sp.hi.data_ptr(), sp.lo.data_ptr(), B, L, heads, H // heads, float(scale),
+                                                  int(bool(causal)), _stream(qkv)), "mq_attention_split_f32")
+        return sp
     out = torch.empty((B * L, H), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
         _lib.check(lib.mq_attention_causal_f32(qkv.data_ptr(), mask.data_ptr() if mask is not None else None, out.data_ptr(),
@@ -206,29 +282,45 @@ class BertEncoderHIP(_HipEncoder):
         tt = token_type_ids.to(torch.int64).contiguous() if token_type_ids is not None else None
         mask = attention_mask.to(torch.int64).contiguous() if attention_mask is not None else None
         H = self.hidden
+        split = _use_split(H, self.l0_wi.shape[0])  # activations that only feed GEMMs travel as (hi, lo) bf16 pairs
         h = torch.empty((B * L, H), dtype=torch.float32, device=dev)
+        hs = SplitAct.empty(B * L, H, dev) if split else None
         with torch.cuda.device(dev):
-            _lib.check(lib.mq_bert_embed_ln_f32(ids.data_ptr(), tt.data_ptr() if tt is not None else None, self.w_word.data_ptr(),
-                                                self.w_pos.data_ptr(), self.w_type.data_ptr(), self.emb_g.data_ptr(),
-                                                self.emb_b.data_ptr(), h.data_ptr(), B, L, H, self.eps, _stream(h)),
-                       "mq_bert_embed_ln_f32")
+            _lib.check(lib.mq_bert_embed_ln_split_f32(
+                ids.data_ptr(), tt.data_ptr() if tt is not None else None, self.w_word.data_ptr(), self.w_pos.data_ptr(),
+                self.w_type.data_ptr(), self.emb_g.data_ptr(), self.emb_b.data_ptr(), h.data_ptr(),
+                hs.hi.data_ptr() if split else None, hs.lo.data_ptr() if split else None, B, L, H, self.eps, _stream(h)),
+                "mq_bert_embed_ln_split_f32")
         hidden = [h.view(B, L, H)] if output_hidden_states else None
         scale = 1.0 / math.sqrt(H // self.heads)
         for i in range(self.layers):
             w = lambda n: getattr(self, f"l{i}_{n}")  # noqa: E731
             sp = lambda n: self._ws(f"l{i}_{n}")  # noqa: E731
-            qkv = gemm_nt(h, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
-            ctx = attention(qkv, mask, B, L, self.heads, scale)
-            if cls_only and i == self.layers - 1:
-                # DPR reads only last_hidden_state[:, 0]: after the last attention, the output projection, both
-                # LayerNorms and the FFN are row-wise, so run them on the [CLS] rows alone (same numbers, 1/L of the rows)
-                ctx = ctx.view(B, L, H)[:, 0, :].contiguous()
-                h = h.view(B, L, H)[:, 0, :].contiguous()
-            a = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, wsplit=sp("wo"))
-            h1 = layernorm(a, w("g1"), w("b1"), self.eps, out=a)
-            f = gemm_nt(h1, w("wi"), w("bi"), None, EPI_BIAS_GELU, wsplit=sp("wi"))
-            o = gemm_nt(f, w("w2"), w("b2"), h1, EPI_BIAS_RESIDUAL, wsplit=sp("w2"))
-            h = layernorm(o, w("g2"), w("b2n"), self.eps, out=o)
+            last_cls = cls_only and i == self.layers - 1
+            if split:
+                qkv = gemm_nt(hs, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
+                ctx = attention(qkv, mask, B, L, self.heads, scale, split=True)
+                if last_cls:
+                    # DPR reads only last_hidden_state[:, 0]: after the last attention, the output projection, both
+                    # LayerNorms and the FFN are row-wise, so run them on the [CLS] rows alone (same numbers, 1/L of the rows)
+                    ctx = ctx.first_rows(B, L)
+                    h = h.view(B, L, H)[:, 0, :].contiguous()
+                a = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, wsplit=sp("wo"))
+                h1, h1s = layernorm_split(a, w("g1"), w("b1"), self.eps, f32_out=a)
+                f = gemm_nt(h1s, w("wi"), w("bi"), None, EPI_BIAS_GELU, wsplit=sp("wi"), out_split=True)
+                o = gemm_nt(f, w("w2"), w("b2"), h1, EPI_BIAS_RESIDUAL, wsplit=sp("w2"))
+                h, hs = layernorm_split(o, w("g2"), w("b2n"), self.eps, f32_out=o)
+            else:
+                qkv = gemm_nt(h, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
+                ctx = attention(qkv, mask, B, L, self.heads, scale)
+                if last_cls:
+                    ctx = ctx.view(B, L, H)[:, 0, :].contiguous()
+                    h = h.view(B, L, H)[:, 0, :].contiguous()
+                a = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, wsplit=sp("wo"))
+                h1 = layernorm(a, w("g1"), w("b1"), self.eps, out=a)
+                f = gemm_nt(h1, w("wi"), w("bi"), None, EPI_BIAS_GELU, wsplit=sp("wi"))
+                o = gemm_nt(f, w("w2"), w("b2"), h1, EPI_BIAS_RESIDUAL, wsplit=sp("w2"))
+                h = layernorm(o, w("g2"), w("b2n"), self.eps, out=o)
             if output_hidden_states:
                 hidden.append(h.view(B, L, H))
         if cls_only:
@@ -278,6 +370,25 @@ class DPRQuestionEncoder(_DPREncoder):
 # --------------------------------------------------------------------------------------------------
 # CLIP vision tower
 # --------------------------------------------------------------------------------------------------
+def _clip_block(h, w, sp, mask, B, T, heads, scale, eps, act, causal):
+    """One pre-LN CLIP transformer block on the residual stream h [B*T, H] (updated in place)."""
+    if _use_split(h.shape[1], w("w1").shape[0]):
+        _, y = layernorm_split(h, w("g1"), w("b1"), eps, want_f32=False)
+        qkv = gemm_nt(y, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
+        ctx = attention(qkv, mask, B, T, heads, scale, causal=causal, split=True)
+        h = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("wo"))
+        _, y = layernorm_split(h, w("g2"), w("b2n"), eps, want_f32=False)
+        f = gemm_nt(y, w("w1"), w("bb1"), None, act, wsplit=sp("w1"), out_split=True)
+        return gemm_nt(f, w("w2"), w("bb2"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("w2"))
+    y = layernorm(h, w("g1"), w("b1"), eps)
+    qkv = gemm_nt(y, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
+    ctx = attention(qkv, mask, B, T, heads, scale, causal=causal)
+    h = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("wo"))
+    y = layernorm(h, w("g2"), w("b2n"), eps, out=y)
+    f = gemm_nt(y, w("w1"), w("bb1"), None, act, wsplit=sp("w1"))
+    return gemm_nt(f, w("w2"), w("bb2"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("w2"))
+
+
 class CLIPModel(_HipEncoder):
     """transformers.CLIPModel restricted to the two calls the reference makes: ``get_image_features``
     (experiments/image_embedding/clip/vit_config.json:18: ViT vision tower + visual projection) and
@@ -410,13 +521,7 @@ class CLIPModel(_HipEncoder):
         for i in range(self.t_layers):
             w = lambda n: getattr(self, f"t{i}_{n}")  # noqa: E731
             sp = lambda n: self._ws(f"t{i}_{n}")  # noqa: E731
-            y = layernorm(h, w("g1"), w("b1"), self.t_eps)
-            qkv = gemm_nt(y, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
-            ctx = attention(qkv, mask, B, L, self.t_heads, scale, causal=True)
-            h = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("wo"))
-            y = layernorm(h, w("g2"), w("b2n"), self.t_eps, out=y)
-            f = gemm_nt(y, w("w1"), w("bb1"), None, self.t_act, wsplit=sp("w1"))
-            h = gemm_nt(f, w("w2"), w("bb2"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("w2"))
+            h = _clip_block(h, w, sp, mask, B, L, self.t_heads, scale, self.t_eps, self.t_act, causal=True)
         pooled = torch.empty((B, H), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(lib.mq_clip_eos_pool_ln_f32(h.data_ptr(), ids.data_ptr(), self.t_eos, self.t_fin_g.data_ptr(),
@@ -449,14 +554,8 @@ class CLIPModel(_HipEncoder):
         scale = (H // self.heads) ** -0.5
         for i in range(self.layers):
             w = lambda n: getattr(self, f"l{i}_{n}")  # noqa: E731
-            y = layernorm(h, w("g1"), w("b1"), self.eps)
             sp = lambda n: self._ws(f"l{i}_{n}")  # noqa: E731
-            qkv = gemm_nt(y, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
-            ctx = attention(qkv, None, B, T, self.heads, scale)
-            h = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("wo"))
-            y = layernorm(h, w("g2"), w("b2n"), self.eps, out=y)
-            f = gemm_nt(y, w("w1"), w("bb1"), None, self.act, wsplit=sp("w1"))
-            h = gemm_nt(f, w("w2"), w("bb2"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("w2"))
+            h = _clip_block(h, w, sp, None, B, T, self.heads, scale, self.eps, self.act, causal=False)
         pooled = layernorm(h.view(B, T, H)[:, 0, :].contiguous(), self.post_g, self.post_b, self.eps)
         return gemm_nt(pooled, self.wproj, None, None, EPI_NONE, wsplit=self._ws("wproj"))
 
