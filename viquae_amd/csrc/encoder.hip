@@ -638,7 +638,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     const int H = heads * DH, ld = 3 * H;
     const float* base = qkv + (size_t)bi * L * ld + h * DH;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int e = tid; e < NK * (DH / 4); e += 256) {
+    const int nthr = blockDim.x;  // 64 * min(4, ceil(queries of this block / 32)) threads: no wave without queries
+    for (int e = tid; e < NK * (DH / 4); e += nthr) {
         const int j = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
         float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
         if (j < L) {
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         kd[0] = kf.x; kd[1] = kf.y; kd[2] = kf.z; kd[3] = kf.w;
         *reinterpret_cast<float4*>(Vs + j * 64 + c4) = vf;
     }
-    for (int j = tid; j < NK; j += 256) addm[j] = (j < L && (!mask || mask[(size_t)bi * L + j] != 0)) ? 0.f : -INFINITY;
+    for (int j = tid; j < NK; j += nthr) addm[j] = (j < L && (!mask || mask[(size_t)bi * L + j] != 0)) ? 0.f : -INFINITY;
     __syncthreads();
 
     const int i = lane & 31, kh = lane >> 5;
@@ -938,11 +939,12 @@ int mq_attention_split_f32(const float* qkv_dev, const int64_t* attention_mask_d
     if (head_dim != DH || L > 256) return MQ_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(B * heads), (unsigned)((L + 127) / 128));
+    const unsigned nthr = 64u * (unsigned)(L >= 97 ? 4 : (L + 31) / 32);  // one wave per 32 queries (short sequences: fewer waves)
 #define MQ_ATT(NKT)                                                                                                   \
     {                                                                                                                 \
         const size_t lds = (size_t)(32 * NKT) * (65 + 64 + 1) * 4 > (size_t)4 * 32 * 65 * 4 ? (size_t)(32 * NKT) * (65 + 64 + 1) * 4 : (size_t)4 * 32 * 65 * 4; \
         ENC_HIP(hipFuncSetAttribute((const void*)attention_mfma_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(attention_mfma_kernel<NKT>, grid, dim3(256), lds, st, qkv_dev, (const long long*)attention_mask_dev,    \
+        hipLaunchKernelGGL(attention_mfma_kernel<NKT>, grid, dim3(nthr), lds, st, qkv_dev, (const long long*)attention_mask_dev,    \
                            out_dev, (unsigned short*)out_h_dev, (unsigned short*)out_l_dev, L, heads, scale, causal ? 1 : 0); \
     }
     if (L <= 64) MQ_ATT(2)
