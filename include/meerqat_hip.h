@@ -193,7 +193,8 @@ int mq_clip_eos_pool_ln_f32(const float *hidden_dev, const int64_t *input_ids_de
  *   mq_gemm_nt_bf16x3s_f32     mq_gemm_nt_bf16x3_f32 with A given as (Ah, Al); output EITHER fp32 C OR the pair (Ch, Cl)
  *   mq_layernorm_split_f32     mq_layernorm_f32 writing Y (fp32, may be NULL) and/or the pair (Yh, Yl)
  *   mq_bert_embed_ln_split_f32 mq_bert_embed_ln_f32 writing fp32 and, optionally, the pair
- *   mq_attention_split_f32     mq_attention_causal_f32 writing fp32 (may be NULL) and/or the pair
+ *   mq_attention_split_f32     mq_attention_causal_f32 writing fp32 (may be NULL) and/or the pair; bf16x3 != 0 computes
+ *                              q.k and p.v as three-term split-bf16 products on the bf16 matrix pipe (fp32-class accuracy)
  * Pair outputs need an even feature count. */
 int mq_gemm_nt_bf16x3s_f32(const uint16_t *Ah_dev, const uint16_t *Al_dev, const uint16_t *Wh_dev, const uint16_t *Wl_dev,
                            const float *bias_dev, const float *residual_dev, float *C_dev, uint16_t *Ch_dev, uint16_t *Cl_dev,
@@ -205,7 +206,8 @@ int mq_bert_embed_ln_split_f32(const int64_t *input_ids_dev, const int64_t *toke
                                float *out_dev, uint16_t *out_h_dev, uint16_t *out_l_dev, int B, int L, int H, float eps,
                                void *stream);
 int mq_attention_split_f32(const float *qkv_dev, const int64_t *attention_mask_dev, float *out_dev, uint16_t *out_h_dev,
-                           uint16_t *out_l_dev, int B, int L, int heads, int head_dim, float scale, int causal, void *stream);
+                           uint16_t *out_l_dev, int B, int L, int heads, int head_dim, float scale, int causal, int bf16x3,
+                           void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Late fusion of several runs on the device: replaces, for integer document

@@ -104,13 +104,16 @@ def test_attention_vs_torch(B, L, heads, masked):
     if masked:
         lens = torch.randint(1, L + 1, (B,), generator=g, device="cuda")
         mask = (torch.arange(L, device="cuda")[None] < lens[:, None]).to(torch.int64)
-    out = E.attention(qkv, mask, B, L, heads, 0.125)
+    out = E.attention(qkv, mask, B, L, heads, 0.125, bf16x3=False)
+    out3 = E.attention(qkv, mask, B, L, heads, 0.125, bf16x3=True)
     q, k, v = [t.reshape(B, L, heads, 64).permute(0, 2, 1, 3).double() for t in qkv.split(H, dim=1)]
     s = q @ k.transpose(-1, -2) * 0.125
     if mask is not None:
         s = s + (1.0 - mask.double())[:, None, None, :] * torch.finfo(torch.float32).min
     ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * L, H)
     assert (out.double() - ref).abs().max().item() < 1e-5
+    # split-bf16 products (3 x 2^-18 relative per product, on logits of a few units): fp32-class, far below the 1e-3 bar
+    assert (out3.double() - ref).abs().max().item() < 5e-5
 
 
 def _dpr(cfg, seed):
@@ -197,7 +200,8 @@ def test_causal_attention_vs_torch(B, L, heads, with_mask):
     if with_mask:
         lens = torch.randint(1, L + 1, (B,), generator=g, device="cuda")
         mask = (torch.arange(L, device="cuda")[None] < lens[:, None]).to(torch.int64)
-    out = E.attention(qkv, mask, B, L, heads, 0.125, causal=True)
+    out = E.attention(qkv, mask, B, L, heads, 0.125, causal=True, bf16x3=False)
+    out3 = E.attention(qkv, mask, B, L, heads, 0.125, causal=True, bf16x3=True)
     q, k, v = [t.reshape(B, L, heads, 64).transpose(1, 2).double() for t in qkv.view(B, L, 3 * H).split(H, dim=2)]
     s = q @ k.transpose(-1, -2) * 0.125
     allowed = torch.tril(torch.ones((L, L), dtype=torch.bool, device="cuda"))[None, None]
@@ -206,6 +210,7 @@ def test_causal_attention_vs_torch(B, L, heads, with_mask):
     s = s.masked_fill(~allowed, float("-inf"))
     ref = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B * L, H)
     assert (out.double() - ref).abs().max().item() < 2e-5   # fp32 softmax / accumulation over <= 200 keys
+    assert (out3.double() - ref).abs().max().item() < 5e-5  # split-bf16 products
 
 
 def test_clip_text_embed_and_eos_pool_ops():
@@ -308,10 +313,11 @@ def test_attention_split_output_is_the_split_of_the_fp32_output(B, L, heads, cau
     qkv = torch.randn((B * L, 3 * heads * 64), generator=g, device="cuda")
     lens = torch.randint(1, L + 1, (B,), generator=g, device="cuda")
     mask = (torch.arange(L, device="cuda")[None] < lens[:, None]).to(torch.int64)
-    out = E.attention(qkv, mask, B, L, heads, 0.125, causal=causal)
-    sp = E.attention(qkv, mask, B, L, heads, 0.125, causal=causal, split=True)
-    hi, lo = _pair_of(out)
-    assert torch.equal(sp.hi, hi) and torch.equal(sp.lo, lo)
+    for x3 in (False, True):
+        out = E.attention(qkv, mask, B, L, heads, 0.125, causal=causal, bf16x3=x3)
+        sp = E.attention(qkv, mask, B, L, heads, 0.125, causal=causal, split=True, bf16x3=x3)
+        hi, lo = _pair_of(out)
+        assert torch.equal(sp.hi, hi) and torch.equal(sp.lo, lo)
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (800, 768, 768), (37, 100, 96), (300, 2304, 768), (513, 128, 3072)])

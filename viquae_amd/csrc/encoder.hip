@@ -729,6 +729,175 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 attention: the same softmax(q k^T * scale + mask) v on the bf16 matrix pipe at fp32-class accuracy.
+// K and V^T are staged in LDS as (hi, lo) bf16 pairs, Q is split in registers, and every product is the three-term
+// sum lo.hi + hi.lo + hi.hi (fp32 accumulate), as in the split-bf16 GEMM: 12 MFMAs of 32 cycles per 32-key tile for
+// S and 12 for P.V instead of 32 + 32 fp32 MFMAs of 64 cycles.  S^T = K . Q^T keeps one query per lane column
+// (softmax = per-lane reduction + one lane^32 exchange).  For P.V the probabilities are the B operand: lane
+// (query j, half kg) needs P for 8 CONSECUTIVE keys, while the accumulator layout gave it keys {0-3, 8-11, ...} + 4 kh:
+// four values per 16-key group are exchanged with lane^32, then split into (hi, lo).
+// LDS: Kh, Kl [NK][64] bf16 (16-byte chunks swizzled by (key >> 1) & 7), Vth, Vtl [64][NK] bf16 (chunks swizzled by
+// d & (NK/8 - 1)), mask row.
+// ------------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ qkv, const long long* __restrict__ mask,
+                                                           float* __restrict__ out, unsigned short* __restrict__ out_h,
+                                                           unsigned short* __restrict__ out_l, int L, int heads, float scale,
+                                                           int causal) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NK = 32 * NKT, NCH = NK / 8;           // 16-byte chunks (8 keys) per V^T row
+    constexpr int K_BYTES = NK * 128, V_BYTES = 64 * NK * 2;
+    char* Kh = smem;
+    char* Kl = Kh + K_BYTES;
+    char* Vth = Kl + K_BYTES;
+    char* Vtl = Vth + V_BYTES;
+    float* addm = reinterpret_cast<float*>(Vtl + V_BYTES);  // [NK] 0 or -inf
+    const int bi = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int H = heads * DH, ld = 3 * H;
+    const float* base = qkv + (size_t)bi * L * ld + h * DH;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nthr = blockDim.x;
+    for (int e = tid; e < NK * (DH / 4); e += nthr) {
+        const int j = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
+        float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
+        if (j < L) {
+            kf = *reinterpret_cast<const float4*>(base + (size_t)j * ld + H + c4);
+            vf = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * H + c4);
+        }
+        // K row j: four consecutive d -> 8 bytes inside chunk c4 / 8
+        const unsigned k01 = split_bits(kf.x), k23 = split_bits(kf.y), k45 = split_bits(kf.z), k67 = split_bits(kf.w);
+        const int koff = j * 128 + (((c4 >> 3) ^ ((j >> 1) & 7)) * 16) + (c4 & 7) * 2;
+        *reinterpret_cast<uint2*>(Kh + koff) = make_uint2((k01 & 0xFFFFu) | (k23 << 16), (k45 & 0xFFFFu) | (k67 << 16));
+        *reinterpret_cast<uint2*>(Kl + koff) = make_uint2((k01 >> 16) | (k23 & 0xFFFF0000u), (k45 >> 16) | (k67 & 0xFFFF0000u));
+        // V^T rows c4 .. c4+3, column j
+        const float vv[4] = {vf.x, vf.y, vf.z, vf.w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int d = c4 + jj;
+            const unsigned vb = split_bits(vv[jj]);
+            const int voff = d * (NK * 2) + (((j >> 3) ^ (d & (NCH - 1))) * 16) + (j & 7) * 2;
+            *reinterpret_cast<unsigned short*>(Vth + voff) = (unsigned short)(vb & 0xFFFFu);
+            *reinterpret_cast<unsigned short*>(Vtl + voff) = (unsigned short)(vb >> 16);
+        }
+    }
+    for (int j = tid; j < NK; j += nthr) addm[j] = (j < L && (!mask || mask[(size_t)bi * L + j] != 0)) ? 0.f : -INFINITY;
+    __syncthreads();
+
+    const int i = lane & 31, kg = lane >> 5;
+    const int qrow = blockIdx.y * 128 + 32 * w + i;   // this lane's query
+    bf16x8_t qh[4], ql[4];                            // d in [16 m + 8 kg, + 8)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+        if (qrow < L) {
+            const float* qp = base + (size_t)qrow * ld + 16 * m + 8 * kg;
+            u = *reinterpret_cast<const float4*>(qp);
+            v = *reinterpret_cast<const float4*>(qp + 4);
+        }
+        split8(u, v, qh[m], ql[m]);
+    }
+
+    f32x16 sacc[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) sacc[t] = (f32x16){0};
+    const int ksw = (i >> 1) & 7;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int ko = (32 * t + i) * 128 + (((2 * m + kg) ^ ksw) * 16);
+            const bf16x8_t kh_ = *reinterpret_cast<const bf16x8_t*>(Kh + ko);
+            const bf16x8_t kl_ = *reinterpret_cast<const bf16x8_t*>(Kl + ko);
+            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl_, qh[m], sacc[t], 0, 0, 0);
+            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh_, ql[m], sacc[t], 0, 0, 0);
+            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh_, qh[m], sacc[t], 0, 0, 0);
+        }
+    }
+    // sacc[t][reg] = <k_key, q_query>, key = 32 t + (reg&3) + 8 (reg>>2) + 4 kg, query = this lane's column
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int key = 32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+            float sv = sacc[t][reg] * scale + addm[key];
+            if (causal && key > qrow) sv = -INFINITY;
+            sacc[t][reg] = sv;
+            mx = fmaxf(mx, sv);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float den = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const float p = (sacc[t][reg] == -INFINITY) ? 0.f : expf(sacc[t][reg] - mx);
+            sacc[t][reg] = p;
+            den += p;
+        }
+    }
+    den += __shfl_xor(den, 32);
+
+    f32x16 oacc0 = {0}, oacc1 = {0};
+    const int vsw0 = i & (NCH - 1);  // d = i and d = 32 + i swizzle alike when NCH <= 32
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            // keys 32 t + 16 g + 8 kg + (0..7): k 0..3 sit in the lower lane's registers 8g+4kg+r, k 4..7 in the upper's
+            float p8[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float lo_half = sacc[t][8 * g + r], hi_half = sacc[t][8 * g + 4 + r];
+                const float send = kg ? lo_half : hi_half;          // what the partner lane needs from me
+                const float recv = __shfl_xor(send, 32);
+                p8[r] = kg ? recv : lo_half;                        // keys +0..3: held by the lower lane
+                p8[4 + r] = kg ? hi_half : recv;                    // keys +4..7: held by the upper lane
+            }
+            bf16x8_t ph, pl;
+            split8(make_float4(p8[0], p8[1], p8[2], p8[3]), make_float4(p8[4], p8[5], p8[6], p8[7]), ph, pl);
+            const int ck = 4 * t + 2 * g + kg;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int vo = (32 * dt + i) * (NK * 2) + ((ck ^ vsw0) * 16);
+                const bf16x8_t vh_ = *reinterpret_cast<const bf16x8_t*>(Vth + vo);
+                const bf16x8_t vl_ = *reinterpret_cast<const bf16x8_t*>(Vtl + vo);
+                if (dt == 0) {
+                    oacc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl_, ph, oacc0, 0, 0, 0);
+                    oacc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh_, pl, oacc0, 0, 0, 0);
+                    oacc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh_, ph, oacc0, 0, 0, 0);
+                } else {
+                    oacc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl_, ph, oacc1, 0, 0, 0);
+                    oacc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh_, pl, oacc1, 0, 0, 0);
+                    oacc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh_, ph, oacc1, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // oacc{0,1}[reg] = sum_key p V[key][d], d = 32 dt + (reg&3) + 8 (reg>>2) + 4 kg, for this lane's query.
+    // Transpose through LDS (K/V are dead) so that every query row is stored as 256 contiguous bytes.
+    __syncthreads();
+    float* Ot = reinterpret_cast<float*>(smem) + w * (32 * 65);   // [32 queries][65]
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int d = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+        Ot[i * 65 + d] = oacc0[reg] * inv;
+        Ot[i * 65 + 32 + d] = oacc1[reg] * inv;
+    }
+    __syncthreads();
+    for (int e = lane; e < 32 * 64; e += 64) {
+        const int r = e >> 6, c = e & 63;
+        const int qr = blockIdx.y * 128 + 32 * w + r;
+        const size_t at = ((size_t)bi * L + qr) * H + h * DH;
+        const float val = Ot[r * 65 + c];
+        if (out && qr < L) out[at + c] = val;
+        if (out_h) store_split_pair(val, qr < L, out_h, out_l, at + (c & ~1), lane);
+    }
+}
+
 // CLIP text tower input: token embedding + position embedding (no LayerNorm, no token types)
 __global__ __launch_bounds__(256) void clip_text_embed_kernel(const long long* __restrict__ ids, const float* __restrict__ tok,
                                                               const float* __restrict__ pos, float* __restrict__ out, int M,
@@ -929,11 +1098,13 @@ int mq_attention_f32(const float* qkv_dev, const int64_t* attention_mask_dev, fl
 int mq_attention_causal_f32(const float* qkv_dev, const int64_t* attention_mask_dev, float* out_dev, int B, int L, int heads,
                             int head_dim, float scale, int causal, void* stream) {
     if (!out_dev) return (B == 0 || L == 0) ? MQ_OK : MQ_EINVAL;
-    return mq_attention_split_f32(qkv_dev, attention_mask_dev, out_dev, nullptr, nullptr, B, L, heads, head_dim, scale, causal, stream);
+    return mq_attention_split_f32(qkv_dev, attention_mask_dev, out_dev, nullptr, nullptr, B, L, heads, head_dim, scale, causal, 0,
+                                  stream);
 }
 
 int mq_attention_split_f32(const float* qkv_dev, const int64_t* attention_mask_dev, float* out_dev, uint16_t* out_h_dev,
-                           uint16_t* out_l_dev, int B, int L, int heads, int head_dim, float scale, int causal, void* stream) {
+                           uint16_t* out_l_dev, int B, int L, int heads, int head_dim, float scale, int causal, int bf16x3,
+                           void* stream) {
     if (B == 0 || L == 0) return MQ_OK;
     if (!qkv_dev || (!out_dev && !out_h_dev) || (!out_h_dev != !out_l_dev) || B < 0 || L < 0 || heads <= 0) return MQ_EINVAL;
     if (head_dim != DH || L > 256) return MQ_EUNSUPPORTED;
@@ -947,10 +1118,26 @@ int mq_attention_split_f32(const float* qkv_dev, const int64_t* attention_mask_d
         hipLaunchKernelGGL(attention_mfma_kernel<NKT>, grid, dim3(nthr), lds, st, qkv_dev, (const long long*)attention_mask_dev,    \
                            out_dev, (unsigned short*)out_h_dev, (unsigned short*)out_l_dev, L, heads, scale, causal ? 1 : 0); \
     }
-    if (L <= 64) MQ_ATT(2)
-    else if (L <= 128) MQ_ATT(4)
-    else MQ_ATT(8)
+#define MQ_ATT3(NKT)                                                                                                  \
+    {                                                                                                                 \
+        const size_t need = (size_t)(32 * NKT) * 128 * 2 + (size_t)64 * (32 * NKT) * 2 * 2 + (size_t)(32 * NKT) * 4;    \
+        const size_t lds = need > (size_t)4 * 32 * 65 * 4 ? need : (size_t)4 * 32 * 65 * 4;                           \
+        ENC_HIP(hipFuncSetAttribute((const void*)attention_x3_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(attention_x3_kernel<NKT>, grid, dim3(nthr), lds, st, qkv_dev, (const long long*)attention_mask_dev,    \
+                           out_dev, (unsigned short*)out_h_dev, (unsigned short*)out_l_dev, L, heads, scale, causal ? 1 : 0); \
+    }
+    if (bf16x3) {
+        if (((uintptr_t)qkv_dev & 15) || (heads * DH) % 4) return MQ_EINVAL;  // 16-byte query loads
+        if (L <= 64) MQ_ATT3(2)
+        else if (L <= 128) MQ_ATT3(4)
+        else MQ_ATT3(8)
+    } else {
+        if (L <= 64) MQ_ATT(2)
+        else if (L <= 128) MQ_ATT(4)
+        else MQ_ATT(8)
+    }
 #undef MQ_ATT
+#undef MQ_ATT3
     ENC_HIP(hipGetLastError());
     return MQ_OK;
 }

@@ -169,23 +169,23 @@ def layernorm_split(x, g, b, eps, f32_out=None, want_f32=True):
     return y, sp
 
 
-def attention(qkv, mask, B, L, heads, scale, causal=False, split=False):
+def attention(qkv, mask, B, L, heads, scale, causal=False, split=False, bf16x3=None):
+    """softmax(q k^T * scale + mask) v.  ``bf16x3`` (default: on in split_bf16 mode) computes both products as
+    three-term split-bf16 sums on the bf16 matrix pipe; ``split`` returns the output as a :class:`SplitAct`."""
     _check_cuda(qkv)
     lib = _lib.load()
     H = qkv.shape[1] // 3
-    if split:
-        sp = SplitAct.empty(B * L, H, qkv.device)
-        with torch.cuda.device(qkv.device):
-            _lib.check(lib.mq_attention_split_f32(qkv.data_ptr(), mask.data_ptr() if mask is not None else None, None,
-                                                  sp.hi.data_ptr(), sp.lo.data_ptr(), B, L, heads, H // heads, float(scale),
-                                                  int(bool(causal)), _stream(qkv)), "mq_attention_split_f32")
-        return sp
-    out = torch.empty((B * L, H), dtype=torch.float32, device=qkv.device)
+    if bf16x3 is None:
+        bf16x3 = _gemm_mode() == "split_bf16"
+    sp = SplitAct.empty(B * L, H, qkv.device) if split else None
+    out = None if split else torch.empty((B * L, H), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        _lib.check(lib.mq_attention_causal_f32(qkv.data_ptr(), mask.data_ptr() if mask is not None else None, out.data_ptr(),
-                                               B, L, heads, H // heads, float(scale), int(bool(causal)), _stream(qkv)),
-                   "mq_attention_causal_f32")
-    return out
+        _lib.check(lib.mq_attention_split_f32(qkv.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                              out.data_ptr() if out is not None else None,
+                                              sp.hi.data_ptr() if split else None, sp.lo.data_ptr() if split else None, B, L,
+                                              heads, H // heads, float(scale), int(bool(causal)), int(bool(bf16x3)),
+                                              _stream(qkv)), "mq_attention_split_f32")
+    return sp if split else out
 
 
 # --------------------------------------------------------------------------------------------------
