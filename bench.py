@@ -109,6 +109,11 @@ def load_traffic(workload_key):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout when the process
+    # exits: keep a private handle on the real stdout for the JSON line and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from viquae_amd import _lib
@@ -345,7 +350,7 @@ def main():
                 }
             except Exception as e:
                 rec["secondary"] = {"error": repr(e)}
-        print(json.dumps(rec), flush=True)
+        os.write(json_fd, (json.dumps(rec) + "\n").encode())
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
