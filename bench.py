@@ -164,7 +164,7 @@ def main():
         if (which or mode) == "screened":
             _lib.check(lib.mq_knn_search_screened_f32(
                 local._packed.data_ptr(), local._sqnorm.data_ptr(), local._rowmajor.data_ptr(), local._bf16.data_ptr(),
-                local._xmax2.data_ptr(), rows, DIM, Q.data_ptr(), nq, k, 0, local.id_offset, D.data_ptr(), I.data_ptr(),
+                local._xmax2.data_ptr(), rows, DIM, Q.data_ptr(), nq, k, 0, 0, local.id_offset, D.data_ptr(), I.data_ptr(),
                 ws.data_ptr(), ws_bytes, stream.cuda_stream, e0, e1), "mq_knn_search_screened_f32")
         else:
             _lib.check(lib.mq_knn_search_f32_ev(local._packed.data_ptr(), local._sqnorm.data_ptr(), rows, DIM, Q.data_ptr(),

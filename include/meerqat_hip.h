@@ -90,23 +90,26 @@ int mq_knn_search_f32_ev(const float *packed_dev, const float *sqnorm_dev, int64
                          void *ev_scan_end);
 
 /* ---------------------------------------------------------------------------------------------
- * Screened search: SAME exact result as mq_knn_search_f32 (inner product), computed as a bf16
+ * Screened search: SAME exact result as mq_knn_search_f32 (both metrics), computed as a bf16
  * screening scan over a bf16 copy of the shard + exact fp32 re-scoring of the few survivors
- * (csrc/knn_screen.inc states the error bound that makes the screen lossless).  Extra shard buffers:
+ * (csrc/knn_screen.inc states the error bound that makes the screen lossless).  For MQ_METRIC_L2 the bf16 copy carries
+ * two extra columns, the bf16 pair of -||x||^2/2 (queries get 1, 1), so that the same scan ranks by q.x - ||x||^2/2.
+ * The bf16 copy is metric-specific: pass the same `metric` to the three calls.  Extra shard buffers:
  *   rowmajor_dev [N, d] fp32  : the stored rows in row-major order (re-scoring operand)
- *   bf16_dev                  : mq_knn_screen_bytes(N, d) bytes, bf16 copy (rows padded to 256, d to 64)
+ *   bf16_dev                  : mq_knn_screen_bytes(N, d, metric) bytes, bf16 copy (rows padded to 256, d (+2) to 64)
  *   xstats_dev                : two floats kept by mq_knn_screen_prepare (zero them before its first call):
  *                               max ||x||^2 and max ||x - bf16(x)||^2 over the shard, the inputs of the error bound
  * mq_knn_screen_prepare fills rowmajor/bf16 for rows [row_offset, row_offset+n) from the panel buffer.
  * Query tiles whose bounded candidate buffers overflow are recomputed by the exact scan inside the
  * same call.  Workspace: mq_knn_workspace_bytes (covers both paths).
  * ------------------------------------------------------------------------------------------- */
-size_t mq_knn_screen_bytes(int64_t n_rows, int d);
-int mq_knn_screen_prepare(const float *packed_dev, int64_t capacity_rows, int d, int64_t row_offset, int64_t n,
-                          float *rowmajor_dev, uint16_t *bf16_dev, float *xstats_dev, void *stream);
+size_t mq_knn_screen_bytes(int64_t n_rows, int d, int metric);
+int mq_knn_screen_prepare(const float *packed_dev, const float *sqnorm_dev, int64_t capacity_rows, int d, int metric,
+                          int64_t row_offset, int64_t n, float *rowmajor_dev, uint16_t *bf16_dev, float *xstats_dev,
+                          void *stream);
 int mq_knn_search_screened_f32(const float *packed_dev, const float *sqnorm_dev, const float *rowmajor_dev,
                                const uint16_t *bf16_dev, const float *xstats_dev, int64_t N, int d,
-                               const float *queries_dev, int nq, int k, int l2norm_queries, int64_t id_offset,
+                               const float *queries_dev, int nq, int k, int metric, int l2norm_queries, int64_t id_offset,
                                float *D_dev, int64_t *I_dev, void *ws_dev, size_t ws_bytes, void *stream,
                                void *ev_scan_begin, void *ev_scan_end);
 /* Telemetry of the last screened search held in ws_dev (synchronises the stream): out[0] = query

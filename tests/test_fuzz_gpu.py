@@ -36,7 +36,7 @@ def test_fuzz_against_oracle(seed):
     from viquae_amd.index import MI355XFlatIndex
     X, Q, k, metric, regime = _case(seed)
     Do, Io = ok.knn(X, Q, k, metric=metric)
-    for screen in ([True, False] if metric == 0 else [False]):
+    for screen in (True, False):
         idx = MI355XFlatIndex(string_factory="Flat", metric_type=metric, screen=screen)
         idx.add_vectors(X)
         D, I = idx.search_batch(Q, k)

@@ -77,10 +77,73 @@ def test_screened_l2norm_factory_and_incremental_add():
     assert np.array_equal(I, Io) and np.array_equal(D, Do)
 
 
-def test_l2_metric_never_uses_the_screen():
+@pytest.mark.parametrize("n,d,nq,k", [(3000, 64, 70, 10), (20000, 768, 300, 100), (70001, 100, 513, 128), (5000, 30, 1, 1)])
+def test_l2_screen_equals_exact_scan_and_oracle(n, d, nq, k):
+    """metric_type 1 (FAISS's default): the screen ranks by q.x - ||x||^2/2 through two extra bf16 columns; distances and
+    ids must equal the exact fp32 L2 scan and the oracle bit for bit."""
+    import torch
+    from oracle import knn as ok
     from viquae_amd.index import MI355XFlatIndex
+    rng = np.random.default_rng(n + d)
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    Q[0] = X[7]          # an exact hit: distance 0 (the clamp)
+    X[11] = X[7]         # ... twice: a clamped tie, lowest id first
+    scr = MI355XFlatIndex(string_factory="Flat", metric_type=1, screen=True)
+    assert scr.screen
+    scr.add_vectors(X)
+    ex = MI355XFlatIndex(string_factory="Flat", metric_type=1, screen=False)
+    ex.add_vectors(X)
+    D, I = scr.search_batch(Q, k)
+    D0, I0 = ex.search_batch(Q, k)
+    Do, Io = ok.knn(X, Q, k, metric=1)
+    assert np.array_equal(I, I0) and np.array_equal(D, D0)
+    assert np.array_equal(I, Io) and np.array_equal(D, Do)
+    assert I[0, 0] == 7 and D[0, 0] == 0.0 and (k == 1 or I[0, 1] == 11)
+    assert scr.screen_stats(nq, k)[0] == 0  # no tile needed the exact fallback
+
+
+def test_l2_screen_with_many_exact_duplicates_of_the_query():
+    """More than k rows at distance exactly 0: the exact path returns the k lowest ids; so must the screen."""
+    from viquae_amd.index import MI355XFlatIndex
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((4000, 96), dtype=np.float32)
+    dup = rng.choice(4000, 300, replace=False)
+    X[dup] = X[dup[0]]
+    Q = np.stack([X[dup[0]], rng.standard_normal(96).astype(np.float32)])
+    a = MI355XFlatIndex(string_factory="Flat", metric_type=1, screen=True)
+    a.add_vectors(X)
+    b = MI355XFlatIndex(string_factory="Flat", metric_type=1, screen=False)
+    b.add_vectors(X)
+    D, I = a.search_batch(Q, 100)
+    D0, I0 = b.search_batch(Q, 100)
+    assert np.array_equal(I, I0) and np.array_equal(D, D0)
+    assert np.array_equal(I[0], np.sort(dup)[:100]) and np.all(D[0] == 0.0)
+
+
+def test_l2_margin_dominates_the_measured_screening_error():
+    """|S~' - (qn - d_f)/2| <= margin'/2 with S~' recomputed in float64 from the bf16 operands incl. the (h, l) columns."""
+    import torch
+    from viquae_amd.index import MI355XFlatIndex
+    g = torch.Generator(device="cuda").manual_seed(8)
+    n, d, nq, k = 5000, 200, 200, 10
+    X = torch.randn((n, d), generator=g, device="cuda") * torch.exp(0.3 * torch.randn((n, 1), generator=g, device="cuda"))
+    Q = torch.randn((nq, d), generator=g, device="cuda")
     idx = MI355XFlatIndex(string_factory="Flat", metric_type=1, screen=True)
-    assert idx.screen is False
+    idx.add(X)
+    idx.search_device(Q, k)
+    kernel_max_margin = idx.screen_stats(nq, k)[5] * 1e-6
+    xn = idx._sqnorm[:n].double()
+    v = -0.5 * idx._sqnorm[:n]
+    h = v.to(torch.bfloat16)
+    l = (v - h.float()).to(torch.bfloat16)
+    screen = Q.to(torch.bfloat16).double() @ X.to(torch.bfloat16).double().T + (h.double() + l.double())[None]
+    qn = (Q.double() ** 2).sum(1)
+    d_exact = (qn[:, None] + xn[None]) - 2 * (Q.double() @ X.double().T)
+    target = (qn[:, None] - d_exact) / 2
+    dev = (screen - target).abs().max().item()
+    assert kernel_max_margin >= 2 * dev, (kernel_max_margin, dev)
+    assert kernel_max_margin <= 40 * dev   # and it is not vacuous
 
 
 def test_nan_inf_rows_with_screen():

@@ -19,6 +19,7 @@ def case(seed):
     nq = pick([1, 100, 256, 300, 1024, 2500, 4096, 5000])
     k = pick([1, 10, 100, 128])
     regime = pick(["normal", "clustered", "dups", "scaled", "lowrank", "sorted", "l2norm"])
+    metric = pick([0, 0, 1])
     X = torch.randn((n, d), generator=g, device="cuda")
     Q = torch.randn((nq, d), generator=g, device="cuda")
     factory = "Flat"
@@ -41,7 +42,7 @@ def case(seed):
         X = X[torch.argsort(X @ Q[0])]
     elif regime == "l2norm":
         factory = "L2norm,Flat"
-    return X, Q, k, regime, factory
+    return X, Q, k, regime, factory, metric
 
 
 def main():
@@ -50,16 +51,16 @@ def main():
     bad = 0
     t0 = time.time()
     for seed in range(first, first + n_cases):
-        X, Q, k, regime, factory = case(seed)
-        a = MI355XFlatIndex(string_factory=factory, metric_type=0, screen=True)
+        X, Q, k, regime, factory, metric = case(seed)
+        a = MI355XFlatIndex(string_factory=factory, metric_type=metric, screen=True)
         a.add(X)
-        b = MI355XFlatIndex(string_factory=factory, metric_type=0, screen=False)
+        b = MI355XFlatIndex(string_factory=factory, metric_type=metric, screen=False)
         b.add(X)
         D, I = a.search_device(Q, k)
         D0, I0 = b.search_device(Q, k)
         ok = torch.equal(I, I0) and torch.equal(D, D0)
         st = a.screen_stats(Q.shape[0], k)
-        print(f"seed {seed:4d} {regime:9s} N={X.shape[0]:6d} d={X.shape[1]:3d} nq={Q.shape[0]:4d} k={k:3d} "
+        print(f"seed {seed:4d} {'L2' if metric else 'IP'} {regime:9s} N={X.shape[0]:6d} d={X.shape[1]:3d} nq={Q.shape[0]:4d} k={k:3d} "
               f"{'ok ' if ok else 'MISMATCH'} exact-recomputed tiles {st[0]} cand/query {st[1] / max(1, min(Q.shape[0], 4096)):.0f}", flush=True)
         bad += not ok
         del a, b

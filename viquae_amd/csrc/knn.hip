@@ -714,6 +714,9 @@ struct Geometry {
     int ms, sps;  // stripe-maxima slots per query / per slab
 };
 
+// bf16 row length of the screening copy: d (inner product) or d + 2 (L2: the (h, l) pair of -||x||^2 / 2), padded to 64
+int screen_dp(int d, int metric) { return (int)round_up(d + (metric == MQ_METRIC_L2 ? 2 : 0), SBK); }
+
 Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
     Geometry g;
     g.dpad = (int)round_up(d, BK);
@@ -749,7 +752,7 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
     g.off_qn = o;    o += (size_t)g.nqpad * 4;
     g.off_qtmp = o;  o += (size_t)round_up((int64_t)(nq > 0 ? nq : 1) * d * 4, 256);
     g.off_lists = o; o += (size_t)g.nqt * g.S * TQ * (size_t)SPOOL * 8;  // SPOOL >= POOL: shared by both paths
-    g.dp = (int)round_up(d, SBK);
+    g.dp = (int)round_up(d + 2, SBK);  // sized for the L2 screen (two extra columns); the search uses screen_dp()
     const size_t nq1 = (size_t)(nq > 0 ? nq : 1);
     g.off_qb = o;     o += (size_t)round_up((int64_t)g.nqpad * g.dp * 2, 256);
     g.off_margin = o; o += (size_t)g.nqpad * 4;
@@ -912,25 +915,27 @@ int mq_knn_search_f32_ev(const float* packed_dev, const float* sqnorm_dev, int64
 }
 
 /* ---- screened path (bf16 screening + exact re-scoring): see knn_screen.inc ---- */
-size_t mq_knn_screen_bytes(int64_t n_rows, int d) {
-    return (size_t)mq_padded_rows(n_rows) * (size_t)round_up(d, SBK) * 2;
+size_t mq_knn_screen_bytes(int64_t n_rows, int d, int metric) {
+    return (size_t)mq_padded_rows(n_rows) * (size_t)screen_dp(d, metric) * 2;
 }
 
-int mq_knn_screen_prepare(const float* packed_dev, int64_t capacity_rows, int d, int64_t row_offset, int64_t n,
-                          float* rowmajor_dev, uint16_t* bf16_dev, float* xstats_dev, void* stream) {
+int mq_knn_screen_prepare(const float* packed_dev, const float* sqnorm_dev, int64_t capacity_rows, int d, int metric,
+                          int64_t row_offset, int64_t n, float* rowmajor_dev, uint16_t* bf16_dev, float* xstats_dev,
+                          void* stream) {
     if (n == 0) return MQ_OK;
-    if (!packed_dev || !rowmajor_dev || !bf16_dev || !xstats_dev || n < 0 || d <= 0 || row_offset < 0 ||
+    if (!packed_dev || !sqnorm_dev || !rowmajor_dev || !bf16_dev || !xstats_dev || n < 0 || d <= 0 || row_offset < 0 ||
         row_offset + n > capacity_rows)
         return MQ_EINVAL;
+    if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int dpad = mq_padded_dim(d), dp = (int)round_up(d, SBK);
+    const int dpad = mq_padded_dim(d), dp = screen_dp(d, metric);
     float* rm = rowmajor_dev + (size_t)row_offset * d;
     const int64_t total = n * (int64_t)d;
     hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, packed_dev, d, dpad, row_offset, n, rm);
     MQ_HIP(hipGetLastError());
     const int64_t quads = n * (int64_t)(dp / 4);
     hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, rm, n, d, dp,
-                       (unsigned short*)bf16_dev + (size_t)row_offset * dp);
+                       (unsigned short*)bf16_dev + (size_t)row_offset * dp, metric == MQ_METRIC_L2 ? 1 : 0, sqnorm_dev + row_offset);
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(row_err_stats_kernel, dim3((unsigned)((n + 3) / 4 < 2048 ? (n + 3) / 4 : 2048)), dim3(256), 0, st, rm,
                        (const unsigned short*)bf16_dev + (size_t)row_offset * dp, n, d, dp, (unsigned*)xstats_dev);
@@ -940,9 +945,12 @@ int mq_knn_screen_prepare(const float* packed_dev, int64_t capacity_rows, int d,
 
 int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev, const float* rowmajor_dev,
                                const uint16_t* bf16_dev, const float* xstats_dev, int64_t N, int d, const float* queries_dev,
-                               int nq, int k, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev, void* ws_dev,
-                               size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
+                               int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev,
+                               void* ws_dev, size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
     if (nq == 0) return MQ_OK;
+    if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
+    const int l2 = metric == MQ_METRIC_L2;
+    const int dp = screen_dp(d, metric);
     if (!packed_dev || !sqnorm_dev || !rowmajor_dev || !bf16_dev || !xstats_dev || !queries_dev || !D_dev || !I_dev || !ws_dev)
         return MQ_EINVAL;
     if (N <= 0 || d <= 0 || nq < 0 || k <= 0) return MQ_EINVAL;
@@ -974,18 +982,19 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         q_rm = qtmp;
     }
     MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
-    MQ_HIP(hipMemsetAsync(Qb, 0, (size_t)g.nqpad * g.dp * 2, st));
+    MQ_HIP(hipMemsetAsync(Qb, 0, (size_t)g.nqpad * dp * 2, st));
     MQ_HIP(hipMemsetAsync(ovf, 0, (size_t)round_up((int64_t)g.nqt * 4, 256) + (size_t)g.nqpad * 4, st));  // ovf + gthr
     MQ_HIP(hipMemsetAsync(ws + g.off_smax, 0, (size_t)g.nqpad * g.ms * 4, st));
     hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((nq + PANEL - 1) / PANEL)), dim3(256), 0, st, q_rm, (int64_t)nq, d,
                        g.dpad, (int64_t)0, 0, Qp, qn);
     MQ_HIP(hipGetLastError());
     {
-        const int64_t quads = (int64_t)nq * (g.dp / 4);
-        hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, q_rm, (int64_t)nq, d, g.dp, Qb);
+        const int64_t quads = (int64_t)nq * (dp / 4);
+        hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, q_rm, (int64_t)nq, d, dp, Qb,
+                           l2 ? 2 : 0, (const float*)nullptr);
         MQ_HIP(hipGetLastError());
         hipLaunchKernelGGL(screen_margin_kernel, dim3((unsigned)((g.nqpad + 3) / 4)), dim3(256), 0, st, q_rm, Qb, xstats_dev, nq,
-                           (int)g.nqpad, d, g.dp, margin);
+                           (int)g.nqpad, d, dp, margin, l2);
         MQ_HIP(hipGetLastError());
     }
     // 1. bf16 screening scan
@@ -994,7 +1003,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         a.Xb = bf16_dev; a.Qb = Qb; a.margin = margin; a.pools = pools; a.pcount = pcount; a.ovf = ovf; a.gthr = (unsigned*)(ws + g.off_gthr);
         a.smax = (unsigned*)(ws + g.off_smax); a.ms = g.ms; a.sps = g.sps;
         a.dbg = getenv("MQ_DBG_PTR") ? (unsigned long long*)strtoull(getenv("MQ_DBG_PTR"), nullptr, 0) : nullptr;
-        a.N = N; a.dp = g.dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx; a.nchunks = g.nchunks;
+        a.N = N; a.dp = dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx; a.nchunks = g.nchunks;
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
         MQ_HIP(hipFuncSetAttribute((const void*)screen_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_TOTAL));
         hipLaunchKernelGGL(screen_scan_kernel, dim3((unsigned)(g.nqt * g.S)), dim3(1024), S_LDS_TOTAL, st, a);
@@ -1005,10 +1014,11 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     hipLaunchKernelGGL(cand_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin,
                        (const unsigned*)(ws + g.off_gthr), (const unsigned*)(ws + g.off_smax), g.ms, ovf, nq, g.S, k, cand, ccount);
     MQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq, RMAX / 64), dim3(256), 0, st, rowmajor_dev, q_rm, d, cand, ccount, ckeys);
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq, RMAX / 64), dim3(256), 0, st, rowmajor_dev, q_rm, d, cand, ccount, ckeys,
+                       l2 ? (const float*)qn : (const float*)nullptr, sqnorm_dev);
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(final_select_kernel, dim3((unsigned)nq), dim3(64), 0, st, ckeys, ccount, ovf, k, (long long)id_offset, D_dev,
-                       (long long*)I_dev);
+                       (long long*)I_dev, l2);
     MQ_HIP(hipGetLastError());
     // 5. query tiles whose bounded buffers overflowed are recomputed by the exact scan (no-op otherwise:
     //    every workgroup of an unflagged tile returns at once)
@@ -1016,11 +1026,19 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         ScanArgs a;
         a.Xp = packed_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = pools;
         a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = nullptr; a.only = ovf;
-        MQ_HIP(hipFuncSetAttribute((const void*)knn_scan_kernel<MQ_METRIC_IP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-        hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_IP>, dim3((unsigned)(g.nqt * g.S)), dim3(1024), LDS_TOTAL, st, a);
-        MQ_HIP(hipGetLastError());
-        hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, st, pools, nq, g.S, k,
-                           (long long)id_offset, D_dev, (long long*)I_dev, (const int*)ovf);
+        if (l2) {
+            MQ_HIP(hipFuncSetAttribute((const void*)knn_scan_kernel<MQ_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+            hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_L2>, dim3((unsigned)(g.nqt * g.S)), dim3(1024), LDS_TOTAL, st, a);
+            MQ_HIP(hipGetLastError());
+            hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(128), 0, st, pools, nq, g.S, k,
+                               (long long)id_offset, D_dev, (long long*)I_dev, (const int*)ovf);
+        } else {
+            MQ_HIP(hipFuncSetAttribute((const void*)knn_scan_kernel<MQ_METRIC_IP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+            hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_IP>, dim3((unsigned)(g.nqt * g.S)), dim3(1024), LDS_TOTAL, st, a);
+            MQ_HIP(hipGetLastError());
+            hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, st, pools, nq, g.S, k,
+                               (long long)id_offset, D_dev, (long long*)I_dev, (const int*)ovf);
+        }
         MQ_HIP(hipGetLastError());
     }
     return MQ_OK;

@@ -115,7 +115,7 @@ class MI355XFlatIndex(BaseIndex):
         # indexes only; costs 1.5x the shard's HBM footprint.  MQ_KNN_SCREEN=0/1 overrides the default.
         if screen is None:
             screen = os.environ.get("MQ_KNN_SCREEN", "1") != "0"
-        self.screen = bool(screen) and self.metric_type == METRIC_INNER_PRODUCT
+        self.screen = bool(screen)  # both metrics: the L2 screen ranks by q.x - ||x||^2/2 (two extra bf16 columns)
         self._rowmajor = None  # torch.float32 [capacity, d] (screened path only)
         self._bf16 = None      # torch.uint8 bf16 copy
         self._xmax2 = None     # torch.float32 [2]: max ||x||^2, max ||x - bf16(x)||^2 (kept by mq_knn_screen_prepare)
@@ -143,7 +143,7 @@ class MI355XFlatIndex(BaseIndex):
             new_sqnorm[: self._sqnorm.numel()].copy_(self._sqnorm)
         if self.screen:
             new_rm = torch.empty((cap, self.d), dtype=torch.float32, device=self._torch_device)
-            new_bf = torch.zeros(int(lib.mq_knn_screen_bytes(cap, self.d)), dtype=torch.uint8, device=self._torch_device)
+            new_bf = torch.zeros(int(lib.mq_knn_screen_bytes(cap, self.d, self.metric_type)), dtype=torch.uint8, device=self._torch_device)
             if self._rowmajor is not None and self.ntotal > 0:
                 new_rm[: self.ntotal].copy_(self._rowmajor[: self.ntotal])
                 new_bf[: self._bf16.numel()].copy_(self._bf16)
@@ -187,9 +187,9 @@ class MI355XFlatIndex(BaseIndex):
                 if self.screen:
                     if self._xmax2 is None:
                         self._xmax2 = torch.zeros(2, dtype=torch.float32, device=self._torch_device)
-                    _lib.check(lib.mq_knn_screen_prepare(self._packed.data_ptr(), self._capacity, self.d, self.ntotal,
-                                                         dev.shape[0], self._rowmajor.data_ptr(), self._bf16.data_ptr(),
-                                                         self._xmax2.data_ptr(), stream),
+                    _lib.check(lib.mq_knn_screen_prepare(self._packed.data_ptr(), self._sqnorm.data_ptr(), self._capacity, self.d,
+                                                         self.metric_type, self.ntotal, dev.shape[0], self._rowmajor.data_ptr(),
+                                                         self._bf16.data_ptr(), self._xmax2.data_ptr(), stream),
                                "mq_knn_screen_prepare")
                 self.ntotal += dev.shape[0]
                 # `dev` must outlive the kernel: synchronise before it is released
@@ -263,7 +263,8 @@ class MI355XFlatIndex(BaseIndex):
                 if self.screen:
                     _lib.check(lib.mq_knn_search_screened_f32(
                         self._packed.data_ptr(), self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(),
-                        self._xmax2.data_ptr(), self.ntotal, self.d, q.data_ptr(), q.shape[0], k, int(self.do_l2norm),
+                        self._xmax2.data_ptr(), self.ntotal, self.d, q.data_ptr(), q.shape[0], k, self.metric_type,
+                        int(self.do_l2norm),
                         self.id_offset, Dq.data_ptr(), Iq.data_ptr(), ws.data_ptr(), ws.numel(), stream, None, None),
                         "mq_knn_search_screened_f32")
                 else:
