@@ -212,6 +212,11 @@ int mq_attention_split_f32(const float *qkv_dev, const int64_t *attention_mask_d
                            uint16_t *out_l_dev, int B, int L, int heads, int head_dim, float scale, int causal, int bf16x3,
                            void *stream);
 
+/* Multimodal encoders of the reference (meerqat/models/mm.py: ECAEncoder :557-754, IntermediateLinearFusion :773-861) reuse
+ * the entry points above; the only extra arithmetic is the sum of an example's face embeddings into its text vector
+ * (mm.py:838-843): out[g, :] = init[g, :] + sum_j x[g, j, :], x [G, n, H], init (may be NULL) and out [G, H]. */
+int mq_sum_groups_f32(const float *x_dev, const float *init_dev, float *out_dev, int G, int n, int H, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Late fusion of several runs on the device: replaces, for integer document
  * ids, `default_minimum` (meerqat/ir/fuse.py:129-146), `gzmuv_norm` (:86-126) and ranx's

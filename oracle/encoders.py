@@ -191,9 +191,24 @@ def bert_forward(state, cfg, input_ids, token_type_ids=None, attention_mask=None
     B, L = ids.shape
     tt = np.zeros_like(ids) if token_type_ids is None else np.asarray(token_type_ids)
     eps, heads = cfg["layer_norm_eps"], cfg["num_attention_heads"]
+    h = bert_embeddings(state, cfg, ids, tt, prefix)
+    out, hidden = bert_layers(state, cfg, h, attention_mask, prefix)
+    return (out, hidden) if return_hidden else out
+
+
+def bert_embeddings(state, cfg, ids, tt, prefix):
+    """BertEmbeddings: word + token type + position, LayerNorm (meerqat/models/bert.py)."""
+    g = lambda n: state[prefix + n]  # noqa: E731
+    L = ids.shape[1]
     h = g("embeddings.word_embeddings.weight")[ids] + g("embeddings.token_type_embeddings.weight")[tt] \
         + g("embeddings.position_embeddings.weight")[np.arange(L)][None]
-    h = layer_norm(h, g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"), eps)
+    return layer_norm(h, g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"), cfg["layer_norm_eps"])
+
+
+def bert_layers(state, cfg, h, attention_mask, prefix):
+    """BertEncoder over embeddings h [B, L, H] with a 0/1 padding mask -> (h[:, 0], hidden states)."""
+    g = lambda n: state[prefix + n]  # noqa: E731
+    eps, heads = cfg["layer_norm_eps"], cfg["num_attention_heads"]
     add_mask = None
     if attention_mask is not None:
         m = np.asarray(attention_mask).astype(F32)
@@ -211,8 +226,117 @@ def bert_forward(state, cfg, input_ids, token_type_ids=None, attention_mask=None
         o = linear(f, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
         h = layer_norm(o + h, g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"), eps)
         hidden.append(h)
-    out = h[:, 0, :].astype(F32)
+    return h[:, 0, :].astype(F32), hidden
+
+
+# ----------------------------------------------------------------------------------------------
+# multimodal encoders of the reference (meerqat/models/mm.py): ECAEncoder (:557-754), IntermediateLinearFusion (:773-861)
+# ----------------------------------------------------------------------------------------------
+MM_TINY = dict(BERT_TINY, n_images=1, n_faces=4, face_kwargs=dict(face_dim=64, bbox_dim=7),
+               image_kwargs={"clip-RN50": {"input_dim": 96}, "imagenet-RN50": {"input_dim": 160}},
+               face_and_image_are_exclusive=False, no_text=False, gating=False)
+
+
+def mm_embedding_param_shapes(cfg, image_layer_norm=False):
+    H = cfg["hidden_size"]
+    s = {}
+    if cfg["n_faces"] > 0:
+        s.update({"face_embedding.face_proj.weight": (H, cfg["face_kwargs"]["face_dim"]), "face_embedding.face_proj.bias": (H,),
+                  "face_embedding.bbox_proj.weight": (H, cfg["face_kwargs"]["bbox_dim"]), "face_embedding.bbox_proj.bias": (H,),
+                  "face_embedding.LayerNorm.weight": (H,), "face_embedding.LayerNorm.bias": (H,)})
+    for name, kw in cfg["image_kwargs"].items():
+        s[f"image_embeddings.{name}.linear.weight"] = (H, kw["input_dim"])
+        s[f"image_embeddings.{name}.linear.bias"] = (H,)
+    return s
+
+
+def eca_param_shapes(cfg):
+    s = bert_param_shapes(cfg, prefix="bert_model.")
+    s.update(mm_embedding_param_shapes(cfg))
+    if cfg.get("gating"):
+        if cfg["n_faces"] > 0:
+            s["face_gate.gate_param"] = (1,)
+        for name in cfg["image_kwargs"]:
+            s[f"image_gates.{name}.gate_param"] = (1,)
+    return s
+
+
+def ilf_param_shapes(cfg, question_encoder=True):
+    s = bert_param_shapes(cfg, prefix="dpr_encoder.question_encoder.bert_model." if question_encoder
+                          else "dpr_encoder.ctx_encoder.bert_model.")
+    s.update(mm_embedding_param_shapes(cfg))
+    H = cfg["hidden_size"]
+    s.update({"dpr_proj.weight": (H, H), "dpr_proj.bias": (H,), "LayerNorm.weight": (H,), "LayerNorm.bias": (H,)})
+    return s
+
+
+def face_embedding(state, cfg, face, bbox):
+    """FaceEmbedding.forward (meerqat/models/image.py:5-19), one image per example: LN(face_proj(face) + bbox_proj(bbox))."""
+    e = linear(face, state["face_embedding.face_proj.weight"], state["face_embedding.face_proj.bias"]) \
+        + linear(bbox, state["face_embedding.bbox_proj.weight"], state["face_embedding.bbox_proj.bias"])
+    return layer_norm(e, state["face_embedding.LayerNorm.weight"], state["face_embedding.LayerNorm.bias"], cfg["layer_norm_eps"])
+
+
+def eca_forward(state, cfg, input_ids, token_type_ids, attention_mask, face, bbox, face_mask, images, return_hidden=False):
+    """ECAEncoder.forward with n_images == 1: [text | faces | images] at the sequence level, BERT encoder, [CLS].
+    face [B, 1, n_faces, face_dim], bbox [B, 1, n_faces, bbox_dim], face_mask [B, 1, n_faces],
+    images {name: (input [B, 1, dim], mask [B, 1])} in the order of cfg['image_kwargs']."""
+    assert cfg["n_images"] == 1
+    ids = np.asarray(input_ids)
+    mask = np.asarray(attention_mask)
+    tt = np.zeros_like(ids) if token_type_ids is None else np.asarray(token_type_ids)
+    B = ids.shape[0]
+    H = cfg["hidden_size"]
+    nf = cfg["n_faces"]
+    if nf > 0:
+        fo = face_embedding(state, cfg, np.asarray(face, F32).reshape(B * nf, -1), np.asarray(bbox, F32).reshape(B * nf, -1))
+        fo = fo.reshape(B, nf, H)
+        if cfg.get("gating"):
+            fo = (fo * np.tanh(state["face_gate.gate_param"])).astype(F32)
+    else:
+        fo = np.zeros((B, 0, H), F32)
+    fmask = np.asarray(face_mask).reshape(B, nf)
+    outs, imasks = [], []
+    for name in cfg["image_kwargs"]:
+        x, m = images[name]
+        io = linear(np.asarray(x, F32).reshape(B, -1), state[f"image_embeddings.{name}.linear.weight"],
+                    state[f"image_embeddings.{name}.linear.bias"])
+        if cfg.get("gating"):
+            io = (io * np.tanh(state[f"image_gates.{name}.gate_param"])).astype(F32)
+        outs.append(io.reshape(B, 1, H))
+        imasks.append(np.asarray(m).reshape(B, 1))
+    io = np.concatenate(outs, axis=1) if outs else np.zeros((B, 0, H), F32)
+    imask = np.concatenate(imasks, axis=1) if imasks else np.zeros((B, 0), np.int64)
+    if cfg.get("face_and_image_are_exclusive"):
+        imask = imask.copy()
+        imask[fmask.any(axis=1)] = 0
+    if cfg.get("no_text"):
+        ids, mask, tt = ids[:, :1], mask[:, :1], tt[:, :1]
+    te = bert_embeddings(state, cfg, ids, tt, "bert_model.")
+    h = np.concatenate([te, fo, io], axis=1).astype(F32)
+    full_mask = np.concatenate([mask, fmask, imask], axis=1)
+    out, hidden = bert_layers(state, cfg, h, full_mask, "bert_model.")
     return (out, hidden) if return_hidden else out
+
+
+def ilf_forward(state, cfg, input_ids, token_type_ids, attention_mask, face, bbox, face_mask, images, question_encoder=True):
+    """IntermediateLinearFusion.forward: LN(dpr_proj(DPR [CLS]) + sum of face embeddings + image projections)."""
+    prefix = "dpr_encoder.question_encoder.bert_model." if question_encoder else "dpr_encoder.ctx_encoder.bert_model."
+    out = bert_forward(state, cfg, input_ids, token_type_ids, attention_mask, prefix=prefix)
+    out = linear(out, state["dpr_proj.weight"], state["dpr_proj.bias"])
+    B = out.shape[0]
+    nf = cfg["n_faces"]
+    fmask = np.asarray(face_mask).reshape(B, nf)
+    if nf > 0:
+        fo = face_embedding(state, cfg, np.asarray(face, F32).reshape(B * nf, -1), np.asarray(bbox, F32).reshape(B * nf, -1))
+        out = (out + fo.reshape(B, nf, -1).sum(axis=1, dtype=F32)).astype(F32)
+    for name in cfg["image_kwargs"]:
+        x, _ = images[name]
+        x = np.asarray(x, F32).reshape(B, -1).copy()
+        if cfg.get("face_and_image_are_exclusive"):
+            x[fmask.any(axis=1)] = 0
+        out = (out + linear(x, state[f"image_embeddings.{name}.linear.weight"], state[f"image_embeddings.{name}.linear.bias"])).astype(F32)
+    return layer_norm(out, state["LayerNorm.weight"], state["LayerNorm.bias"], cfg["layer_norm_eps"])
 
 
 def clip_vision_forward(state, cfg, pixel_values, return_hidden=False):

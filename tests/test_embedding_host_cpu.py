@@ -167,3 +167,52 @@ def test_clip_text_oracle_matches_hf_goldens(name, eos):
             ids2[b, n:] = 5
         out2 = oe.clip_text_forward(state, cfg, ids2, None)
         assert np.abs(out2 - out).max() < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# multimodal encoders: oracle vs the reference's own ECAEncoder / IntermediateLinearFusion
+# ---------------------------------------------------------------------------------------------------
+MM_CASES = [("eca", {}), ("eca_gated_exclusive", {"gating": True, "face_and_image_are_exclusive": True}),
+            ("eca_no_text", {"no_text": True}), ("ilf", {"face_and_image_are_exclusive": True})]
+
+
+def _mm_case(tag, extra):
+    from oracle import encoders as oe
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"mm_{tag}.npz"))
+    cfg = dict(oe.MM_TINY, **extra)
+    images = {n: (z[f"image_{n}"], np.ones((len(z["input_ids"]), 1), np.int64)) for n in cfg["image_kwargs"]}
+    if tag == "ilf":
+        state = oe.seeded_state(oe.ilf_param_shapes(cfg, True), int(z["seed"]))
+    else:
+        state = oe.seeded_state(oe.eca_param_shapes(cfg), int(z["seed"]))
+        for k in state:  # the gate values the golden was minted with (tools/make_golden_mm.py)
+            if k.endswith("gate_param"):
+                state[k] = np.asarray([0.7 if "face" in k else -0.4 if "clip" in k else 1.3], np.float32)
+    return z, cfg, state, images
+
+
+@pytest.mark.parametrize("tag,extra", MM_CASES)
+def test_mm_oracle_matches_reference_goldens(tag, extra):
+    from oracle import encoders as oe
+    z, cfg, state, images = _mm_case(tag, extra)
+    tt = z["token_type_ids"] if "token_type_ids" in z.files else None
+    fn = oe.ilf_forward if tag == "ilf" else oe.eca_forward
+    out = fn(state, cfg, z["input_ids"], tt, z["attention_mask"], z["face"], z["bbox"], z["face_mask"], images)
+    assert out.shape == z["pooler_output"].shape
+    assert np.abs(out - z["pooler_output"]).max() < 2e-5
+
+
+def test_multimodal_input_builders_match_the_reference_shapes():
+    """get_face_inputs / get_image_inputs (meerqat/ir/embedding.py:29-107): trimming, padding, None = no face."""
+    from viquae_amd.ir import embedding as IE
+    batch = {"face_embedding": [None, [[1.0, 2.0, 3.0]], [[float(i)] * 3 for i in range(6)]],
+             "face_box": [None, [[0.1] * 7], [[0.2] * 7 for _ in range(6)]],
+             "clip-RN50": [[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]]}
+    f = IE.get_face_inputs(batch, n_faces=4, face_dim=3, bbox_dim=7)
+    assert f["face"].shape == (3, 1, 4, 3) and f["bbox"].shape == (3, 1, 4, 7) and f["attention_mask"].shape == (3, 1, 4)
+    assert f["attention_mask"].reshape(3, 4).tolist() == [[0, 0, 0, 0], [1, 0, 0, 0], [1, 1, 1, 1]]
+    assert f["face"][2, 0, 3].tolist() == [3.0, 3.0, 3.0] and f["face"][1, 0, 1].abs().sum() == 0
+    im = IE.get_image_inputs(batch, {"clip-RN50": {"input_dim": 2}})
+    assert im["clip-RN50"]["input"].shape == (3, 1, 2) and im["clip-RN50"]["attention_mask"].tolist() == [[1], [1], [1]]
+    zero = IE.get_face_inputs(batch, n_faces=0, face_dim=3, bbox_dim=7)
+    assert zero["face"].shape == (3, 1, 0, 3)

@@ -356,3 +356,51 @@ def test_split_and_fp32_activation_paths_agree_end_to_end(monkeypatch):
     assert torch.equal(a["pooler_output"], b["pooler_output"])
     for x, y in zip(a["hidden_states"], b["hidden_states"]):
         assert torch.equal(x, y)
+
+
+# ---------------------------------------------------------------------------------------------------
+# multimodal encoders: HIP ECAEncoder / IntermediateLinearFusion vs the reference's own classes
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,extra", [("eca", {}), ("eca_gated_exclusive", {"gating": True, "face_and_image_are_exclusive": True}),
+                                       ("eca_no_text", {"no_text": True}), ("ilf", {"face_and_image_are_exclusive": True})])
+def test_multimodal_encoders_match_reference_goldens(tag, extra):
+    from tests.test_embedding_host_cpu import _mm_case
+    from viquae_amd import encoders as E
+    z, cfg, state, images = _mm_case(tag, extra)
+    Model = E.IntermediateLinearFusion if tag == "ilf" else E.ECAEncoder
+    model = Model.from_state_dict(dict(cfg, question_encoder=True), state).to("cuda").eval()
+    text = {"input_ids": _cuda(z["input_ids"]), "attention_mask": _cuda(z["attention_mask"])}
+    if "token_type_ids" in z.files:
+        text["token_type_ids"] = _cuda(z["token_type_ids"])
+    face = {"face": _cuda(z["face"]), "bbox": _cuda(z["bbox"]), "attention_mask": _cuda(z["face_mask"])}
+    imgs = {n: {"input": _cuda(images[n][0]), "attention_mask": _cuda(images[n][1])} for n in images}
+    out = model(text_inputs=text, face_inputs=face, image_inputs=imgs)
+    got = out["pooler_output"].cpu().numpy()
+    assert got.shape == z["pooler_output"].shape
+    assert np.abs(got - z["pooler_output"]).max() < TOL
+    assert type(model.config).__name__ == "MMConfig"  # what the embed mirror's is_multimodal() looks at
+
+
+def test_multimodal_through_the_embed_mirror():
+    """embed() with an ECAEncoder: text tokenised, face / image features read from the batch (ir/embedding.py:181-192)."""
+    from tests.test_embedding_host_cpu import _mm_case
+    from viquae_amd import encoders as E
+    from viquae_amd.ir import embedding as IE
+    z, cfg, state, images = _mm_case("eca", {})
+    model = E.ECAEncoder.from_state_dict(cfg, state).to("cuda").eval()
+    B = len(z["input_ids"])
+    faces, boxes = [], []
+    for b in range(B):
+        n = int(z["face_mask"][b].sum())
+        faces.append(None if n == 0 else z["face"][b, 0, :n].tolist())
+        boxes.append(None if n == 0 else z["bbox"][b, 0, :n].tolist())
+    batch = {"input": ["x"] * B, "face_embedding": faces, "face_box": boxes}
+    for n in images:
+        batch[n] = images[n][0][:, 0].tolist()
+
+    class Tok:
+        def __call__(self, texts, **kw):
+            return {"input_ids": torch.from_numpy(z["input_ids"]), "token_type_ids": torch.from_numpy(z["token_type_ids"]),
+                    "attention_mask": torch.from_numpy(z["attention_mask"])}
+    out = IE.embed(batch, model, Tok(), key="input", save_as="emb", output_key="pooler_output")
+    assert np.abs(np.asarray(out["emb"]) - z["pooler_output"]).max() < TOL

@@ -57,6 +57,7 @@ SIGNATURES = {
                                            c_int, ctypes.c_float, c_ptr]),
     "mq_attention_split_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, ctypes.c_float, c_int,
                                        c_int, c_ptr]),
+    "mq_sum_groups_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
     "mq_topk_merge_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "mq_fuse_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "mq_fuse_wsum_f64": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_sz,

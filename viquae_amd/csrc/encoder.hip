@@ -898,6 +898,18 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
     }
 }
 
+// out[g] = init[g] + x[g][0] + x[g][1] + ... (IntermediateLinearFusion: the face embeddings of one example are summed
+// into the projected text vector, meerqat/models/mm.py:838-843)
+__global__ __launch_bounds__(256) void sum_groups_kernel(const float* __restrict__ x, const float* __restrict__ init,
+                                                         float* __restrict__ out, int G, int n, int H) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)G * H) return;
+    const size_t g = e / H, c = e % H;
+    float acc = init ? init[e] : 0.f;
+    for (int j = 0; j < n; ++j) acc += x[(g * n + j) * H + c];
+    out[e] = acc;
+}
+
 // CLIP text tower input: token embedding + position embedding (no LayerNorm, no token types)
 __global__ __launch_bounds__(256) void clip_text_embed_kernel(const long long* __restrict__ ids, const float* __restrict__ tok,
                                                               const float* __restrict__ pos, float* __restrict__ out, int M,
@@ -1138,6 +1150,16 @@ int mq_attention_split_f32(const float* qkv_dev, const int64_t* attention_mask_d
     }
 #undef MQ_ATT
 #undef MQ_ATT3
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_sum_groups_f32(const float* x_dev, const float* init_dev, float* out_dev, int G, int n, int H, void* stream) {
+    if (G == 0 || H == 0) return MQ_OK;
+    if (!x_dev || !out_dev || G < 0 || n < 0 || H < 0) return MQ_EINVAL;
+    const size_t total = (size_t)G * H;
+    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_dev, init_dev,
+                       out_dev, G, n, H);
     ENC_HIP(hipGetLastError());
     return MQ_OK;
 }

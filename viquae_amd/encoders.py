@@ -282,7 +282,7 @@ class BertEncoderHIP(_HipEncoder):
         tt = token_type_ids.to(torch.int64).contiguous() if token_type_ids is not None else None
         mask = attention_mask.to(torch.int64).contiguous() if attention_mask is not None else None
         H = self.hidden
-        split = _use_split(H, self.l0_wi.shape[0])  # activations that only feed GEMMs travel as (hi, lo) bf16 pairs
+        split = self.uses_split()  # activations that only feed GEMMs travel as (hi, lo) bf16 pairs
         h = torch.empty((B * L, H), dtype=torch.float32, device=dev)
         hs = SplitAct.empty(B * L, H, dev) if split else None
         with torch.cuda.device(dev):
@@ -291,6 +291,19 @@ class BertEncoderHIP(_HipEncoder):
                 self.w_type.data_ptr(), self.emb_g.data_ptr(), self.emb_b.data_ptr(), h.data_ptr(),
                 hs.hi.data_ptr() if split else None, hs.lo.data_ptr() if split else None, B, L, H, self.eps, _stream(h)),
                 "mq_bert_embed_ln_split_f32")
+        return self._layers(h, hs, mask, B, L, output_hidden_states, cls_only)
+
+    def uses_split(self):
+        return _use_split(self.hidden, self.l0_wi.shape[0])
+
+    @torch.no_grad()
+    def _layers(self, h, hs, mask, B, L, output_hidden_states=False, cls_only=False):
+        """The encoder stack over embeddings h [B*L, H] (hs = their split pair in split mode, or None to make it here)
+        with an int64 0/1 mask [B, L] -> (last hidden [B, L or 1, H], hidden states or None)."""
+        H = self.hidden
+        split = self.uses_split()
+        if split and hs is None:
+            hs = SplitAct(*split_bf16(h))
         hidden = [h.view(B, L, H)] if output_hidden_states else None
         scale = 1.0 / math.sqrt(H // self.heads)
         for i in range(self.layers):
@@ -560,4 +573,202 @@ class CLIPModel(_HipEncoder):
         return gemm_nt(pooled, self.wproj, None, None, EPI_NONE, wsplit=self._ws("wproj"))
 
 
-HIP_CLASSES = {"DPRContextEncoder": DPRContextEncoder, "DPRQuestionEncoder": DPRQuestionEncoder, "CLIPModel": CLIPModel}
+
+# --------------------------------------------------------------------------------------------------
+# multimodal encoders (meerqat/models/mm.py): ECAEncoder (:557-754), IntermediateLinearFusion (:773-861)
+# --------------------------------------------------------------------------------------------------
+class MMConfig:
+    """The fields of the reference's MMConfig / ILFConfig (meerqat/models/mm.py:20-87,757-770) this build reads;
+    ``meerqat.ir.embedding.is_multimodal`` (:147-152) recognises the model by this class name."""
+
+    def __init__(self, config):
+        c = dict(config)
+        self.raw = c
+        self.hidden_size = int(c["hidden_size"])
+        self.layer_norm_eps = float(c.get("layer_norm_eps", 1e-12))
+        self.n_images = int(c.get("n_images", 1))
+        self.n_faces = int(c.get("n_faces", 4))
+        self.face_kwargs = dict(c.get("face_kwargs") or dict(face_dim=512, bbox_dim=7))
+        self.image_kwargs = dict(c.get("image_kwargs") or {"clip-RN50": {"input_dim": 1024}, "imagenet-RN50": {"input_dim": 2048}})
+        self.face_and_image_are_exclusive = bool(c.get("face_and_image_are_exclusive", False))
+        self.no_text = bool(c.get("no_text", False))
+        self.gating = bool(c.get("gating", False))
+        self.question_encoder = bool(c.get("question_encoder", True))
+        if self.n_images != 1:
+            raise NotImplementedError("n_images > 1 (image type embeddings) is outside this build; the shipped configs use 1")
+
+
+def _pad_k(x, multiple=32):
+    """zero-pad the feature dimension of a [rows, K] matrix to a multiple of the GEMM's K step"""
+    K = x.shape[1]
+    Kp = -(-K // multiple) * multiple
+    if Kp == K:
+        return x.contiguous()
+    out = torch.zeros((x.shape[0], Kp), dtype=torch.float32, device=x.device)
+    out[:, :K] = x
+    return out
+
+
+class _MMEmbeddings(_HipEncoder):
+    """FaceEmbedding / ImageEmbedding of meerqat/models/image.py as GEMMs with fused bias / residual epilogues.
+    A tanh gate (mm.py:610-629, meerqat/models/utils.py:11-27) multiplies a module's output by the scalar
+    tanh(gate_param): it is folded into the LayerNorm's (faces) or the linear layer's (images) parameters at load time."""
+
+    def _init_mm(self, mmc, state, gated):
+        self.mm = mmc
+        self.config = mmc  # what is_multimodal() and get_inputs() look at
+        H = mmc.hidden_size
+        if mmc.n_faces > 0:
+            g = math.tanh(float(_t(state["face_gate.gate_param"]).reshape(-1)[0])) if gated else 1.0
+            self._reg("f_w", _pad_k(_t(state["face_embedding.face_proj.weight"])))
+            self._reg("f_b", state["face_embedding.face_proj.bias"])
+            self._reg("b_w", _pad_k(_t(state["face_embedding.bbox_proj.weight"])))
+            self._reg("b_b", state["face_embedding.bbox_proj.bias"])
+            self._reg("f_g", _t(state["face_embedding.LayerNorm.weight"]) * g)
+            self._reg("f_beta", _t(state["face_embedding.LayerNorm.bias"]) * g)
+        self.image_names = list(mmc.image_kwargs)
+        for n, name in enumerate(self.image_names):
+            g = math.tanh(float(_t(state[f"image_gates.{name}.gate_param"]).reshape(-1)[0])) if gated else 1.0
+            self._reg(f"i{n}_w", _pad_k(_t(state[f"image_embeddings.{name}.linear.weight"]) * g))
+            self._reg(f"i{n}_b", _t(state[f"image_embeddings.{name}.linear.bias"]) * g)
+        assert H % 2 == 0
+
+    def _faces(self, face_inputs, B):
+        """-> (face embeddings fp32 [B * n_faces, H] or None, face mask int64 [B, n_faces])"""
+        nf = self.mm.n_faces
+        fmask = face_inputs["attention_mask"].reshape(B, -1).to(torch.int64)
+        if nf == 0:
+            return None, fmask
+        face = _pad_k(face_inputs["face"].to(torch.float32).reshape(B * nf, -1))
+        bbox = _pad_k(face_inputs["bbox"].to(torch.float32).reshape(B * nf, -1))
+        e = gemm_nt(face, self.f_w, self.f_b, None, EPI_BIAS, wsplit=self._ws("f_w"))
+        e = gemm_nt(bbox, self.b_w, self.b_b, e, EPI_BIAS_RESIDUAL, out=e, wsplit=self._ws("b_w"))
+        return layernorm(e, self.f_g, self.f_beta, self.mm.layer_norm_eps, out=e), fmask
+
+    def _image(self, n, x, residual=None):
+        x = _pad_k(x.to(torch.float32))
+        if residual is None:
+            return gemm_nt(x, getattr(self, f"i{n}_w"), getattr(self, f"i{n}_b"), None, EPI_BIAS, wsplit=self._ws(f"i{n}_w"))
+        return gemm_nt(x, getattr(self, f"i{n}_w"), getattr(self, f"i{n}_b"), residual, EPI_BIAS_RESIDUAL, out=residual,
+                       wsplit=self._ws(f"i{n}_w"))
+
+
+class ECAEncoder(_MMEmbeddings):
+    """meerqat.models.mm.ECAEncoder: text, face and image tokens concatenated at the sequence level, BERT encoder,
+    [CLS] vector.  Call surface of the reference: ``model(text_inputs=..., face_inputs=..., image_inputs=...)``."""
+    config_class = dict
+
+    def __init__(self, config, state):
+        super().__init__()
+        mmc = MMConfig(config)
+        self.bert_model = BertEncoderHIP(config, state, "bert_model.")
+        self._init_mm(mmc, state, mmc.gating)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, **kwargs):
+        config, state = read_checkpoint(pretrained_model_name_or_path)
+        return cls(config, state)
+
+    @classmethod
+    def from_state_dict(cls, config, state):
+        return cls(config, state)
+
+    @torch.no_grad()
+    def forward(self, text_inputs=None, face_inputs=None, image_inputs=None, output_attentions=False,
+                output_hidden_states=False, return_dict=True, **unused):
+        if output_attentions:
+            raise NotImplementedError("attention maps are not materialised by the fused attention kernel")
+        bert, mmc = self.bert_model, self.mm
+        ids = text_inputs["input_ids"]
+        _check_cuda(ids, bert.w_word)
+        lib = _lib.load()
+        mask = text_inputs["attention_mask"].to(torch.int64)
+        tt = text_inputs.get("token_type_ids")
+        if mmc.no_text:  # only the [CLS] token of the text (mm.py:724-729)
+            ids, mask = ids[:, :1], mask[:, :1]
+            tt = tt[:, :1] if tt is not None else None
+        ids = ids.to(torch.int64).contiguous()
+        tt = tt.to(torch.int64).contiguous() if tt is not None else None
+        B, L = ids.shape
+        dev, H = ids.device, bert.hidden
+        te = torch.empty((B * L, H), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mq_bert_embed_ln_split_f32(
+                ids.data_ptr(), tt.data_ptr() if tt is not None else None, bert.w_word.data_ptr(), bert.w_pos.data_ptr(),
+                bert.w_type.data_ptr(), bert.emb_g.data_ptr(), bert.emb_b.data_ptr(), te.data_ptr(), None, None, B, L, H,
+                bert.eps, _stream(te)), "mq_bert_embed_ln_split_f32")
+        parts, masks = [te.view(B, L, H)], [mask]
+        fo, fmask = self._faces(face_inputs, B)
+        if fo is not None:
+            parts.append(fo.view(B, mmc.n_faces, H))
+        masks.append(fmask)
+        imasks = []
+        for n, name in enumerate(self.image_names):
+            image = image_inputs[name]
+            parts.append(self._image(n, image["input"].reshape(B, -1)).view(B, 1, H))
+            imasks.append(image["attention_mask"].reshape(B, 1).to(torch.int64))
+        if imasks:
+            imask = torch.cat(imasks, dim=1)
+            if mmc.face_and_image_are_exclusive:  # mask the images of examples with at least one face (mm.py:716-720)
+                imask = imask * (fmask.sum(dim=1, keepdim=True) == 0).to(torch.int64)
+            masks.append(imask)
+        h = torch.cat(parts, dim=1).contiguous()
+        full_mask = torch.cat(masks, dim=1).contiguous()
+        Lt = h.shape[1]
+        last, hidden = bert._layers(h.view(B * Lt, H), None, full_mask, B, Lt, output_hidden_states, cls_only=not output_hidden_states)
+        pooled = last[:, 0, :]
+        if not return_dict:
+            return (pooled, last) + ((tuple(hidden),) if hidden is not None else ())
+        return ModelOutput(pooler_output=pooled, last_hidden_state=last,
+                           hidden_states=tuple(hidden) if hidden is not None else None, attentions=None)
+
+
+class IntermediateLinearFusion(_MMEmbeddings):
+    """meerqat.models.mm.IntermediateLinearFusion: LayerNorm(dpr_proj(DPR [CLS]) + sum of the face embeddings + the image
+    projections).  Like the reference, ALL n_faces slots are summed, padded ones included (mm.py:838-843)."""
+    config_class = dict
+
+    def __init__(self, config, state):
+        super().__init__()
+        mmc = MMConfig(config)
+        prefix = "dpr_encoder.question_encoder.bert_model." if mmc.question_encoder else "dpr_encoder.ctx_encoder.bert_model."
+        self.bert_model = BertEncoderHIP(config, state, prefix)
+        self._init_mm(mmc, state, False)
+        self._reg("p_w", state["dpr_proj.weight"])
+        self._reg("p_b", state["dpr_proj.bias"])
+        self._reg("ln_g", state["LayerNorm.weight"])
+        self._reg("ln_b", state["LayerNorm.bias"])
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, **kwargs):
+        config, state = read_checkpoint(pretrained_model_name_or_path)
+        return cls(config, state)
+
+    @classmethod
+    def from_state_dict(cls, config, state):
+        return cls(config, state)
+
+    @torch.no_grad()
+    def forward(self, text_inputs=None, face_inputs=None, image_inputs=None, **unused):
+        mmc = self.mm
+        lib = _lib.load()
+        last, _ = self.bert_model(text_inputs["input_ids"], text_inputs.get("token_type_ids"), text_inputs.get("attention_mask"),
+                                  cls_only=True)
+        pooled = last[:, 0, :].contiguous()
+        B, H = pooled.shape
+        out = gemm_nt(pooled, self.p_w, self.p_b, None, EPI_BIAS, wsplit=self._ws("p_w"))
+        fo, fmask = self._faces(face_inputs, B)
+        if fo is not None:
+            with torch.cuda.device(out.device):
+                _lib.check(lib.mq_sum_groups_f32(fo.data_ptr(), out.data_ptr(), out.data_ptr(), B, mmc.n_faces, H, _stream(out)),
+                           "mq_sum_groups_f32")
+        for n, name in enumerate(self.image_names):
+            x = image_inputs[name]["input"].reshape(B, -1).to(torch.float32)
+            if mmc.face_and_image_are_exclusive:  # zero the image features of examples with a detected face (mm.py:852-856)
+                x = x * (fmask.sum(dim=1, keepdim=True) == 0).to(torch.float32)
+            out = self._image(n, x, residual=out)
+        return ModelOutput(pooler_output=layernorm(out, self.ln_g, self.ln_b, mmc.layer_norm_eps, out=out))
+
+
+HIP_CLASSES = {"DPRContextEncoder": DPRContextEncoder, "DPRQuestionEncoder": DPRQuestionEncoder, "CLIPModel": CLIPModel,
+               "ECAEncoder": ECAEncoder, "IntermediateLinearFusion": IntermediateLinearFusion}

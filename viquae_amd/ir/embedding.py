@@ -3,8 +3,9 @@
 (:249-272) and the ``__main__`` wiring (:275-298) as :func:`main`.
 
 The model is one of :mod:`viquae_amd.encoders` (or anything with the same call surface); its
-``forward`` runs in HIP kernels.  The multimodal branch of the reference (ECA / ILF encoders fed
-with face and image features, :29-125,181-192) is outside this build and raises.
+``forward`` runs in HIP kernels.  The multimodal branch (ECA / ILF encoders fed with pre-computed face and image
+features: ``get_face_inputs`` :29-76, ``get_image_inputs`` :79-107, ``map_passage_to_kb`` :110-125, ``get_inputs``
+:181-192) is mirrored too.
 """
 import json
 
@@ -29,16 +30,62 @@ def expand_query(batch, key="passage", kb=None, run=None, tokenizer=None, qe_pre
     return batch[key]
 
 
+def get_face_inputs(batch, n_faces=4, face_dim=512, bbox_dim=7):
+    """Pre-computed face features as square tensors: face [B, 1, n_faces, face_dim], bbox [B, 1, n_faces, bbox_dim],
+    attention_mask [B, 1, n_faces] (1 = a detected face); ``None`` = no face detected, extra faces are trimmed."""
+    face_list = batch["face_embedding"]
+    batch_size = len(face_list)
+    face = torch.zeros((batch_size, 1, n_faces, face_dim))
+    bbox = torch.zeros((batch_size, 1, n_faces, bbox_dim))
+    attention_mask = torch.zeros((batch_size, 1, n_faces), dtype=torch.long)
+    if n_faces > 0:
+        for i, (face_embedding, box) in enumerate(zip(face_list, batch["face_box"])):
+            if face_embedding is None:
+                continue
+            n = min(n_faces, len(face_embedding))
+            face[i, 0, :n] = torch.as_tensor(face_embedding[:n], dtype=torch.float32)
+            bbox[i, 0, :n] = torch.as_tensor(box[:n], dtype=torch.float32)
+            attention_mask[i, 0, :n] = 1
+    return {"face": face, "bbox": bbox, "attention_mask": attention_mask}
+
+
+def get_image_inputs(batch, image_kwargs):
+    """One entry per image feature named in ``image_kwargs``: input [B, 1, dim], attention_mask [B, 1] of ones."""
+    image_inputs = {}
+    for name in image_kwargs:
+        features = torch.as_tensor(batch[name], dtype=torch.float32).unsqueeze(1)
+        image_inputs[name] = dict(input=features, attention_mask=torch.ones((features.shape[0], 1), dtype=torch.long))
+    return image_inputs
+
+
+def map_passage_to_kb(batch, kb, features):
+    """Adds the KB's pre-computed ``features`` of the rows ``batch['index']`` to the batch (passages -> their article)."""
+    subset = kb.select(batch["index"])
+    for feature in features:
+        batch.setdefault(feature, subset[feature])
+    return batch
+
+
 def is_multimodal(model):
     cfg = getattr(model, "config", None)
     return cfg is not None and type(cfg).__name__ == "MMConfig"
 
 
 def get_inputs(batch, model, tokenizer, tokenization_kwargs={}, key="passage", kb=None, run=None, qe_predictions_key=None):
-    if is_multimodal(model):
-        raise NotImplementedError("multimodal encoders (ECA/ILF) are outside the MI355X build (SURVEY.md section 2)")
     text_inputs = expand_query(batch, key=key, kb=kb, run=run, tokenizer=tokenizer, qe_predictions_key=qe_predictions_key)
-    return tokenizer(text_inputs, **tokenization_kwargs)
+    text_inputs = tokenizer(text_inputs, **tokenization_kwargs)
+    if not is_multimodal(model):
+        return text_inputs
+    if kb is not None:
+        if run is not None:
+            raise NotImplementedError("The use of kb is ambiguous when run is provided AND model is multimodal")
+        features = {"face_embedding", "face_box"} | model.config.image_kwargs.keys()
+        new_batch = map_passage_to_kb(batch.copy(), kb, features)  # a copy: the KB's features must not be saved with the batch
+    else:
+        new_batch = batch
+    return dict(text_inputs=text_inputs,
+                face_inputs=get_face_inputs(new_batch, model.config.n_faces, **model.config.face_kwargs),
+                image_inputs=get_image_inputs(new_batch, model.config.image_kwargs))
 
 
 def embed(batch, model, tokenizer, tokenization_kwargs={}, key="passage", save_as="text_embedding", output_key=None,
