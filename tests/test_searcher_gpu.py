@@ -67,3 +67,28 @@ def test_dataset_search_two_indexes_then_fusion(tmp_path):
     assert_same_run(fused, want)
     assert_same_run(json.load(open(out / "test_run.json")), want)
     assert (out / "dpr.json").exists() and (out / "clip.json").exists() and (out / "qrels.json").exists()
+
+
+def test_search_cli_main(tmp_path):
+    """python -m viquae_amd.ir.searcher <dataset> <config> --k --metrics: the reference's CLI wiring (search.py:527-543)."""
+    import datasets
+    import numpy as np
+    from oracle import knn as ok
+    from viquae_amd.ir import searcher
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((500, 32)).astype(np.float32)
+    kb_path, q_path = str(tmp_path / "kb"), str(tmp_path / "questions")
+    datasets.Dataset.from_dict({"vec": [r for r in X], "passage": [f"p {i}" for i in range(500)]}).save_to_disk(kb_path)
+    Q = rng.standard_normal((9, 32)).astype(np.float32)
+    datasets.Dataset.from_dict({"id": [f"q{i}" for i in range(9)], "vec_q": [r for r in Q],
+                                "output": [{"original_answer": "p 3", "answer": ["p 3"]}] * 9}).save_to_disk(q_path)
+    config = {"kb_kwargs": {kb_path: {"index_kwargs": {"dense": {"column": "vec", "key": "vec_q", "string_factory": "Flat",
+                                                                  "metric_type": 0}}}},
+              "reference_kb_path": kb_path, "reference_key": "passage", "format": {"type": "numpy", "columns": ["vec_q"],
+                                                                                   "output_all_columns": True}}
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps(config))
+    s = searcher.main(q_path, str(cfg_path), k=5, metrics=str(tmp_path / "m"))
+    D, I = ok.knn(X, Q, 5, metric=0)
+    assert {q: list(r) for q, r in s.runs["dense"].items()} == {f"q{i}": [str(int(j)) for j in I[i]] for i in range(9)}
+    assert (tmp_path / "m" / "dense.json").exists()

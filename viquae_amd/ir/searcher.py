@@ -215,3 +215,29 @@ def dataset_search(dataset, k=100, metric_save_path=None, map_kwargs={}, **kwarg
         fuser = Fusion(qrels=searcher.qrels, runs=list(searcher.runs.values()), output=metric_save_path, **fusion_kwargs)
         searcher.fusion = getattr(fuser, subcommand)(**subcommand_kwargs)
     return searcher
+
+
+def main(dataset_path, config_path, k=100, metrics=None, disable_caching=False):
+    """The reference's ``python -m meerqat.ir.search <dataset> <config> [--k=<k> --metrics=<path> --disable_caching]``
+    (meerqat/ir/search.py:527-543): load the dataset and the JSON config, apply its ``format`` entry, search, save."""
+    import datasets
+    from datasets import load_from_disk
+    if disable_caching:
+        datasets.disable_caching()
+    dataset = load_from_disk(dataset_path)
+    with open(config_path, "rt") as file:
+        config = json.load(file)
+    dataset.set_format(**config.pop("format", {}))
+    return dataset_search(dataset, int(k), metric_save_path=Path(metrics) if metrics is not None else None, **config)
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description="search a dataset's embedded questions in HIP-backed KBs (meerqat.ir.search)")
+    ap.add_argument("dataset")
+    ap.add_argument("config")
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--metrics")
+    ap.add_argument("--disable_caching", action="store_true")
+    a = ap.parse_args()
+    main(a.dataset, a.config, a.k, a.metrics, a.disable_caching)
