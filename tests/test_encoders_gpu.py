@@ -404,3 +404,28 @@ def test_multimodal_through_the_embed_mirror():
                     "attention_mask": torch.from_numpy(z["attention_mask"])}
     out = IE.embed(batch, model, Tok(), key="input", save_as="emb", output_key="pooler_output")
     assert np.abs(np.asarray(out["emb"]) - z["pooler_output"]).max() < TOL
+
+
+def test_eca_shipped_shape_no_faces_one_image_feature():
+    """experiments/mm/eca/config.yaml ships n_faces: 0 with clip-RN50 only: HIP module vs the oracle (itself pinned to the
+    reference class on the face-bearing goldens)."""
+    from oracle import encoders as oe
+    from viquae_amd import encoders as E
+    cfg = dict(oe.MM_TINY, n_faces=0, image_kwargs={"clip-RN50": {"input_dim": 96}})
+    state = oe.seeded_state(oe.eca_param_shapes(cfg), 61)
+    rng = np.random.default_rng(61)
+    B, L = 5, 14
+    ids = rng.integers(1, cfg["vocab_size"], (B, L)).astype(np.int64)
+    mask = (np.arange(L)[None] < np.array([14, 3, 14, 8, 1])[:, None]).astype(np.int64)
+    img = rng.standard_normal((B, 1, 96)).astype(np.float32)
+    face = np.zeros((B, 1, 0, 64), np.float32)
+    bbox = np.zeros((B, 1, 0, 7), np.float32)
+    fmask = np.zeros((B, 1, 0), np.int64)
+    want = oe.eca_forward(state, cfg, ids, None, mask, face, bbox, fmask, {"clip-RN50": (img, np.ones((B, 1), np.int64))})
+    model = E.ECAEncoder.from_state_dict(cfg, state).to("cuda").eval()
+    out = model(text_inputs={"input_ids": _cuda(ids), "attention_mask": _cuda(mask)},
+                face_inputs={"face": _cuda(face), "bbox": _cuda(bbox), "attention_mask": _cuda(fmask)},
+                image_inputs={"clip-RN50": {"input": _cuda(img), "attention_mask": torch.ones((B, 1), dtype=torch.long, device="cuda")}},
+                output_hidden_states=True)
+    assert np.abs(out["pooler_output"].cpu().numpy() - want).max() < TOL
+    assert out["last_hidden_state"].shape == (B, L + 1, cfg["hidden_size"]) and len(out["hidden_states"]) == cfg["num_hidden_layers"] + 1
