@@ -155,9 +155,6 @@ def main():
     I = torch.empty((nq, k), dtype=torch.int64, device=device)
 
     mode = args.mode
-    if mode == "screened":
-        local.search_device(Q[:256].contiguous(), k)  # builds the shard-level scalars of the screened path (max ||x||^2)
-
     def local_step(ev0=None, ev1=None, which=None):
         e0 = ev0.cuda_event if ev0 is not None else None
         e1 = ev1.cuda_event if ev1 is not None else None
@@ -216,8 +213,6 @@ def main():
     other = None
     if world == 1 and not args.no_other_path:
         which = "exact_f32" if mode == "screened" else "screened"
-        if which == "screened" and local._xmax2 is None:
-            local.search_device(Q[:256].contiguous(), k)
         D_head, I_head = D.clone(), I.clone()
         n2 = max(2, min(5, args.steps))
         local_step(which=which)
