@@ -88,6 +88,10 @@ class SplitAct:
         H = self.hi.shape[1]
         return SplitAct(self.hi.view(B, L, H)[:, 0, :].contiguous(), self.lo.view(B, L, H)[:, 0, :].contiguous())
 
+    def rows(self, index):
+        """the rows `index` (int64 tensor)"""
+        return SplitAct(self.hi.index_select(0, index).contiguous(), self.lo.index_select(0, index).contiguous())
+
     def float(self):
         return self.hi.view(torch.bfloat16).float() + self.lo.view(torch.bfloat16).float()
 
@@ -383,12 +387,16 @@ class DPRQuestionEncoder(_DPREncoder):
 # --------------------------------------------------------------------------------------------------
 # CLIP vision tower
 # --------------------------------------------------------------------------------------------------
-def _clip_block(h, w, sp, mask, B, T, heads, scale, eps, act, causal):
-    """One pre-LN CLIP transformer block on the residual stream h [B*T, H] (updated in place)."""
+def _clip_block(h, w, sp, mask, B, T, heads, scale, eps, act, causal, keep_rows=None):
+    """One pre-LN CLIP transformer block on the residual stream h [B*T, H] (updated in place).  ``keep_rows`` (int64 row
+    indices, one per sequence) is given for the LAST block: only the pooled token's row leaves the tower, and everything
+    after the attention is row-wise, so the output projection and the MLP run on those B rows alone (same numbers)."""
     if _use_split(h.shape[1], w("w1").shape[0]):
         _, y = layernorm_split(h, w("g1"), w("b1"), eps, want_f32=False)
         qkv = gemm_nt(y, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
         ctx = attention(qkv, mask, B, T, heads, scale, causal=causal, split=True)
+        if keep_rows is not None:
+            ctx, h = ctx.rows(keep_rows), h.index_select(0, keep_rows).contiguous()
         h = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("wo"))
         _, y = layernorm_split(h, w("g2"), w("b2n"), eps, want_f32=False)
         f = gemm_nt(y, w("w1"), w("bb1"), None, act, wsplit=sp("w1"), out_split=True)
@@ -396,8 +404,10 @@ def _clip_block(h, w, sp, mask, B, T, heads, scale, eps, act, causal):
     y = layernorm(h, w("g1"), w("b1"), eps)
     qkv = gemm_nt(y, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
     ctx = attention(qkv, mask, B, T, heads, scale, causal=causal)
+    if keep_rows is not None:
+        ctx, h = ctx.index_select(0, keep_rows).contiguous(), h.index_select(0, keep_rows).contiguous()
     h = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("wo"))
-    y = layernorm(h, w("g2"), w("b2n"), eps, out=y)
+    y = layernorm(h, w("g2"), w("b2n"), eps)
     f = gemm_nt(y, w("w1"), w("bb1"), None, act, wsplit=sp("w1"))
     return gemm_nt(f, w("w2"), w("bb2"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("w2"))
 
@@ -534,12 +544,14 @@ class CLIPModel(_HipEncoder):
         for i in range(self.t_layers):
             w = lambda n: getattr(self, f"t{i}_{n}")  # noqa: E731
             sp = lambda n: self._ws(f"t{i}_{n}")  # noqa: E731
-            h = _clip_block(h, w, sp, mask, B, L, self.t_heads, scale, self.t_eps, self.t_act, causal=True)
-        pooled = torch.empty((B, H), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            _lib.check(lib.mq_clip_eos_pool_ln_f32(h.data_ptr(), ids.data_ptr(), self.t_eos, self.t_fin_g.data_ptr(),
-                                                   self.t_fin_b.data_ptr(), pooled.data_ptr(), B, L, H, self.t_eps, _stream(h)),
-                       "mq_clip_eos_pool_ln_f32")
+            keep = None
+            if i == self.t_layers - 1:
+                # end-of-text position per sequence (HF: the largest id for legacy eos_token_id == 2 configs, else the first
+                # eos_token_id): only that row of the last block's output is pooled
+                eot = ids.to(torch.int32).argmax(dim=1) if self.t_eos == 2 else (ids == self.t_eos).to(torch.int32).argmax(dim=1)
+                keep = torch.arange(B, device=dev, dtype=torch.int64) * L + eot.to(torch.int64)
+            h = _clip_block(h, w, sp, mask, B, L, self.t_heads, scale, self.t_eps, self.t_act, causal=True, keep_rows=keep)
+        pooled = layernorm(h, self.t_fin_g, self.t_fin_b, self.t_eps)  # h = the B end-of-text rows after the last block
         return gemm_nt(pooled, self.t_wproj, None, None, EPI_NONE, wsplit=self._ws("t_wproj"))
 
     @torch.no_grad()
@@ -568,8 +580,10 @@ class CLIPModel(_HipEncoder):
         for i in range(self.layers):
             w = lambda n: getattr(self, f"l{i}_{n}")  # noqa: E731
             sp = lambda n: self._ws(f"l{i}_{n}")  # noqa: E731
-            h = _clip_block(h, w, sp, None, B, T, self.heads, scale, self.eps, self.act, causal=False)
-        pooled = layernorm(h.view(B, T, H)[:, 0, :].contiguous(), self.post_g, self.post_b, self.eps)
+            last = i == self.layers - 1
+            h = _clip_block(h, w, sp, None, B, T, self.heads, scale, self.eps, self.act, causal=False,
+                            keep_rows=torch.arange(B, device=dev, dtype=torch.int64) * T if last else None)
+        pooled = layernorm(h, self.post_g, self.post_b, self.eps)  # h = the B [CLS] rows after the last block
         return gemm_nt(pooled, self.wproj, None, None, EPI_NONE, wsplit=self._ws("wproj"))
 
 
