@@ -1,0 +1,272 @@
+// image.hip -- image preprocessing in front of the CLIP tower on gfx950: what
+// `transform(images, return_tensors="pt")` computes in meerqat/image/embedding.py:141-152 with the
+// CLIPFeatureExtractor of experiments/image_embedding/clip/vit_config.json:13-17 -- Pillow's 8-bit
+// `Image.resize(size, BICUBIC)` (ImagingResample: double-precision filter weights rounded to 22-bit fixed point,
+// a horizontal then a vertical pass of integer multiply-adds, each rounded and clipped to uint8), the centre crop,
+// `float32(float64(u8) * rescale_factor)` and `(x - mean) / std`.  C ABI: include/meerqat_hip.h.
+//
+// The decoded images of a batch arrive as ONE packed uint8 buffer (HWC, RGB, each image at its own offset) with a
+// small geometry table (mq_image_plan, host arithmetic inside this library).  Three launches per batch:
+//
+//   resample_coeffs_kernel   per (image, axis, output coordinate inside the crop window): bounds + fixed-point taps,
+//                            f64 without contraction = the C doubles of Pillow's precompute_coeffs
+//   resample_rows_kernel     horizontal pass, only the source rows the crop window's vertical taps touch and only
+//                            the crop window's columns: uint8 [rows][crop_w][3] per image
+//   resample_cols_kernel     vertical pass + rescale + normalise + HWC -> CHW: float32 [B][3][crop_h][crop_w]
+//
+// Byte/integer work bound by HBM (each source pixel is read once from HBM, taps hit L1/L2); bit-exact with Pillow
+// + transformers by construction (integer MACs; the float steps are single IEEE operations).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/meerqat_hip.h"
+
+extern "C" void mq_internal_set_hip_error(int e);
+
+namespace {
+
+#define IMG_HIP(call)                                  \
+    do {                                               \
+        hipError_t _e = (call);                        \
+        if (_e != hipSuccess) { mq_internal_set_hip_error((int)_e); return MQ_EHIP; } \
+    } while (0)
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;  // Resample.c
+constexpr int G = MQ_IMAGE_GEOM;            // int64 fields per image, see mq_image_plan
+enum { G_SRC = 0, G_INH, G_INW, G_OUTH, G_OUTW, G_TOP, G_LEFT, G_COEFH, G_COEFV, G_INTER, G_KH, G_KV };
+
+__host__ __device__ inline double filter_support(int filter) { return filter == MQ_IMAGE_BICUBIC ? 2.0 : 1.0; }
+
+// ksize of Pillow's precompute_coeffs for the full-image box
+__host__ __device__ inline int resample_ksize(int in_size, int out_size, int filter) {
+    double scale = (double)((float)in_size - 0.0f) / out_size;
+    double filterscale = scale < 1.0 ? 1.0 : scale;
+    return (int)ceil(filter_support(filter) * filterscale) * 2 + 1;
+}
+
+__device__ __forceinline__ double filter_eval(int filter, double x) {
+    if (x < 0.0) x = -x;
+    if (filter == MQ_IMAGE_BICUBIC) {  // Keys, a = -0.5
+        if (x < 1.0) return ((-0.5 + 2.0) * x - (-0.5 + 3.0)) * x * x + 1;
+        if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * -0.5;
+        return 0.0;
+    }
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+
+struct ImgArgs {
+    const uint8_t* src;
+    const int64_t* geom;  // [B][G]
+    int32_t* bounds;      // [B][2 axes][crop_max][2] (first source index, taps)
+    int32_t* coefs;       // per image / axis at geom[G_COEF*], [crop][ksize]
+    uint8_t* inter;       // per image at geom[G_INTER]: [rows][crop_w][3]
+    int32_t* rowspan;     // [B][2]: first source row, rows the vertical pass touches
+    float* out;           // [B][3][crop_h][crop_w]
+    int B, crop_h, crop_w, crop_max, filter, flags;
+    double rescale;
+    float mean[3], stdv[3];
+};
+
+// One thread per (image, axis, j): the taps of output coordinate crop_offset + j.
+__global__ __launch_bounds__(256) void resample_coeffs_kernel(const ImgArgs a) {
+    const int b = blockIdx.y, axis = blockIdx.z;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int64_t* g = a.geom + (size_t)b * G;
+    const int crop = axis ? a.crop_h : a.crop_w;
+    if (j >= crop) return;
+    const int in_size = (int)(axis ? g[G_INH] : g[G_INW]);
+    const int out_size = (int)(axis ? g[G_OUTH] : g[G_OUTW]);
+    const int xx = (int)(axis ? g[G_TOP] : g[G_LEFT]) + j;
+    const int ksize = (int)(axis ? g[G_KV] : g[G_KH]);
+    int32_t* k = a.coefs + (axis ? g[G_COEFV] : g[G_COEFH]) + (size_t)j * ksize;
+    int32_t* bd = a.bounds + (((size_t)b * 2 + axis) * a.crop_max + j) * 2;
+
+    const double scale = (double)((float)in_size - 0.0f) / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = filter_support(a.filter) * filterscale;
+    const double center = 0.0 + (xx + 0.5) * scale;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) ww += filter_eval(a.filter, (x + xmin - center + 0.5) * ss);
+    for (int x = 0; x < xmax; ++x) {
+        double w = filter_eval(a.filter, (x + xmin - center + 0.5) * ss);
+        if (ww != 0.0) w /= ww;
+        k[x] = w < 0 ? (int)(-0.5 + w * (1 << PRECISION_BITS)) : (int)(0.5 + w * (1 << PRECISION_BITS));
+    }
+    for (int x = xmax; x < ksize; ++x) k[x] = 0;
+    bd[0] = xmin;
+    bd[1] = xmax;
+    if (axis == 1 && (j == 0 || j == crop - 1)) {
+        // source rows the vertical pass touches: [first tap of the crop's first row, last tap of its last row)
+        if (j == 0) a.rowspan[b * 2 + 0] = xmin;
+        if (j == crop - 1) a.rowspan[b * 2 + 1] = xmin + xmax;  // end (exclusive); turned into a count by the reader
+    }
+}
+
+__device__ __forceinline__ int clip8(int v) {
+    v >>= PRECISION_BITS;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+constexpr int ROWS_PER_BLOCK = 8;
+
+// Horizontal pass.  blockIdx.y = image, blockIdx.x = group of 8 needed source rows; a thread produces the three
+// channels of one (row, crop column).
+__global__ __launch_bounds__(256) void resample_rows_kernel(const ImgArgs a) {
+    const int b = blockIdx.y;
+    const int64_t* g = a.geom + (size_t)b * G;
+    const int row0 = a.rowspan[b * 2 + 0], nrows = a.rowspan[b * 2 + 1] - row0;
+    const int r0 = blockIdx.x * ROWS_PER_BLOCK;
+    if (r0 >= nrows) return;
+    const int in_w = (int)g[G_INW], ksize = (int)g[G_KH];
+    const uint8_t* src = a.src + g[G_SRC];
+    const int32_t* coef = a.coefs + g[G_COEFH];
+    const int32_t* bd = a.bounds + ((size_t)b * 2 + 0) * a.crop_max * 2;
+    uint8_t* dst = a.inter + g[G_INTER];
+    const int rows = min(ROWS_PER_BLOCK, nrows - r0);
+    for (int idx = threadIdx.x; idx < rows * a.crop_w; idx += 256) {
+        const int r = r0 + idx / a.crop_w, j = idx % a.crop_w;
+        const int xmin = bd[j * 2], n = bd[j * 2 + 1];
+        const uint8_t* p = src + ((size_t)(row0 + r) * in_w + xmin) * 3;
+        const int32_t* k = coef + (size_t)j * ksize;
+        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        for (int x = 0; x < n; ++x) {
+            const int kx = k[x];
+            s0 += p[3 * x] * kx;
+            s1 += p[3 * x + 1] * kx;
+            s2 += p[3 * x + 2] * kx;
+        }
+        uint8_t* o = dst + ((size_t)r * a.crop_w + j) * 3;
+        o[0] = (uint8_t)clip8(s0);
+        o[1] = (uint8_t)clip8(s1);
+        o[2] = (uint8_t)clip8(s2);
+    }
+}
+
+// Vertical pass + rescale + normalise.  blockIdx.y = image, blockIdx.x = 256 output pixels of the crop window.
+__global__ __launch_bounds__(256) void resample_cols_kernel(const ImgArgs a) {
+    const int b = blockIdx.y;
+    const int64_t* g = a.geom + (size_t)b * G;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.crop_h * a.crop_w) return;
+    const int i = idx / a.crop_w, j = idx % a.crop_w;
+    const int row0 = a.rowspan[b * 2 + 0], ksize = (int)g[G_KV];
+    const int32_t* bd = a.bounds + (((size_t)b * 2 + 1) * a.crop_max + i) * 2;
+    const int ymin = bd[0], n = bd[1];
+    const int32_t* k = a.coefs + g[G_COEFV] + (size_t)i * ksize;
+    const uint8_t* p = a.inter + g[G_INTER] + ((size_t)(ymin - row0) * a.crop_w + j) * 3;
+    const size_t stride = (size_t)a.crop_w * 3;
+    int s[3] = {1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1)};
+    for (int y = 0; y < n; ++y) {
+        const int ky = k[y];
+        s[0] += p[y * stride] * ky;
+        s[1] += p[y * stride + 1] * ky;
+        s[2] += p[y * stride + 2] * ky;
+    }
+    const size_t plane = (size_t)a.crop_h * a.crop_w;
+    float* o = a.out + (size_t)b * 3 * plane + idx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int u = clip8(s[c]);
+        float v = (a.flags & MQ_IMAGE_RESCALE) ? (float)((double)u * a.rescale) : (float)u;
+        if (a.flags & MQ_IMAGE_NORMALIZE) v = __fdiv_rn(__fsub_rn(v, a.mean[c]), a.stdv[c]);
+        o[c * plane] = v;
+    }
+}
+
+inline size_t align_up(size_t v, size_t al) { return (v + al - 1) / al * al; }
+
+}  // namespace
+
+extern "C" {
+
+int mq_image_plan(const int64_t* sizes_host, int n_images, int resize_mode, int size_h, int size_w, int crop_h, int crop_w,
+                  int filter, int64_t* geom_host, int64_t* totals_host) {
+    if (!sizes_host || !geom_host || !totals_host || n_images < 0 || crop_h < 1 || crop_w < 1) return MQ_EINVAL;
+    if (filter != MQ_IMAGE_BICUBIC && filter != MQ_IMAGE_BILINEAR) return MQ_EUNSUPPORTED;
+    if (resize_mode != MQ_IMAGE_RESIZE_NONE && resize_mode != MQ_IMAGE_RESIZE_SHORTEST && resize_mode != MQ_IMAGE_RESIZE_EXACT)
+        return MQ_EINVAL;
+    if (resize_mode != MQ_IMAGE_RESIZE_NONE && (size_h < 1 || (resize_mode == MQ_IMAGE_RESIZE_EXACT && size_w < 1))) return MQ_EINVAL;
+    int64_t src = 0, coef = 0, inter = 0, max_rows = 0;
+    for (int b = 0; b < n_images; ++b) {
+        const int64_t h = sizes_host[2 * b], w = sizes_host[2 * b + 1];
+        if (h < 1 || w < 1 || h >= (1 << 24) || w >= (1 << 24)) return MQ_EINVAL;
+        int64_t oh = h, ow = w;
+        if (resize_mode == MQ_IMAGE_RESIZE_SHORTEST) {
+            // transformers get_resize_output_image_size(default_to_square=False): int(size * long / short)
+            const int64_t sh = w <= h ? w : h, lg = w <= h ? h : w;
+            const int64_t nl = (int64_t)((double)(size_h * lg) / (double)sh);
+            oh = w <= h ? nl : size_h;
+            ow = w <= h ? size_h : nl;
+        } else if (resize_mode == MQ_IMAGE_RESIZE_EXACT) {
+            oh = size_h;
+            ow = size_w;
+        }
+        if (oh < crop_h || ow < crop_w) return MQ_EUNSUPPORTED;  // HF would zero-pad: not provided
+        if (oh >= (1 << 24) || ow >= (1 << 24)) return MQ_EINVAL;
+        int64_t* g = geom_host + (size_t)b * G;
+        g[G_SRC] = src;
+        g[G_INH] = h; g[G_INW] = w; g[G_OUTH] = oh; g[G_OUTW] = ow;
+        g[G_TOP] = (oh - crop_h) / 2;
+        g[G_LEFT] = (ow - crop_w) / 2;
+        g[G_KH] = resample_ksize((int)w, (int)ow, filter);
+        g[G_KV] = resample_ksize((int)h, (int)oh, filter);
+        g[G_COEFH] = coef; coef += (int64_t)crop_w * g[G_KH];
+        g[G_COEFV] = coef; coef += (int64_t)crop_h * g[G_KV];
+        g[G_INTER] = inter; inter += (int64_t)align_up((size_t)h * crop_w * 3, 16);
+        src += (int64_t)align_up((size_t)h * w * 3, 16);
+        if (h > max_rows) max_rows = h;
+    }
+    const int crop_max = crop_h > crop_w ? crop_h : crop_w;
+    size_t ws = 0;
+    ws += align_up((size_t)n_images * 2 * crop_max * 2 * sizeof(int32_t), 256);  // bounds
+    ws += align_up((size_t)n_images * 2 * sizeof(int32_t), 256);                 // rowspan
+    ws += align_up((size_t)coef * sizeof(int32_t), 256);                         // coefficients
+    ws += align_up((size_t)inter, 256);                                          // horizontal-pass image
+    totals_host[0] = src;
+    totals_host[1] = (int64_t)ws;
+    totals_host[2] = max_rows;
+    totals_host[3] = coef;
+    return MQ_OK;
+}
+
+int mq_image_preprocess_u8(const uint8_t* src_dev, const int64_t* geom_dev, int n_images, int crop_h, int crop_w, int filter,
+                           int flags, double rescale_factor, const float* mean3_host, const float* std3_host, int64_t max_rows,
+                           int64_t coef_ints, float* out_dev, void* ws_dev, size_t ws_bytes, void* stream) {
+    if (n_images == 0) return MQ_OK;
+    if (!src_dev || !geom_dev || !out_dev || !ws_dev || n_images < 0 || crop_h < 1 || crop_w < 1 || max_rows < 1 || coef_ints < 1)
+        return MQ_EINVAL;
+    if (filter != MQ_IMAGE_BICUBIC && filter != MQ_IMAGE_BILINEAR) return MQ_EUNSUPPORTED;
+    if ((flags & MQ_IMAGE_NORMALIZE) && (!mean3_host || !std3_host)) return MQ_EINVAL;
+    ImgArgs a;
+    a.src = src_dev;
+    a.geom = geom_dev;
+    a.B = n_images; a.crop_h = crop_h; a.crop_w = crop_w; a.crop_max = crop_h > crop_w ? crop_h : crop_w;
+    a.filter = filter; a.flags = flags; a.rescale = rescale_factor;
+    for (int c = 0; c < 3; ++c) {
+        a.mean[c] = mean3_host ? mean3_host[c] : 0.f;
+        a.stdv[c] = std3_host ? std3_host[c] : 1.f;
+    }
+    char* p = static_cast<char*>(ws_dev);
+    size_t off = 0;
+    a.bounds = reinterpret_cast<int32_t*>(p + off); off += align_up((size_t)n_images * 2 * a.crop_max * 2 * sizeof(int32_t), 256);
+    a.rowspan = reinterpret_cast<int32_t*>(p + off); off += align_up((size_t)n_images * 2 * sizeof(int32_t), 256);
+    a.coefs = reinterpret_cast<int32_t*>(p + off); off += align_up((size_t)coef_ints * sizeof(int32_t), 256);
+    a.inter = reinterpret_cast<uint8_t*>(p + off);
+    if (off > ws_bytes) return MQ_EWORKSPACE;
+    a.out = out_dev;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(resample_coeffs_kernel, dim3((a.crop_max + 255) / 256, n_images, 2), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(resample_rows_kernel, dim3((unsigned)((max_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), n_images), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(resample_cols_kernel, dim3((crop_h * crop_w + 255) / 256, n_images), dim3(256), 0, st, a);
+    IMG_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+}  // extern "C"

@@ -4,7 +4,8 @@
 
 Class names are resolved in :mod:`viquae_amd.encoders` FIRST (``DPRContextEncoder``,
 ``DPRQuestionEncoder``, ``CLIPModel`` -> the HIP-backed modules) and then in ``transformers``
-(tokenizers, feature extractors), so the reference's JSON configs
+(tokenizers); ``CLIPFeatureExtractor`` / ``CLIPImageProcessor`` resolve to the device-side
+:class:`viquae_amd.image.preprocess.CLIPImageProcessorHIP`, so the reference's JSON configs
 (experiments/ir/viquae/dpr/passages/config.json, experiments/image_embedding/clip/vit_config.json)
 load unchanged.  The reference also searches its own ``mm``/``qa``/``rr`` modules (multimodal
 encoders, readers, rerankers): those are outside this build."""
@@ -17,10 +18,18 @@ from .. import encoders as _encoders
 IMAGE_PATH = Path(os.environ.get("VIQUAE_IMAGES_PATH", "data/Commons"))
 
 
+# the transform of experiments/image_embedding/clip/vit_config.json ("CLIPFeatureExtractor", gone from transformers 5;
+# "CLIPImageProcessor" is its successor) runs on the device too; MQ_IMAGE_TRANSFORM=transformers keeps Hugging Face's
+_IMAGE_PROCESSORS = ("CLIPFeatureExtractor", "CLIPImageProcessor")
+
+
 def get_class_from_name(class_name):
     Class = _encoders.HIP_CLASSES.get(class_name)
     if Class is not None:
         return Class
+    if class_name in _IMAGE_PROCESSORS and os.environ.get("MQ_IMAGE_TRANSFORM", "hip") != "transformers":
+        from ..image.preprocess import CLIPImageProcessorHIP
+        return CLIPImageProcessorHIP
     import transformers
     Class = getattr(transformers, class_name, None)
     if Class is not None:

@@ -1,7 +1,8 @@
 """Mirror of ``meerqat.image.embedding`` for the ``type: "transformers"`` branch (SURVEY.md
 section 8 a8): ``get_model_and_transform`` (:97-122), ``embed`` (:125-166), ``dataset_embed``
 (:169-183).  The model is :class:`viquae_amd.encoders.CLIPModel`; the transform is the Hugging Face
-feature extractor named in the config (CPU preprocessing, outside the arithmetic this build owns).
+feature extractor named in the config, which resolves to the device-side
+:class:`viquae_amd.image.preprocess.CLIPImageProcessorHIP` (Pillow-exact resize / crop / normalise on the GPU).
 torchvision / openai-clip / torchscript model types are outside this build and raise."""
 import numpy as np
 import torch
@@ -32,7 +33,7 @@ def embed(batch, model, transform, save_as="image_embedding", image_key="image",
     if not kept:
         return output  # (sic) the reference returns the bare list here: meerqat/image/embedding.py:134-135
     images = [images[i] for i in kept]
-    if pool is not None:
+    if pool is not None and not getattr(transform, "on_device", False):
         per_image = pool.map(transform, images)
         inputs = {k: torch.tensor(np.concatenate([p[k] for p in per_image]), device=device) for k in per_image[0].keys()}
     else:
