@@ -253,17 +253,19 @@ int mq_fuse_wsum_f64(const int64_t *ids_dev, const double *scores_dev, int n_run
  *
  * mq_image_plan (HOST arithmetic, needs no GPU): sizes_host [n_images][2] = (height, width) of the decoded RGB
  * images -> geom_host [n_images][MQ_IMAGE_GEOM] int64 (source byte offset of the image in the packed buffer, sizes,
- * resized sizes, crop origin, workspace offsets, tap counts) and totals_host[4] = {bytes of the packed uint8 source
- * buffer (each image HWC, 16-byte aligned start), workspace bytes, largest image height, coefficient ints}.
+ * resized sizes, crop origin, workspace offsets, tap counts) and totals_host[MQ_IMAGE_TOTALS] = {bytes of the packed uint8
+ * source buffer (each image HWC at a 16-byte aligned offset, the buffer itself 16-byte aligned), workspace bytes, largest
+ * image height, coefficient ints, largest image width}.
  *   resize_mode  MQ_IMAGE_RESIZE_NONE | _SHORTEST (shortest edge -> size_h, long edge int(size_h * long / short), the
  *                `get_resize_output_image_size(default_to_square=False)` rule) | _EXACT (size_h x size_w)
  *   MQ_EUNSUPPORTED when a resized image is smaller than the crop window (HF zero-pads; not provided) or for filters
  *   other than bilinear / bicubic.
  * mq_image_preprocess_u8: src_dev = the packed source buffer, geom_dev = geom_host copied to the device,
- *   flags = MQ_IMAGE_RESCALE | MQ_IMAGE_NORMALIZE, mean3_host / std3_host = 3 floats in HOST memory, max_rows /
- *   coef_ints = totals_host[2] / [3]; out_dev float32 [n_images][3][crop_h][crop_w].
+ *   totals_host = what the plan returned, flags = MQ_IMAGE_RESCALE | MQ_IMAGE_NORMALIZE, mean3_host / std3_host = 3
+ *   floats in HOST memory; out_dev float32 [n_images][3][crop_h][crop_w].  Images wider than 21 k pixels: MQ_EUNSUPPORTED.
  * ------------------------------------------------------------------------------------------- */
 #define MQ_IMAGE_GEOM 12
+#define MQ_IMAGE_TOTALS 5
 #define MQ_IMAGE_BILINEAR 2 /* PIL.Image.Resampling values */
 #define MQ_IMAGE_BICUBIC 3
 #define MQ_IMAGE_RESIZE_NONE 0
@@ -273,9 +275,9 @@ int mq_fuse_wsum_f64(const int64_t *ids_dev, const double *scores_dev, int n_run
 #define MQ_IMAGE_NORMALIZE 2
 int mq_image_plan(const int64_t *sizes_host, int n_images, int resize_mode, int size_h, int size_w, int crop_h, int crop_w,
                   int filter, int64_t *geom_host, int64_t *totals_host);
-int mq_image_preprocess_u8(const uint8_t *src_dev, const int64_t *geom_dev, int n_images, int crop_h, int crop_w, int filter,
-                           int flags, double rescale_factor, const float *mean3_host, const float *std3_host, int64_t max_rows,
-                           int64_t coef_ints, float *out_dev, void *ws_dev, size_t ws_bytes, void *stream);
+int mq_image_preprocess_u8(const uint8_t *src_dev, const int64_t *geom_dev, int n_images, const int64_t *totals_host, int crop_h,
+                           int crop_w, int filter, int flags, double rescale_factor, const float *mean3_host,
+                           const float *std3_host, float *out_dev, void *ws_dev, size_t ws_bytes, void *stream);
 
 #ifdef __cplusplus
 }

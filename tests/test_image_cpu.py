@@ -68,7 +68,7 @@ def test_plan_matches_the_oracle_geometry():
     lib = _lib.load()
     sizes = np.array([[300, 200], [224, 224], [225, 1000], [37, 53], [1, 1], [4000, 3000], [223, 500]], dtype=np.int64)
     geom = np.zeros((len(sizes), 12), dtype=np.int64)
-    totals = np.zeros(4, dtype=np.int64)
+    totals = np.zeros(5, dtype=np.int64)
     assert lib.mq_image_plan(sizes.ctypes.data, len(sizes), 1, 224, 0, 224, 224, 3, geom.ctypes.data, totals.ctypes.data) == 0
     off = 0
     for (h, w), g in zip(sizes, geom):
@@ -79,7 +79,7 @@ def test_plan_matches_the_oracle_geometry():
         off += (h * w * 3 + 15) // 16 * 16
         for in_size, out_size, ks in ((w, ow, g[10]), (h, oh, g[11])):
             assert ks == oi.precompute_coeffs(int(in_size), int(out_size), 3)[1].shape[1]
-    assert totals[0] == off and totals[2] == 4000 and totals[1] > 0
+    assert totals[0] == off and totals[2] == 4000 and totals[4] == 3000 and totals[1] > 0
     # images smaller than the crop window after resizing are refused (HF would zero-pad)
     assert lib.mq_image_plan(sizes.ctypes.data, len(sizes), 1, 100, 0, 224, 224, 3, geom.ctypes.data, totals.ctypes.data) == -4
     assert lib.mq_image_plan(sizes.ctypes.data, len(sizes), 1, 224, 0, 224, 224, 1, geom.ctypes.data, totals.ctypes.data) == -4  # lanczos

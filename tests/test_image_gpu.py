@@ -47,7 +47,7 @@ def test_hip_resize_equals_pillow_goldens():
 
 
 SIZES = [(300, 200), (224, 224), (640, 480), (225, 1000), (1000, 225), (2000, 1500), (100, 80), (37, 53), (1, 1), (2, 300),
-         (223, 225), (448, 448), (449, 447), (3000, 224), (224, 3000), (500, 375), (375, 500)]
+         (223, 225), (448, 448), (449, 447), (3000, 224), (224, 3000), (500, 375), (375, 500), (60, 9000)]
 
 
 @pytest.mark.parametrize("kind", [3, 2])
@@ -62,6 +62,17 @@ def test_hip_equals_oracle_on_a_ragged_batch(kind):
     want = oi.clip_preprocess(ims, kind=kind)
     assert got.shape == (len(SIZES), 3, 224, 224)
     assert np.array_equal(got, want)
+
+
+def test_crop_windows_wider_than_a_workgroup_and_odd_widths():
+    """crop 300 x 333 (more columns than the row pass has threads; 999-byte rows are not dword aligned)."""
+    from oracle import image as oi
+    from viquae_amd.image.preprocess import CLIPImageProcessorHIP
+    rng = np.random.default_rng(12)
+    ims = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in [(400, 600), (333, 350), (900, 700)]]
+    p = CLIPImageProcessorHIP(size={"shortest_edge": 340}, crop_size={"height": 300, "width": 333})
+    got = p(ims)["pixel_values"].cpu().numpy()
+    assert np.array_equal(got, oi.clip_preprocess(ims, size=340, crop=(300, 333)))
 
 
 def test_pil_inputs_modes_and_empty_batch():

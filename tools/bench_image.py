@@ -22,7 +22,7 @@ def main(B=3072, H=375, W=500, cpu_sample=64):
     base = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(32)]
     ims = [base[i % 32] if i % 3 else np.ascontiguousarray(base[i % 32].transpose(1, 0, 2)) for i in range(B)]
     p = CLIPImageProcessorHIP()
-    p(ims[:64])
+    p(ims)  # first call: pins the staging buffer, starts the packing threads
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = p(ims)["pixel_values"]
@@ -37,8 +37,8 @@ def main(B=3072, H=375, W=500, cpu_sample=64):
     st = torch.cuda.current_stream().cuda_stream
 
     def run():
-        _lib.check(lib.mq_image_preprocess_u8(src.data_ptr(), gdev.data_ptr(), B, 224, 224, 3, 3, ctypes.c_double(1 / 255),
-                                              p.image_mean.ctypes.data, p.image_std.ctypes.data, int(totals[2]), int(totals[3]),
+        _lib.check(lib.mq_image_preprocess_u8(src.data_ptr(), gdev.data_ptr(), B, totals.ctypes.data, 224, 224, 3, 3,
+                                              ctypes.c_double(1 / 255), p.image_mean.ctypes.data, p.image_std.ctypes.data,
                                               out.data_ptr(), ws.data_ptr(), ws.numel(), st))
     run()
     torch.cuda.synchronize()

@@ -60,7 +60,7 @@ SIGNATURES = {
     "mq_sum_groups_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
     "mq_topk_merge_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "mq_image_plan": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
-    "mq_image_preprocess_u8": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, ctypes.c_double, c_ptr, c_ptr, c_i64, c_i64,
+    "mq_image_preprocess_u8": (c_int, [c_ptr, c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_int, ctypes.c_double, c_ptr, c_ptr,
                                        c_ptr, c_ptr, c_sz, c_ptr]),
     "mq_fuse_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "mq_fuse_wsum_f64": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_sz,

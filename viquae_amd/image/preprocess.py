@@ -94,12 +94,12 @@ class CLIPImageProcessorHIP:
         return out
 
     def plan(self, sizes):
-        """sizes int64 [B, 2] (h, w) -> (geom int64 [B, MQ_IMAGE_GEOM], totals int64 [4]); host arithmetic only."""
+        """sizes int64 [B, 2] (h, w) -> (geom int64 [B, MQ_IMAGE_GEOM], totals int64 [MQ_IMAGE_TOTALS]); host arithmetic only."""
         lib = _lib.load()
         sizes = np.ascontiguousarray(sizes, dtype=np.int64).reshape(-1, 2)
         B = sizes.shape[0]
         geom = np.zeros((B, 12), dtype=np.int64)
-        totals = np.zeros(4, dtype=np.int64)
+        totals = np.zeros(5, dtype=np.int64)
         mode = 0 if not self.do_resize else (1 if self.size_mode == "shortest" else 2)
         _lib.check(lib.mq_image_plan(sizes.ctypes.data, B, mode, self.size_h, self.size_w, self.crop_h, self.crop_w,
                                      self.resample, geom.ctypes.data, totals.ctypes.data), "mq_image_plan")
@@ -118,19 +118,26 @@ class CLIPImageProcessorHIP:
         if B == 0:
             return {"pixel_values": out}
         geom, totals = self.plan(np.array([a.shape[:2] for a in arrays], dtype=np.int64))
-        packed = torch.empty(int(totals[0]), dtype=torch.uint8, pin_memory=True)
+        packed = self._staging(int(totals[0]))
         host = packed.numpy()
-        for a, g in zip(arrays, geom):
-            n = a.shape[0] * a.shape[1] * 3
-            host[g[0]:g[0] + n] = a.reshape(-1)  # ravel of a C- or non-contiguous view alike
+
+        def pack(lo, hi):  # numpy's copy releases the GIL: a few threads reach the host memory bandwidth
+            for a, g in zip(arrays[lo:hi], geom[lo:hi]):
+                n = a.shape[0] * a.shape[1] * 3
+                host[g[0]:g[0] + n] = a.reshape(-1)  # C- or non-contiguous views alike
+        if B >= 64:
+            step = (B + self._PACK_THREADS - 1) // self._PACK_THREADS
+            list(self._pool().map(lambda lo: pack(lo, min(B, lo + step)), range(0, B, step)))
+        else:
+            pack(0, B)
         with torch.cuda.device(dev):
-            src = packed.to(dev, non_blocking=True)
+            src = packed[:int(totals[0])].to(dev, non_blocking=True)
             gdev = torch.from_numpy(geom).to(dev, non_blocking=True)
             ws = torch.empty(max(int(totals[1]), 256), dtype=torch.uint8, device=dev)
             flags = (1 if self.do_rescale else 0) | (2 if self.do_normalize else 0)
-            _lib.check(lib.mq_image_preprocess_u8(src.data_ptr(), gdev.data_ptr(), B, self.crop_h, self.crop_w, self.resample,
-                                                  flags, ctypes.c_double(self.rescale_factor), self.image_mean.ctypes.data,
-                                                  self.image_std.ctypes.data, int(totals[2]), int(totals[3]), out.data_ptr(),
+            _lib.check(lib.mq_image_preprocess_u8(src.data_ptr(), gdev.data_ptr(), B, totals.ctypes.data, self.crop_h, self.crop_w,
+                                                  self.resample, flags, ctypes.c_double(self.rescale_factor),
+                                                  self.image_mean.ctypes.data, self.image_std.ctypes.data, out.data_ptr(),
                                                   ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream),
                        "mq_image_preprocess_u8")
             # the pinned staging buffer and the workspace may be recycled as soon as this returns
@@ -138,3 +145,19 @@ class CLIPImageProcessorHIP:
         return {"pixel_values": out}
 
     __call__ = preprocess
+
+    # ---- pinned staging buffer (grow-only: pinning 1-2 GB costs more than the whole batch) and packing threads -----
+    _PACK_THREADS = 8
+
+    def _staging(self, nbytes):
+        buf = getattr(self, "_pinned", None)
+        if buf is None or buf.numel() < nbytes:
+            buf = self._pinned = torch.empty(max(nbytes, 1 << 20) * 5 // 4, dtype=torch.uint8, pin_memory=True)
+        return buf
+
+    def _pool(self):
+        pool = getattr(self, "_threads", None)
+        if pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = self._threads = ThreadPoolExecutor(self._PACK_THREADS)
+        return pool
