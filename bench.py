@@ -312,6 +312,11 @@ def main():
                 d = bench_encoders.dpr_throughput(B=2048, L=100, steps=2)
                 c = bench_encoders.clip_throughput(B=3072, steps=2)
                 tt = bench_encoders.clip_text_throughput(B=2048, L=77, steps=2)
+                try:
+                    import bench_image
+                    ip = bench_image.main()
+                except Exception as e:
+                    ip = {"error": repr(e)}
                 # BASELINE configs[3], search half: 512-d CLIP vectors, "L2norm,Flat" + inner product, 4096-query chunks
                 g3 = torch.Generator(device=device)
                 g3.manual_seed(3)
@@ -339,6 +344,7 @@ def main():
                     "clip": {"workload": "CLIP ViT-B/32, 3072 x 224x224 synthetic images per batch", "ms_per_batch": round(c["ms_per_batch"], 2),
                              "algorithmic_tflops": round(c["tflops"], 2), "x_f32_mfma_peak": round(c["tflops"] / PEAK_F32_MFMA_TFLOPS, 3),
                              "executed_bf16_mfma_frac": round(3 * c["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)},
+                    "image_preprocess": dict(ip, workload="Pillow-exact bicubic resize + crop + normalise of 3072 decoded RGB images on the device (csrc/image.hip)"),
                     "titles_encoded_per_s": round(tt["titles_per_s"], 1),
                     "clip_text": {"workload": "CLIP ViT-B/32 text tower, 2048 x 77 synthetic tokens per batch (causal)",
                                   "ms_per_batch": round(tt["ms_per_batch"], 2), "algorithmic_tflops": round(tt["tflops"], 2)},

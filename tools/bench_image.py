@@ -65,8 +65,8 @@ def main(B=3072, H=375, W=500, cpu_sample=64):
         rec["identical_to_pillow_transformers"] = bool(np.array_equal(ref, head))
     except Exception as e:  # pragma: no cover
         rec["cpu"] = repr(e)
-    print(json.dumps(rec))
+    return rec
 
 
 if __name__ == "__main__":
-    main()
+    print(json.dumps(main()))

@@ -230,22 +230,26 @@ __global__ __launch_bounds__(256) void pixel_lut_kernel(const ImgArgs a) {
     a.lut[c * 256 + u] = v;
 }
 
-// Vertical pass + rescale + normalise + HWC -> CHW.  blockIdx.y = image, blockIdx.x = output row.  Phase 1: a thread
+// Vertical pass + rescale + normalise + HWC -> CHW.  blockIdx.y = image, blockIdx.x = 4 output rows.  Phase 1: a thread
 // owns FOUR consecutive bytes of the interleaved (RGBRGB...) row, one aligned dword per tap row (taps and bounds are
 // wave-uniform); the clipped bytes go to LDS.  Phase 2: the row leaves as three planar runs of floats, coalesced.
+constexpr int COLS_ROWS = 4;  // output rows per workgroup of the column pass
+
 __global__ __launch_bounds__(256) void resample_cols_kernel(const ImgArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t row_lds[];
-    const int b = blockIdx.y, i = blockIdx.x;
+    const int b = blockIdx.y, i0 = blockIdx.x * COLS_ROWS;
     const int64_t* g = a.geom + (size_t)b * G;
     const int stride = a.crop_w * 3, dw = (stride + 3) / 4;
+    const int nr = min(COLS_ROWS, a.crop_h - i0);
     const int row0 = a.rowspan[b * 2 + 0], ksize = (int)g[G_KV];
-    const int32_t* bd = a.bounds + (((size_t)b * 2 + 1) * a.crop_max + i) * 2;
-    const int ymin = bd[0], n = bd[1];
-    const int32_t* k = a.coefs + g[G_COEFV] + (size_t)i * ksize;
-    const uint8_t* base = a.inter + g[G_INTER] + (size_t)(ymin - row0) * stride;
+    const uint8_t* inter = a.inter + g[G_INTER];
     const bool aligned = (stride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.inter) & 3) == 0;
-    for (int t = threadIdx.x; t < dw; t += 256) {
-        const uint8_t* p = base + 4 * t;
+    for (int idx = threadIdx.x; idx < nr * dw; idx += 256) {
+        const int ri = idx / dw, t = idx - ri * dw, i = i0 + ri;
+        const int32_t* bd = a.bounds + (((size_t)b * 2 + 1) * a.crop_max + i) * 2;
+        const int ymin = bd[0], n = bd[1];
+        const int32_t* k = a.coefs + g[G_COEFV] + (size_t)i * ksize;
+        const uint8_t* p = inter + (size_t)(ymin - row0) * stride + 4 * t;
         int s[4] = {1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1)};
         if (aligned) {
             for (int y = 0; y < n; ++y) {
@@ -263,15 +267,18 @@ __global__ __launch_bounds__(256) void resample_cols_kernel(const ImgArgs a) {
                 for (int e = 0; e < nb; ++e) s[e] += __mul24((int)p[(size_t)y * stride + e], ky);
             }
         }
-        reinterpret_cast<unsigned*>(row_lds)[t] = (unsigned)clip8(s[0]) | ((unsigned)clip8(s[1]) << 8) | ((unsigned)clip8(s[2]) << 16) |
-                                                  ((unsigned)clip8(s[3]) << 24);
+        reinterpret_cast<unsigned*>(row_lds)[ri * dw + t] = (unsigned)clip8(s[0]) | ((unsigned)clip8(s[1]) << 8) |
+                                                            ((unsigned)clip8(s[2]) << 16) | ((unsigned)clip8(s[3]) << 24);
     }
     __syncthreads();
     const size_t plane = (size_t)a.crop_h * a.crop_w;
-    float* o = a.out + (size_t)b * 3 * plane + (size_t)i * a.crop_w;
-    for (int j = threadIdx.x; j < a.crop_w; j += 256) {
+    float* o = a.out + (size_t)b * 3 * plane + (size_t)i0 * a.crop_w;
+    for (int ri = 0; ri < nr; ++ri) {
+        const uint8_t* row = row_lds + (size_t)ri * dw * 4;
+        for (int j = threadIdx.x; j < a.crop_w; j += 256) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c * plane + j] = a.lut[c * 256 + row_lds[3 * j + c]];
+            for (int c = 0; c < 3; ++c) o[c * plane + (size_t)ri * a.crop_w + j] = a.lut[c * 256 + row[3 * j + c]];
+        }
     }
 }
 
@@ -376,7 +383,8 @@ int mq_image_preprocess_u8(const uint8_t* src_dev, const int64_t* geom_dev, int 
     hipLaunchKernelGGL(pixel_lut_kernel, dim3(3), dim3(256), 0, st, a);
     hipLaunchKernelGGL(resample_rows_kernel, dim3((unsigned)((max_rows + a.rpb - 1) / a.rpb), n_images), dim3(256),
                        (size_t)a.rpb * pitch + tile_bytes, st, a);
-    hipLaunchKernelGGL(resample_cols_kernel, dim3(crop_h, n_images), dim3(256), align_up((size_t)crop_w * 3 + 4, 16), st, a);
+    hipLaunchKernelGGL(resample_cols_kernel, dim3((crop_h + COLS_ROWS - 1) / COLS_ROWS, n_images), dim3(256),
+                       (size_t)COLS_ROWS * align_up((size_t)crop_w * 3 + 4, 16), st, a);
     IMG_HIP(hipGetLastError());
     return MQ_OK;
 }
