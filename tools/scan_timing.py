@@ -5,7 +5,7 @@ import torch
 from viquae_amd import _lib
 from viquae_amd.index import MI355XFlatIndex
 
-N, d, nq, k = 1_500_000, 768, 4096, 100
+N, d, nq, k = 1_500_000, 768, int(os.environ.get("NQ", 4096)), 100
 dev = torch.device("cuda")
 idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=os.environ.get("SCREEN", "0") == "1")
 g = torch.Generator(device=dev); g.manual_seed(0)
@@ -22,11 +22,7 @@ idx.search_device(Q, k); torch.cuda.synchronize()
 t = dbg.view(256, 16, NS).double()
 tot = t.sum(-1)
 print("per-wave total cycles: mean %.3e min %.3e max %.3e" % (tot.mean(), tot.min(), tot.max()))
-names = (["K loop", "max16+publish", "appends", "barrier A", "refresh", "barrier B", "compaction", "need-check"] if SCREEN
+names = (["K loop issue", "MFMA tail wait", "refresh", "sub-tile tests+appends", "(unused)", "counters+flags", "flag check+compaction", "warm poll+refresh"] if SCREEN
          else ["K loop", "scan+append", "barrier", "compaction"])
-if SCREEN:
-    print("compaction rounds per workgroup: mean %.1f max %.0f" % (t[..., 1].mean(), t[..., 1].max()))
-    t[..., 1] = 0
-    tot = t.sum(-1)
 for i, name in enumerate(names):
     print(f"{name:12s} mean {t[..., i].mean():.3e} ({100 * t[..., i].mean() / tot.mean():.2f} %)  max-wave {t[..., i].max():.3e}")

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from viquae_amd import _lib
 from viquae_amd.index import MI355XFlatIndex
-N, d, nq, k = 1_500_000, 768, 4096, 100
+import os as _os
+N, d, nq, k = 1_500_000, 768, int(_os.environ.get("NQ", 4096)), 100
 dev = torch.device("cuda"); lib = _lib.load()
 idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
 g = torch.Generator(device=dev); g.manual_seed(0)
