@@ -310,6 +310,10 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_encoders
                 d = bench_encoders.dpr_throughput(B=2048, L=100, steps=2)
+                try:
+                    dp = bench_encoders.dpr_padded_throughput()
+                except Exception as e:
+                    dp = {"error": repr(e)}
                 c = bench_encoders.clip_throughput(B=3072, steps=2)
                 tt = bench_encoders.clip_text_throughput(B=2048, L=77, steps=2)
                 try:
@@ -340,6 +344,7 @@ def main():
                     "dpr": {"workload": "DPR bert-base, 2048 x 100 synthetic tokens per batch", "ms_per_batch": round(d["ms_per_batch"], 2),
                             "algorithmic_tflops": round(d["tflops"], 2), "x_f32_mfma_peak": round(d["tflops"] / PEAK_F32_MFMA_TFLOPS, 3),
                             "executed_bf16_mfma_frac": round(3 * d["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)},
+                    "dpr_reference_padding": dict(dp, workload="DPR bert-base, 2048 passages padded to max_length 256 as the reference's tokenization_kwargs do (synthetic lengths ~N(130,30)): padding-aware forward vs dense, identical outputs"),
                     "images_encoded_per_s": round(c["images_per_s"], 1),
                     "clip": {"workload": "CLIP ViT-B/32, 3072 x 224x224 synthetic images per batch", "ms_per_batch": round(c["ms_per_batch"], 2),
                              "algorithmic_tflops": round(c["tflops"], 2), "x_f32_mfma_peak": round(c["tflops"] / PEAK_F32_MFMA_TFLOPS, 3),

@@ -429,3 +429,51 @@ def test_eca_shipped_shape_no_faces_one_image_feature():
                 output_hidden_states=True)
     assert np.abs(out["pooler_output"].cpu().numpy() - want).max() < TOL
     assert out["last_hidden_state"].shape == (B, L + 1, cfg["hidden_size"]) and len(out["hidden_states"]) == cfg["num_hidden_layers"] + 1
+
+
+def _padded_batch(rng, cfg, B, L, lo=3):
+    lens = np.clip(rng.normal(0.5 * L, 0.15 * L, B).astype(int), lo, L)
+    lens[0], lens[1] = L, lo
+    ids = rng.integers(1, cfg["vocab_size"], (B, L)).astype(np.int64)
+    mask = (np.arange(L)[None] < lens[:, None]).astype(np.int64)
+    ids[mask == 0] = 0
+    return ids, mask, lens
+
+
+@pytest.mark.parametrize("B", [1100, 600, 130, 7])
+def test_dpr_padding_aware_forward_is_bit_identical_to_dense(B, monkeypatch):
+    """Passages padded to max_length like the reference's tokenization_kwargs: the bucketed forward (groups of similar
+    length, each dense at its own longest length) must give the dense forward's [CLS] vectors bit for bit."""
+    from oracle import encoders as oe
+    from viquae_amd import encoders
+    cfg = oe.BERT_TINY
+    state = oe.seeded_state(oe.bert_param_shapes(cfg), 7)
+    rng = np.random.default_rng(B)
+    ids, mask, lens = _padded_batch(rng, cfg, B, 48)
+    model = encoders.DPRContextEncoder.from_state_dict(cfg, state).to("cuda").eval()
+    plan = encoders._length_buckets(_cuda(mask))
+    assert plan is not None and len(plan) == (8 if B >= 1024 else 4 if B >= 512 else 2 if B >= 128 else 1)
+    assert sorted(int(i) for idx, _ in plan for i in idx.cpu()) == list(range(B))
+    assert all(L <= 48 for _, L in plan) and (B < 128 or min(L for _, L in plan) < 48)
+    fast = model(input_ids=_cuda(ids), attention_mask=_cuda(mask))["pooler_output"]
+    monkeypatch.setenv("MQ_ENC_PAD_SKIP", "0")
+    assert encoders._length_buckets(_cuda(mask)) is None
+    dense = model(input_ids=_cuda(ids), attention_mask=_cuda(mask))["pooler_output"]
+    assert torch.equal(fast, dense)
+    sub = slice(0, min(B, 40))
+    want = oe.bert_forward(state, cfg, ids[sub], None, mask[sub])
+    assert np.abs(fast[sub].cpu().numpy() - want).max() < TOL
+
+
+def test_padding_plan_declines_masks_it_cannot_skip():
+    from viquae_amd import encoders
+    left = np.zeros((200, 16), np.int64)
+    left[:, 8:] = 1                                   # left padding
+    holes = np.ones((200, 16), np.int64)
+    holes[:, 5] = 0                                   # a hole in the middle
+    full = np.ones((200, 16), np.int64)               # nothing to skip
+    empty = np.ones((200, 16), np.int64)
+    empty[3] = 0                                      # an all-masked sequence (HF: uniform attention)
+    for m in (left, holes, full, empty):
+        assert encoders._length_buckets(_cuda(m)) is None
+    assert encoders._length_buckets(None) is None

@@ -100,6 +100,30 @@ def dpr_throughput(B=2048, L=100, steps=2, device="cuda"):
     return {"passages_per_s": B / t, "ms_per_batch": t * 1e3, "batch": B, "seq_len": L, "tflops": flops / t / 1e12}
 
 
+def dpr_padded_throughput(B=2048, L=256, mean_len=130, std_len=30, steps=2, device="cuda"):
+    """The reference's own tokenization (experiments/ir/viquae/dpr/passages/config.json:11-14): every passage padded to
+    max_length = 256.  Synthetic lengths ~ N(130, 30) (100-word passages); dense forward vs the padding-aware one."""
+    model = DPRContextEncoder.from_state_dict(dict(BERT_BASE), random_bert_state(BERT_BASE, 0)).to(device).eval()
+    rng = np.random.default_rng(4)
+    lens = np.clip(rng.normal(mean_len, std_len, B).astype(int), 8, L)
+    mask = torch.from_numpy((np.arange(L)[None] < lens[:, None]).astype(np.int64)).to(device)
+    g = torch.Generator(device=device).manual_seed(1)
+    ids = torch.randint(1000, 30000, (B, L), generator=g, device=device) * mask
+    tt = torch.zeros((B, L), dtype=torch.int64, device=device)
+    run = lambda: model(input_ids=ids, token_type_ids=tt, attention_mask=mask)["pooler_output"]  # noqa: E731
+    t_skip = time_it(run, steps)
+    a = run()
+    os.environ["MQ_ENC_PAD_SKIP"] = "0"
+    try:
+        t_dense = time_it(run, steps)
+        b = run()
+    finally:
+        del os.environ["MQ_ENC_PAD_SKIP"]
+    return {"passages_per_s": B / t_skip, "ms_per_batch": t_skip * 1e3, "dense_passages_per_s": B / t_dense,
+            "dense_ms_per_batch": t_dense * 1e3, "batch": B, "padded_to": L, "mean_tokens": float(lens.mean()),
+            "identical_to_dense": bool(torch.equal(a, b))}
+
+
 def clip_throughput(B=3072, steps=2, device="cuda"):
     model = CLIPModel.from_state_dict({"vision_config": dict(CLIP_VITB32)}, random_clip_state(CLIP_VITB32, 0)).to(device).eval()
     g = torch.Generator(device=device).manual_seed(2)
@@ -123,4 +147,5 @@ def clip_text_throughput(B=2048, L=77, steps=2, device="cuda"):
 
 
 if __name__ == "__main__":
-    print(json.dumps({"dpr": dpr_throughput(), "clip": clip_throughput(), "clip_text": clip_text_throughput()}))
+    print(json.dumps({"dpr": dpr_throughput(), "dpr_padded": dpr_padded_throughput(), "clip": clip_throughput(),
+                      "clip_text": clip_text_throughput()}))
