@@ -440,7 +440,14 @@ def _padded_batch(rng, cfg, B, L, lo=3):
     return ids, mask, lens
 
 
-@pytest.mark.parametrize("B", [1100, 600, 130, 7])
+def _forced_plan(mask, nb=3):
+    """Three length groups regardless of the size heuristic (the tiny test models never reach it)."""
+    lens = (mask != 0).sum(1).cpu().numpy()
+    order = np.argsort(lens, kind="stable")
+    return [(torch.from_numpy(np.ascontiguousarray(p)).to(mask.device), int(lens[p].max())) for p in np.array_split(order, nb) if len(p)]
+
+
+@pytest.mark.parametrize("B", [600, 130, 7])
 def test_dpr_padding_aware_forward_is_bit_identical_to_dense(B, monkeypatch):
     """Passages padded to max_length like the reference's tokenization_kwargs: the bucketed forward (groups of similar
     length, each dense at its own longest length) must give the dense forward's [CLS] vectors bit for bit."""
@@ -451,13 +458,13 @@ def test_dpr_padding_aware_forward_is_bit_identical_to_dense(B, monkeypatch):
     rng = np.random.default_rng(B)
     ids, mask, lens = _padded_batch(rng, cfg, B, 48)
     model = encoders.DPRContextEncoder.from_state_dict(cfg, state).to("cuda").eval()
-    plan = encoders._length_buckets(_cuda(mask))
-    assert plan is not None and len(plan) == (8 if B >= 1024 else 4 if B >= 512 else 2 if B >= 128 else 1)
+    # the tiny test model never reaches the size heuristic of _length_buckets (tested separately): force three groups
+    monkeypatch.setattr(encoders, "_length_buckets", lambda m, max_buckets=8: _forced_plan(m))
+    plan = _forced_plan(_cuda(mask))
     assert sorted(int(i) for idx, _ in plan for i in idx.cpu()) == list(range(B))
-    assert all(L <= 48 for _, L in plan) and (B < 128 or min(L for _, L in plan) < 48)
+    assert all(L <= 48 for _, L in plan) and min(L for _, L in plan) < 48
     fast = model(input_ids=_cuda(ids), attention_mask=_cuda(mask))["pooler_output"]
-    monkeypatch.setenv("MQ_ENC_PAD_SKIP", "0")
-    assert encoders._length_buckets(_cuda(mask)) is None
+    monkeypatch.setattr(encoders, "_length_buckets", lambda m, max_buckets=8: None)
     dense = model(input_ids=_cuda(ids), attention_mask=_cuda(mask))["pooler_output"]
     assert torch.equal(fast, dense)
     sub = slice(0, min(B, 40))
@@ -474,6 +481,37 @@ def test_padding_plan_declines_masks_it_cannot_skip():
     full = np.ones((200, 16), np.int64)               # nothing to skip
     empty = np.ones((200, 16), np.int64)
     empty[3] = 0                                      # an all-masked sequence (HF: uniform attention)
+    big = lambda m: np.tile(m, (40, 4))               # 8000 x 64: large enough for the size heuristic
     for m in (left, holes, full, empty):
-        assert encoders._length_buckets(_cuda(m)) is None
+        assert encoders._length_buckets(_cuda(big(m))) is None
+    ok = (np.arange(64)[None] < np.random.default_rng(0).integers(4, 40, 8000)[:, None]).astype(np.int64)
+    plan = encoders._length_buckets(_cuda(ok))
+    assert plan is not None and 1 <= len(plan) <= 8
+    assert encoders._length_buckets(_cuda(ok[:100])) is None   # small batch: not worth splitting
     assert encoders._length_buckets(None) is None
+
+
+def test_clip_text_padding_aware_forward_is_bit_identical_to_dense(monkeypatch):
+    """Titles padded to the longest of the batch (CLIP pads with the end-of-text id): grouped-by-length forward == dense."""
+    from oracle import encoders as oe
+    from viquae_amd import encoders
+    cfg = oe.CLIP_TEXT_TINY
+    state = oe.seeded_state(oe.clip_text_param_shapes(cfg), 9)
+    rng = np.random.default_rng(2)
+    B, L = 700, 24
+    bos, eot = cfg["vocab_size"] - 2, cfg["vocab_size"] - 1
+    lens = np.clip(rng.normal(8, 3, B).astype(int), 3, L)
+    lens[0] = L
+    ids = rng.integers(3, cfg["vocab_size"] - 2, (B, L)).astype(np.int64)
+    ids[:, 0] = bos
+    for b, n in enumerate(lens):
+        ids[b, n - 1:] = eot          # end of text, then padding with the same id (CLIPTokenizer's pad token)
+    mask = (np.arange(L)[None] < lens[:, None]).astype(np.int64)
+    model = encoders.CLIPModel.from_state_dict({"text_config": cfg}, state).to("cuda").eval()
+    monkeypatch.setattr(encoders, "_length_buckets", lambda m, max_buckets=8: _forced_plan(m))
+    fast = model.get_text_features(input_ids=_cuda(ids), attention_mask=_cuda(mask))
+    monkeypatch.setattr(encoders, "_length_buckets", lambda m, max_buckets=8: None)
+    dense = model.get_text_features(input_ids=_cuda(ids), attention_mask=_cuda(mask))
+    assert torch.equal(fast, dense)
+    want = oe.clip_text_forward(state, cfg, ids[:32], mask[:32])
+    assert np.abs(fast[:32].cpu().numpy() - want).max() < TOL

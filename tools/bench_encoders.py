@@ -146,6 +146,35 @@ def clip_text_throughput(B=2048, L=77, steps=2, device="cuda"):
     return {"titles_per_s": B / t, "ms_per_batch": t * 1e3, "batch": B, "seq_len": L, "tflops": flops / t / 1e12}
 
 
+def clip_text_padded_throughput(B=2048, mean_len=8, std_len=3, longest=32, steps=3, device="cuda"):
+    """experiments/ir/viquae/clip/config.json:10-13: titles padded to the LONGEST of the batch; synthetic title lengths
+    ~ N(8, 3) tokens with one of `longest` tokens; dense forward vs the padding-aware one."""
+    cfg = CLIP_TEXT_VITB32
+    model = CLIPModel.from_state_dict({"text_config": dict(cfg)}, random_clip_text_state(cfg, 0)).to(device).eval()
+    rng = np.random.default_rng(5)
+    lens = np.clip(rng.normal(mean_len, std_len, B).astype(int), 3, longest)
+    lens[0] = longest
+    L = int(lens.max())
+    ids = rng.integers(3, cfg["vocab_size"] - 2, (B, L)).astype(np.int64)
+    ids[:, 0] = cfg["vocab_size"] - 2
+    for b, n in enumerate(lens):
+        ids[b, n - 1:] = cfg["vocab_size"] - 1
+    ids = torch.from_numpy(ids).to(device)
+    mask = torch.from_numpy((np.arange(L)[None] < lens[:, None]).astype(np.int64)).to(device)
+    run = lambda: model.get_text_features(input_ids=ids, attention_mask=mask)  # noqa: E731
+    t_skip = time_it(run, steps)   # small batches stay dense (size heuristic of _length_buckets)
+    a = run()
+    os.environ["MQ_ENC_PAD_SKIP"] = "0"
+    try:
+        t_dense = time_it(run, steps)
+        b = run()
+    finally:
+        del os.environ["MQ_ENC_PAD_SKIP"]
+    return {"titles_per_s": B / t_skip, "ms_per_batch": t_skip * 1e3, "dense_titles_per_s": B / t_dense,
+            "dense_ms_per_batch": t_dense * 1e3, "batch": B, "padded_to": L, "mean_tokens": float(lens.mean()),
+            "identical_to_dense": bool(torch.equal(a, b))}
+
+
 if __name__ == "__main__":
     print(json.dumps({"dpr": dpr_throughput(), "dpr_padded": dpr_padded_throughput(), "clip": clip_throughput(),
                       "clip_text": clip_text_throughput()}))

@@ -361,7 +361,11 @@ def _length_buckets(attention_mask, max_buckets=8):
     if lens.min() < 1 or int(lens.sum()) > 0.9 * B * L:
         return None
     order = np.argsort(lens, kind="stable")
-    nb = max_buckets if B >= 1024 else (4 if B >= 512 else (2 if B >= 128 else 1))
+    # a group must still fill the chip (its GEMMs have real_tokens / 256 row tiles): ~32 k tokens each, else the dense
+    # forward of a small batch is already one wave of workgroups and splitting it only adds launches
+    nb = int(min(max_buckets, lens.sum() // 32768))
+    if nb < 1 or (nb == 1 and int(lens.max()) > 0.9 * L):
+        return None
     plan = []
     for part in np.array_split(order, nb):
         if len(part):
@@ -577,6 +581,21 @@ class CLIPModel(_HipEncoder):
                              f"and max_position_embeddings: {self.t_max_pos}")
         if B and (int(ids.min()) < 0 or int(ids.max()) >= self.t_tok.shape[0]):
             raise IndexError("input_ids outside the vocabulary")
+        plan = _length_buckets(attention_mask)
+        if plan is not None:
+            # titles padded to the longest of 2048 (experiments/ir/viquae/clip/config.json:10-13) are mostly padding: run
+            # groups of similar length at their own length -- the pooled end-of-text row only attends to real tokens, so
+            # the features are bit-identical to the dense forward
+            out = torch.empty((B, self.t_wproj.shape[0]), dtype=torch.float32, device=ids.device)
+            for idx, Li in plan:
+                out.index_copy_(0, idx, self._text_features_dense(ids.index_select(0, idx)[:, :Li].contiguous(),
+                                                                  attention_mask.index_select(0, idx)[:, :Li]))
+            return out
+        return self._text_features_dense(ids, attention_mask)
+
+    def _text_features_dense(self, ids, attention_mask):
+        lib = _lib.load()
+        B, L = ids.shape
         mask = attention_mask.to(torch.int64).contiguous() if attention_mask is not None else None
         dev, H = ids.device, self.t_hidden
         h = torch.empty((B * L, H), dtype=torch.float32, device=dev)
