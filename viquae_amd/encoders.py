@@ -345,6 +345,17 @@ class BertEncoderHIP(_HipEncoder):
         return h.view(B, L, H), hidden
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    have = _SIDE_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
+
+
 def _length_buckets(attention_mask, max_buckets=8):
     """[(int64 sequence indices on the device, length)] for a right-padded 0/1 mask with padding worth skipping, else
     None (no mask, other mask shapes, empty sequences, nothing to gain, or MQ_ENC_PAD_SKIP=0).  One small D2H copy."""
@@ -411,13 +422,37 @@ class _DPREncoder(_HipEncoder):
         operation is row-wise except attention, where a masked key contributes exactly 0 to every sum and never to the
         row maximum -- so the pooled [CLS] vectors are bit-identical to the dense forward (asserted in the tests)."""
         B = input_ids.shape[0]
-        out = torch.empty((B, self.bert_model.hidden), dtype=torch.float32, device=input_ids.device)
-        for idx, Li in plan:
+        dev = input_ids.device
+        out = torch.empty((B, self.bert_model.hidden), dtype=torch.float32, device=dev)
+        # groups alternate between two side streams: the tail of one group's GEMM (a partial wave of workgroups) is
+        # filled by the other group's kernels
+        main = torch.cuda.current_stream(dev)
+        streams = _side_streams(dev, min(2, len(plan)))
+        ready = torch.cuda.Event()
+        ready.record(main)
+        def run(idx, Li):
             ids = input_ids.index_select(0, idx)[:, :Li]
             tt = token_type_ids.index_select(0, idx)[:, :Li] if token_type_ids is not None else None
             mask = attention_mask.index_select(0, idx)[:, :Li]
             last, _ = self.bert_model(ids, tt, mask, False, cls_only=True)
             out.index_copy_(0, idx, last[:, 0, :])
+
+        first = 0
+        warm_key = (str(dev), self.bert_model.w_word.data_ptr(), _gemm_mode())
+        if self.__dict__.get("_weights_split") != warm_key:
+            # the (hi, lo) weight splits are built lazily by the first forward: build them on the caller's stream before
+            # two other streams start reading them
+            run(*plan[0])
+            first = 1
+            ready.record(main)
+            self.__dict__["_weights_split"] = warm_key
+        for n, (idx, Li) in enumerate(plan[first:]):
+            st = streams[n % len(streams)]
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                run(idx, Li)
+        for st in streams:
+            main.wait_stream(st)
         return out
 
 
