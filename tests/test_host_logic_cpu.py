@@ -153,3 +153,25 @@ def test_no_gpu_means_loud_failure():
     idx = MI355XFlatIndex(string_factory="Flat", metric_type=0)
     with pytest.raises(MeerqatHipError):
         idx.add_vectors(np.zeros((4, 8), np.float32))
+
+
+def test_length_partition_is_optimal_and_covers_everything():
+    """_partition_by_length (padding-aware encoder forward): contiguous groups of the ascending lengths, every sequence in
+    exactly one, total padded tokens no worse than equal-count groups and equal to brute force on a small case."""
+    import itertools
+    from viquae_amd.encoders import _partition_by_length
+    rng = np.random.default_rng(0)
+    lens = np.sort(np.clip(rng.normal(130, 30, 2048).astype(int), 8, 256))
+    for nb in (1, 2, 4, 8):
+        parts = _partition_by_length(lens, nb)
+        assert len(parts) <= nb and parts[0].start == 0 and parts[-1].stop == len(lens)
+        assert all(a.stop == b.start for a, b in zip(parts, parts[1:]))
+        cost = sum((p.stop - p.start) * lens[p].max() for p in parts)
+        equal = sum(len(c) * c.max() for c in np.array_split(lens, nb))
+        assert cost <= equal
+    small = np.sort(rng.integers(1, 30, 12))
+    best = min(sum((b - a) * small[a:b].max() for a, b in zip((0,) + cut, cut + (12,)))
+               for r in range(0, 3) for cut in itertools.combinations(range(1, 12), r))
+    got = _partition_by_length(small, 3)
+    assert sum((p.stop - p.start) * small[p].max() for p in got) == best
+    assert _partition_by_length(np.array([5, 5, 5]), 4) == [slice(0, 3)]

@@ -371,17 +371,41 @@ def _length_buckets(attention_mask, max_buckets=8):
     lens = m.sum(dim=1).cpu().numpy()
     if lens.min() < 1 or int(lens.sum()) > 0.9 * B * L:
         return None
-    order = np.argsort(lens, kind="stable")
     # a group must still fill the chip (its GEMMs have real_tokens / 256 row tiles): ~32 k tokens each, else the dense
     # forward of a small batch is already one wave of workgroups and splitting it only adds launches
     nb = int(min(max_buckets, lens.sum() // 32768))
     if nb < 1 or (nb == 1 and int(lens.max()) > 0.9 * L):
         return None
+    order = np.argsort(lens, kind="stable")
     plan = []
-    for part in np.array_split(order, nb):
-        if len(part):
-            plan.append((torch.from_numpy(np.ascontiguousarray(part)).to(attention_mask.device), int(lens[part].max())))
+    for part in _partition_by_length(lens[order], nb):
+        seqs = order[part]
+        plan.append((torch.from_numpy(np.ascontiguousarray(seqs)).to(attention_mask.device), int(lens[seqs].max())))
     return plan
+
+
+def _partition_by_length(sorted_lens, nb):
+    """Cuts ascending lengths into <= nb contiguous groups minimising sum(group size x group's longest length), the
+    tokens a dense forward of each group processes (dynamic programme over the distinct lengths) -> list of slices."""
+    u, cnt = np.unique(sorted_lens, return_counts=True)
+    U = len(u)
+    nb = max(1, min(nb, U))
+    cs = np.concatenate([[0], np.cumsum(cnt)])
+    cost = np.full((nb + 1, U + 1), np.inf)
+    cost[0, 0] = 0.0
+    arg = np.zeros((nb + 1, U + 1), dtype=np.int64)
+    for b in range(1, nb + 1):
+        for j in range(1, U + 1):
+            c = cost[b - 1, :j] + (cs[j] - cs[:j]) * float(u[j - 1])  # last group = distinct lengths i .. j-1
+            i = int(np.argmin(c))
+            cost[b, j], arg[b, j] = c[i], i
+    b = int(np.argmin(cost[1:, U])) + 1
+    cuts, j = [], U
+    while b > 0:
+        i = int(arg[b, j])
+        cuts.append(slice(int(cs[i]), int(cs[j])))
+        j, b = i, b - 1
+    return [c for c in reversed(cuts) if c.stop > c.start]
 
 
 class _DPREncoder(_HipEncoder):
@@ -427,7 +451,7 @@ class _DPREncoder(_HipEncoder):
         # groups alternate between two side streams: the tail of one group's GEMM (a partial wave of workgroups) is
         # filled by the other group's kernels
         main = torch.cuda.current_stream(dev)
-        streams = _side_streams(dev, min(2, len(plan)))
+        streams = _side_streams(dev, min(int(os.environ.get("MQ_ENC_GROUP_STREAMS", "2")), len(plan)))
         ready = torch.cuda.Event()
         ready.record(main)
         def run(idx, Li):
