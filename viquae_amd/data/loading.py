@@ -19,7 +19,7 @@ IMAGE_PATH = Path(os.environ.get("VIQUAE_IMAGES_PATH", "data/Commons"))
 
 
 # the transform of experiments/image_embedding/clip/vit_config.json ("CLIPFeatureExtractor", gone from transformers 5;
-# "CLIPImageProcessor" is its successor) runs on the device too; MQ_IMAGE_TRANSFORM=transformers keeps Hugging Face's
+# "CLIPImageProcessor" is its successor) runs on the device too
 _IMAGE_PROCESSORS = ("CLIPFeatureExtractor", "CLIPImageProcessor")
 
 
@@ -27,7 +27,7 @@ def get_class_from_name(class_name):
     Class = _encoders.HIP_CLASSES.get(class_name)
     if Class is not None:
         return Class
-    if class_name in _IMAGE_PROCESSORS and os.environ.get("MQ_IMAGE_TRANSFORM", "hip") != "transformers":
+    if class_name in _IMAGE_PROCESSORS:
         from ..image.preprocess import CLIPImageProcessorHIP
         return CLIPImageProcessorHIP
     import transformers
