@@ -164,7 +164,7 @@ int mq_bert_embed_ln_f32(const int64_t *input_ids_dev, const int64_t *token_type
 /* Multi-head self-attention core (BertSelfAttention.forward, meerqat/models/bert.py:44-136):
  * qkv [B*L, 3*heads*head_dim] = [q | k | v] projections; attention_mask int64 [B,L] (1 = attend, as the
  * tokenizer emits it; NULL = attend everywhere); out [B*L, heads*head_dim] = softmax(q k^T * scale + mask) v.
- * head_dim must be 64, L <= 256. */
+ * head_dim must be 64; any L (sequences beyond 256 keys are processed in 256-key blocks with the online softmax). */
 int mq_attention_f32(const float *qkv_dev, const int64_t *attention_mask_dev, float *out_dev, int B, int L, int heads,
                      int head_dim, float scale, void *stream);
 

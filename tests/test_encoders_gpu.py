@@ -94,7 +94,8 @@ def test_layernorm_vs_torch(M, C):
         assert (out - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("B,L,heads,masked", [(3, 100, 12, False), (2, 37, 2, True), (1, 256, 2, True), (4, 50, 12, False), (2, 1, 2, False)])
+@pytest.mark.parametrize("B,L,heads,masked", [(3, 100, 12, False), (2, 37, 2, True), (1, 256, 2, True), (4, 50, 12, False), (2, 1, 2, False),
+                                              (2, 262, 12, True), (2, 300, 2, False), (1, 512, 2, True), (1, 700, 1, True)])
 def test_attention_vs_torch(B, L, heads, masked):
     from viquae_amd import encoders as E
     H = heads * 64
@@ -189,7 +190,7 @@ def test_from_pretrained_reads_hf_checkpoint_dir(tmp_path):
 # ---------------------------------------------------------------------------------------------------
 # CLIP text tower (experiments/ir/viquae/clip/config.json: call = get_text_features)
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,L,heads", [(3, 19, 2), (2, 77, 8), (1, 130, 1), (2, 200, 2)])
+@pytest.mark.parametrize("B,L,heads", [(3, 19, 2), (2, 77, 8), (1, 130, 1), (2, 200, 2), (2, 300, 2), (1, 513, 1)])
 @pytest.mark.parametrize("with_mask", [False, True])
 def test_causal_attention_vs_torch(B, L, heads, with_mask):
     from viquae_amd import encoders as E
@@ -515,3 +516,22 @@ def test_clip_text_padding_aware_forward_is_bit_identical_to_dense(monkeypatch):
     assert torch.equal(fast, dense)
     want = oe.clip_text_forward(state, cfg, ids[:32], mask[:32])
     assert np.abs(fast[:32].cpu().numpy() - want).max() < TOL
+
+
+def test_dpr_beyond_256_tokens_matches_the_oracle():
+    """Sequences longer than one key block of the attention kernels (256): ECA's text + faces + image sequence is 262
+    long with the shipped max_length; BERT itself allows 512.  The kernels loop over key blocks (online softmax)."""
+    from oracle import encoders as oe
+    cfg = dict(oe.BERT_TINY, max_position_embeddings=512)
+    model, state = _dpr(cfg, 11)
+    rng = np.random.default_rng(0)
+    B, L = 3, 400
+    ids = rng.integers(1, cfg["vocab_size"], (B, L)).astype(np.int64)
+    mask = np.ones((B, L), np.int64)
+    mask[1, 300:] = 0
+    mask[2, 260:] = 0
+    out = model(input_ids=_cuda(ids), attention_mask=_cuda(mask), output_hidden_states=True)
+    want, hidden = oe.bert_forward(state, cfg, ids, None, mask, return_hidden=True)
+    assert np.abs(out["pooler_output"].cpu().numpy() - want).max() < TOL
+    real = mask.astype(bool)   # padded positions attend like everybody else but nobody reads them
+    assert np.abs(out["hidden_states"][-1].cpu().numpy() - np.asarray(hidden[-1]).reshape(B, L, -1))[real].max() < TOL

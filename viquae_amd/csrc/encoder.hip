@@ -624,7 +624,7 @@ constexpr int DH = 64;  // attention head size
 // B operand straight from the accumulator registers (lanes 0-31 hold keys = 0..3 mod 8, lanes 32-63
 // keys = 4..7 mod 8, which is exactly a 2-deep k pair), with V^T rows as the A operand.
 // ------------------------------------------------------------------------------------------------
-template <int NKT>  // key tiles of 32: L <= 32 * NKT
+template <int NKT, bool MULTI>  // key tiles of 32 per key block; MULTI: sequences longer than one block loop over blocks (online softmax)
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, const long long* __restrict__ mask,
                                                              float* __restrict__ out, unsigned short* __restrict__ out_h,
                                                              unsigned short* __restrict__ out_l, int L, int heads, float scale,
@@ -639,25 +639,33 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     const float* base = qkv + (size_t)bi * L * ld + h * DH;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nthr = blockDim.x;  // 64 * min(4, ceil(queries of this block / 32)) threads: no wave without queries
-    for (int e = tid; e < NK * (DH / 4); e += nthr) {
-        const int j = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
-        float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
-        if (j < L) {
-            kf = *reinterpret_cast<const float4*>(base + (size_t)j * ld + H + c4);
-            vf = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * H + c4);
-        }
-        float* kd = Ks + j * 65 + c4;
-        kd[0] = kf.x; kd[1] = kf.y; kd[2] = kf.z; kd[3] = kf.w;
-        *reinterpret_cast<float4*>(Vs + j * 64 + c4) = vf;
-    }
-    for (int j = tid; j < NK; j += nthr) addm[j] = (j < L && (!mask || mask[(size_t)bi * L + j] != 0)) ? 0.f : -INFINITY;
-    __syncthreads();
-
     const int i = lane & 31, kh = lane >> 5;
     const int qrow = blockIdx.y * 128 + 32 * w + i;   // this lane's query
     float qreg[32];
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) qreg[kk] = (qrow < L) ? base[(size_t)qrow * ld + 2 * kk + kh] : 0.f;
+
+    // Key blocks of NK keys with the online softmax (running maximum m_run, denominator den, rescaled accumulators);
+    // a sequence that fits one block (L <= NK: every shipped config but ECA's text + faces + image) takes the loop once
+    // and computes exactly what the single-block kernel did.
+    float m_run = -INFINITY, den = 0.f;
+    f32x16 oacc0 = {0}, oacc1 = {0};
+    for (int kb0 = 0; kb0 < (MULTI ? L : 1); kb0 += NK) {  // !MULTI: exactly one pass, known at compile time
+    if (kb0) __syncthreads();  // the previous block's K / V are dead
+    for (int e = tid; e < NK * (DH / 4); e += nthr) {
+        const int j = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
+        float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
+        if (kb0 + j < L) {
+            kf = *reinterpret_cast<const float4*>(base + (size_t)(kb0 + j) * ld + H + c4);
+            vf = *reinterpret_cast<const float4*>(base + (size_t)(kb0 + j) * ld + 2 * H + c4);
+        }
+        float* kd = Ks + j * 65 + c4;
+        kd[0] = kf.x; kd[1] = kf.y; kd[2] = kf.z; kd[3] = kf.w;
+        *reinterpret_cast<float4*>(Vs + j * 64 + c4) = vf;
+    }
+    for (int j = tid; j < NK; j += nthr)
+        addm[j] = (kb0 + j < L && (!mask || mask[(size_t)bi * L + kb0 + j] != 0)) ? 0.f : -INFINITY;
+    __syncthreads();
 
     f32x16 sacc[NKT];
 #pragma unroll
@@ -678,25 +686,32 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         for (int reg = 0; reg < 16; ++reg) {
             const int key = 32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
             float sv = sacc[t][reg] * scale + addm[key];
-            if (causal && key > qrow) sv = -INFINITY;   // CLIP text tower: a token attends to itself and the past
+            if (causal && kb0 + key > qrow) sv = -INFINITY;   // CLIP text tower: a token attends to itself and the past
             sacc[t][reg] = sv;
             mx = fmaxf(mx, sv);
         }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float den = 0.f;
+    mx = fmaxf(fmaxf(mx, __shfl_xor(mx, 32)), m_run);
+    float bsum = 0.f;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const float p = (sacc[t][reg] == -INFINITY) ? 0.f : expf(sacc[t][reg] - mx);
             sacc[t][reg] = p;
-            den += p;
+            bsum += p;
         }
     }
-    den += __shfl_xor(den, 32);
+    bsum += __shfl_xor(bsum, 32);
+    if (kb0) {  // rescale what the earlier blocks accumulated to the new maximum
+        const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - mx);
+        den *= alpha;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) { oacc0[reg] *= alpha; oacc1[reg] *= alpha; }
+    }
+    den += bsum;
+    m_run = mx;
 
-    f32x16 oacc0 = {0}, oacc1 = {0};
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
 #pragma unroll
@@ -707,6 +722,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
             oacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * 64 + 32 + i], p, oacc1, 0, 0, 0);
         }
     }
+    }  // key blocks
     // oacc{0,1}[reg] = sum_key p V[key][d], d = 32 dt + (reg&3) + 8 (reg>>2) + 4 kh, for this lane's query.
     // Transpose through LDS (K/V are dead) so that every query row is stored as 256 contiguous bytes.
     __syncthreads();
@@ -740,7 +756,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 // LDS: Kh, Kl [NK][64] bf16 (16-byte chunks swizzled by (key >> 1) & 7), Vth, Vtl [64][NK] bf16 (chunks swizzled by
 // d & (NK/8 - 1)), mask row.
 // ------------------------------------------------------------------------------------------------
-template <int NKT>
+template <int NKT, bool MULTI>
 __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ qkv, const long long* __restrict__ mask,
                                                            float* __restrict__ out, unsigned short* __restrict__ out_h,
                                                            unsigned short* __restrict__ out_l, int L, int heads, float scale,
@@ -758,12 +774,31 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
     const float* base = qkv + (size_t)bi * L * ld + h * DH;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nthr = blockDim.x;
+    const int i = lane & 31, kg = lane >> 5;
+    const int qrow = blockIdx.y * 128 + 32 * w + i;   // this lane's query
+    bf16x8_t qh[4], ql[4];                            // d in [16 m + 8 kg, + 8)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+        if (qrow < L) {
+            const float* qp = base + (size_t)qrow * ld + 16 * m + 8 * kg;
+            u = *reinterpret_cast<const float4*>(qp);
+            v = *reinterpret_cast<const float4*>(qp + 4);
+        }
+        split8(u, v, qh[m], ql[m]);
+    }
+
+    // key blocks of NK keys with the online softmax (see attention_mfma_kernel): one pass when L <= NK
+    float m_run = -INFINITY, den = 0.f;
+    f32x16 oacc0 = {0}, oacc1 = {0};
+    for (int kb0 = 0; kb0 < (MULTI ? L : 1); kb0 += NK) {  // !MULTI: exactly one pass, known at compile time
+    if (kb0) __syncthreads();  // the previous block's K / V are dead
     for (int e = tid; e < NK * (DH / 4); e += nthr) {
         const int j = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
         float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
-        if (j < L) {
-            kf = *reinterpret_cast<const float4*>(base + (size_t)j * ld + H + c4);
-            vf = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * H + c4);
+        if (kb0 + j < L) {
+            kf = *reinterpret_cast<const float4*>(base + (size_t)(kb0 + j) * ld + H + c4);
+            vf = *reinterpret_cast<const float4*>(base + (size_t)(kb0 + j) * ld + 2 * H + c4);
         }
         // K row j: four consecutive d -> 8 bytes inside chunk c4 / 8
         const unsigned k01 = split_bits(kf.x), k23 = split_bits(kf.y), k45 = split_bits(kf.z), k67 = split_bits(kf.w);
@@ -781,22 +816,9 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
             *reinterpret_cast<unsigned short*>(Vtl + voff) = (unsigned short)(vb >> 16);
         }
     }
-    for (int j = tid; j < NK; j += nthr) addm[j] = (j < L && (!mask || mask[(size_t)bi * L + j] != 0)) ? 0.f : -INFINITY;
+    for (int j = tid; j < NK; j += nthr)
+        addm[j] = (kb0 + j < L && (!mask || mask[(size_t)bi * L + kb0 + j] != 0)) ? 0.f : -INFINITY;
     __syncthreads();
-
-    const int i = lane & 31, kg = lane >> 5;
-    const int qrow = blockIdx.y * 128 + 32 * w + i;   // this lane's query
-    bf16x8_t qh[4], ql[4];                            // d in [16 m + 8 kg, + 8)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
-        if (qrow < L) {
-            const float* qp = base + (size_t)qrow * ld + 16 * m + 8 * kg;
-            u = *reinterpret_cast<const float4*>(qp);
-            v = *reinterpret_cast<const float4*>(qp + 4);
-        }
-        split8(u, v, qh[m], ql[m]);
-    }
 
     f32x16 sacc[NKT];
 #pragma unroll
@@ -822,25 +844,32 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
         for (int reg = 0; reg < 16; ++reg) {
             const int key = 32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
             float sv = sacc[t][reg] * scale + addm[key];
-            if (causal && key > qrow) sv = -INFINITY;
+            if (causal && kb0 + key > qrow) sv = -INFINITY;
             sacc[t][reg] = sv;
             mx = fmaxf(mx, sv);
         }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float den = 0.f;
+    mx = fmaxf(fmaxf(mx, __shfl_xor(mx, 32)), m_run);
+    float bsum = 0.f;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const float p = (sacc[t][reg] == -INFINITY) ? 0.f : expf(sacc[t][reg] - mx);
             sacc[t][reg] = p;
-            den += p;
+            bsum += p;
         }
     }
-    den += __shfl_xor(den, 32);
+    bsum += __shfl_xor(bsum, 32);
+    if (kb0) {  // rescale what the earlier blocks accumulated to the new maximum
+        const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - mx);
+        den *= alpha;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) { oacc0[reg] *= alpha; oacc1[reg] *= alpha; }
+    }
+    den += bsum;
+    m_run = mx;
 
-    f32x16 oacc0 = {0}, oacc1 = {0};
     const int vsw0 = i & (NCH - 1);  // d = i and d = 32 + i swizzle alike when NCH <= 32
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
@@ -876,6 +905,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
             }
         }
     }
+    }  // key blocks
     // oacc{0,1}[reg] = sum_key p V[key][d], d = 32 dt + (reg&3) + 8 (reg>>2) + 4 kg, for this lane's query.
     // Transpose through LDS (K/V are dead) so that every query row is stored as 256 contiguous bytes.
     __syncthreads();
@@ -1119,34 +1149,36 @@ int mq_attention_split_f32(const float* qkv_dev, const int64_t* attention_mask_d
                            void* stream) {
     if (B == 0 || L == 0) return MQ_OK;
     if (!qkv_dev || (!out_dev && !out_h_dev) || (!out_h_dev != !out_l_dev) || B < 0 || L < 0 || heads <= 0) return MQ_EINVAL;
-    if (head_dim != DH || L > 256) return MQ_EUNSUPPORTED;
+    if (head_dim != DH) return MQ_EUNSUPPORTED;  // any L: sequences beyond 256 keys loop over key blocks
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(B * heads), (unsigned)((L + 127) / 128));
     const unsigned nthr = 64u * (unsigned)(L >= 97 ? 4 : (L + 31) / 32);  // one wave per 32 queries (short sequences: fewer waves)
-#define MQ_ATT(NKT)                                                                                                   \
+#define MQ_ATT(NKT, MULTI)                                                                                                   \
     {                                                                                                                 \
         const size_t lds = (size_t)(32 * NKT) * (65 + 64 + 1) * 4 > (size_t)4 * 32 * 65 * 4 ? (size_t)(32 * NKT) * (65 + 64 + 1) * 4 : (size_t)4 * 32 * 65 * 4; \
-        ENC_HIP(hipFuncSetAttribute((const void*)attention_mfma_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(attention_mfma_kernel<NKT>, grid, dim3(nthr), lds, st, qkv_dev, (const long long*)attention_mask_dev,    \
+        ENC_HIP(hipFuncSetAttribute((const void*)attention_mfma_kernel<NKT, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((attention_mfma_kernel<NKT, MULTI>), grid, dim3(nthr), lds, st, qkv_dev, (const long long*)attention_mask_dev,    \
                            out_dev, (unsigned short*)out_h_dev, (unsigned short*)out_l_dev, L, heads, scale, causal ? 1 : 0); \
     }
-#define MQ_ATT3(NKT)                                                                                                  \
+#define MQ_ATT3(NKT, MULTI)                                                                                                  \
     {                                                                                                                 \
         const size_t need = (size_t)(32 * NKT) * 128 * 2 + (size_t)64 * (32 * NKT) * 2 * 2 + (size_t)(32 * NKT) * 4;    \
         const size_t lds = need > (size_t)4 * 32 * 65 * 4 ? need : (size_t)4 * 32 * 65 * 4;                           \
-        ENC_HIP(hipFuncSetAttribute((const void*)attention_x3_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(attention_x3_kernel<NKT>, grid, dim3(nthr), lds, st, qkv_dev, (const long long*)attention_mask_dev,    \
+        ENC_HIP(hipFuncSetAttribute((const void*)attention_x3_kernel<NKT, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((attention_x3_kernel<NKT, MULTI>), grid, dim3(nthr), lds, st, qkv_dev, (const long long*)attention_mask_dev,    \
                            out_dev, (unsigned short*)out_h_dev, (unsigned short*)out_l_dev, L, heads, scale, causal ? 1 : 0); \
     }
     if (bf16x3) {
         if (((uintptr_t)qkv_dev & 15) || (heads * DH) % 4) return MQ_EINVAL;  // 16-byte query loads
-        if (L <= 64) MQ_ATT3(2)
-        else if (L <= 128) MQ_ATT3(4)
-        else MQ_ATT3(8)
+        if (L <= 64) MQ_ATT3(2, false)
+        else if (L <= 128) MQ_ATT3(4, false)
+        else if (L <= 256) MQ_ATT3(8, false)
+        else MQ_ATT3(8, true)
     } else {
-        if (L <= 64) MQ_ATT(2)
-        else if (L <= 128) MQ_ATT(4)
-        else MQ_ATT(8)
+        if (L <= 64) MQ_ATT(2, false)
+        else if (L <= 128) MQ_ATT(4, false)
+        else if (L <= 256) MQ_ATT(8, false)
+        else MQ_ATT(8, true)
     }
 #undef MQ_ATT
 #undef MQ_ATT3
