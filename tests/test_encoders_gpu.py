@@ -432,6 +432,31 @@ def test_eca_shipped_shape_no_faces_one_image_feature():
     assert out["last_hidden_state"].shape == (B, L + 1, cfg["hidden_size"]) and len(out["hidden_states"]) == cfg["num_hidden_layers"] + 1
 
 
+def test_eca_with_the_shipped_max_length_text_plus_faces_plus_image():
+    """experiments/ir/viquae/eca/embedding/kb_config.json pads the text to 256 tokens; with 4 face slots and one image
+    token the attention runs over 261 keys: more than one key block of the kernels."""
+    from oracle import encoders as oe
+    from viquae_amd import encoders as E
+    cfg = dict(oe.MM_TINY, max_position_embeddings=256, n_faces=4, image_kwargs={"clip-RN50": {"input_dim": 96}})
+    state = oe.seeded_state(oe.eca_param_shapes(cfg), 62)
+    rng = np.random.default_rng(62)
+    B, L, F = 3, 256, 4
+    ids = rng.integers(1, cfg["vocab_size"], (B, L)).astype(np.int64)
+    mask = (np.arange(L)[None] < np.array([256, 140, 17])[:, None]).astype(np.int64)
+    img = rng.standard_normal((B, 1, 96)).astype(np.float32)
+    face = rng.standard_normal((B, 1, F, cfg["face_kwargs"]["face_dim"])).astype(np.float32) if "face_kwargs" in cfg else rng.standard_normal((B, 1, F, 64)).astype(np.float32)
+    bbox = rng.standard_normal((B, 1, F, 7)).astype(np.float32)
+    fmask = (np.arange(F)[None, None] < np.array([4, 0, 2])[:, None, None]).astype(np.int64)
+    want = oe.eca_forward(state, cfg, ids, None, mask, face, bbox, fmask, {"clip-RN50": (img, np.ones((B, 1), np.int64))})
+    model = E.ECAEncoder.from_state_dict(cfg, state).to("cuda").eval()
+    out = model(text_inputs={"input_ids": _cuda(ids), "attention_mask": _cuda(mask)},
+                face_inputs={"face": _cuda(face), "bbox": _cuda(bbox), "attention_mask": _cuda(fmask)},
+                image_inputs={"clip-RN50": {"input": _cuda(img), "attention_mask": torch.ones((B, 1), dtype=torch.long, device="cuda")}},
+                output_hidden_states=True)
+    assert out["last_hidden_state"].shape[1] == L + F + 1
+    assert np.abs(out["pooler_output"].cpu().numpy() - want).max() < TOL
+
+
 def _padded_batch(rng, cfg, B, L, lo=3):
     lens = np.clip(rng.normal(0.5 * L, 0.15 * L, B).astype(int), lo, L)
     lens[0], lens[1] = L, lo
