@@ -312,8 +312,9 @@ def main():
                 d = bench_encoders.dpr_throughput(B=2048, L=100, steps=2)
                 try:
                     dp = bench_encoders.dpr_padded_throughput()
+                    dq = bench_encoders.dpr_padded_throughput(mean_len=16, std_len=5)
                 except Exception as e:
-                    dp = {"error": repr(e)}
+                    dp = dq = {"error": repr(e)}
                 c = bench_encoders.clip_throughput(B=3072, steps=2)
                 tt = bench_encoders.clip_text_throughput(B=2048, L=77, steps=2)
                 try:
@@ -345,6 +346,7 @@ def main():
                             "algorithmic_tflops": round(d["tflops"], 2), "x_f32_mfma_peak": round(d["tflops"] / PEAK_F32_MFMA_TFLOPS, 3),
                             "executed_bf16_mfma_frac": round(3 * d["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)},
                     "dpr_reference_padding": dict(dp, workload="DPR bert-base, 2048 passages padded to max_length 256 as the reference's tokenization_kwargs do (synthetic lengths ~N(130,30)): padding-aware forward vs dense, identical outputs"),
+                    "dpr_questions_reference_padding": dict(dq, workload="same with question-like lengths ~N(16,5), padded to 256 (experiments/ir/viquae/dpr/questions/config.json)"),
                     "images_encoded_per_s": round(c["images_per_s"], 1),
                     "clip": {"workload": "CLIP ViT-B/32, 3072 x 224x224 synthetic images per batch", "ms_per_batch": round(c["ms_per_batch"], 2),
                              "algorithmic_tflops": round(c["tflops"], 2), "x_f32_mfma_peak": round(c["tflops"] / PEAK_F32_MFMA_TFLOPS, 3),

@@ -513,7 +513,11 @@ def test_padding_plan_declines_masks_it_cannot_skip():
     ok = (np.arange(64)[None] < np.random.default_rng(0).integers(4, 40, 8000)[:, None]).astype(np.int64)
     plan = encoders._length_buckets(_cuda(ok))
     assert plan is not None and 1 <= len(plan) <= 8
-    assert encoders._length_buckets(_cuda(ok[:100])) is None   # small batch: not worth splitting
+    small = encoders._length_buckets(_cuda(ok[:100]))          # small batch: ONE group, cut at its longest length
+    assert small is not None and len(small) == 1 and small[0][1] == int(ok[:100].sum(1).max()) < 64
+    questions = (np.arange(256)[None] < np.random.default_rng(1).integers(8, 30, 2048)[:, None]).astype(np.int64)
+    plan = encoders._length_buckets(_cuda(questions))          # questions padded to 256 (dpr/questions/config.json)
+    assert plan is not None and max(L for _, L in plan) < 32
     assert encoders._length_buckets(None) is None
 
 

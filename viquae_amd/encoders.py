@@ -373,9 +373,9 @@ def _length_buckets(attention_mask, max_buckets=8):
         return None
     # a group must still fill the chip (its GEMMs have real_tokens / 256 row tiles): ~32 k tokens each, else the dense
     # forward of a small batch is already one wave of workgroups and splitting it only adds launches
-    nb = int(min(max_buckets, lens.sum() // 32768))
-    if nb < 1 or (nb == 1 and int(lens.max()) > 0.9 * L):
-        return None
+    nb = int(max(1, min(max_buckets, lens.sum() // 32768)))
+    if nb == 1 and int(lens.max()) > 0.9 * L:
+        return None  # one group at (nearly) the padded length: nothing to gain
     order = np.argsort(lens, kind="stable")
     plan = []
     for part in _partition_by_length(lens[order], nb):
