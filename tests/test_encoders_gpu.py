@@ -455,6 +455,23 @@ def test_eca_with_the_shipped_max_length_text_plus_faces_plus_image():
                 output_hidden_states=True)
     assert out["last_hidden_state"].shape[1] == L + F + 1
     assert np.abs(out["pooler_output"].cpu().numpy() - want).max() < TOL
+    # short texts padded to 256: the attended tokens (text | faces | image) are compacted to the front and the batch runs
+    # at its longest real length (padding-aware forward); same vectors up to fp32 summation order
+    mask2 = (np.arange(L)[None] < np.array([120, 60, 17])[:, None]).astype(np.int64)
+    want2 = oe.eca_forward(state, cfg, ids, None, mask2, face, bbox, fmask, {"clip-RN50": (img, np.ones((B, 1), np.int64))})
+    args = dict(text_inputs={"input_ids": _cuda(ids), "attention_mask": _cuda(mask2)},
+                face_inputs={"face": _cuda(face), "bbox": _cuda(bbox), "attention_mask": _cuda(fmask)},
+                image_inputs={"clip-RN50": {"input": _cuda(img), "attention_mask": torch.ones((B, 1), dtype=torch.long, device="cuda")}})
+    calls = []
+    orig = E._pooled_by_groups
+    E._pooled_by_groups = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        fast = model(**args)["pooler_output"].cpu().numpy()
+    finally:
+        E._pooled_by_groups = orig
+    assert calls, "the compaction path did not run"
+    dense = model(output_hidden_states=True, **args)["pooler_output"].cpu().numpy()
+    assert np.abs(fast - want2).max() < TOL and np.abs(fast - dense).max() < 1e-5
 
 
 def _padded_batch(rng, cfg, B, L, lo=3):

@@ -440,44 +440,54 @@ class _DPREncoder(_HipEncoder):
         return out
 
     def _forward_buckets(self, plan, input_ids, attention_mask, token_type_ids):
-        """Padding-aware forward: the batch is cut into a few groups of similar length, each run dense at ITS longest
-        length.  The reference pads every passage to 256 tokens (experiments/ir/viquae/dpr/passages/config.json:11-14:
-        ``padding: max_length``) although a 100-word passage has ~130: about half of the dense work is padding.  Every
-        operation is row-wise except attention, where a masked key contributes exactly 0 to every sum and never to the
-        row maximum -- so the pooled [CLS] vectors are bit-identical to the dense forward (asserted in the tests)."""
-        B = input_ids.shape[0]
-        dev = input_ids.device
-        out = torch.empty((B, self.bert_model.hidden), dtype=torch.float32, device=dev)
-        # groups alternate between two side streams: the tail of one group's GEMM (a partial wave of workgroups) is
-        # filled by the other group's kernels
-        main = torch.cuda.current_stream(dev)
-        streams = _side_streams(dev, min(int(os.environ.get("MQ_ENC_GROUP_STREAMS", "2")), len(plan)))
-        ready = torch.cuda.Event()
-        ready.record(main)
-        def run(idx, Li):
+        return _pooled_by_groups(self.bert_model, plan, input_ids, attention_mask, token_type_ids)
+
+
+def _pooled_by_groups(bert, plan, input_ids, attention_mask, token_type_ids=None, embeddings=None):
+    """Padding-aware forward: the batch is cut into a few groups of similar length, each run dense at ITS longest
+    length.  The reference pads every passage to 256 tokens (experiments/ir/viquae/dpr/passages/config.json:11-14:
+    ``padding: max_length``) although a 100-word passage has ~130: about half of the dense work is padding.  Every
+    operation is row-wise except attention, where a masked key contributes exactly 0 to every sum and never to the
+    row maximum -- so the pooled [CLS] vectors are bit-identical to the dense forward (asserted in the tests).
+    ``embeddings`` [B, L, H] (ECA: text + face + image tokens) replaces the token ids when given."""
+    ref = embeddings if embeddings is not None else input_ids
+    B, dev = ref.shape[0], ref.device
+    out = torch.empty((B, bert.hidden), dtype=torch.float32, device=dev)
+    # groups alternate between two side streams: the tail of one group's GEMM (a partial wave of workgroups) is
+    # filled by the other group's kernels
+    main = torch.cuda.current_stream(dev)
+    streams = _side_streams(dev, min(int(os.environ.get("MQ_ENC_GROUP_STREAMS", "2")), len(plan)))
+    ready = torch.cuda.Event()
+    ready.record(main)
+
+    def run(idx, Li):
+        mask = attention_mask.index_select(0, idx)[:, :Li].contiguous()
+        if embeddings is not None:
+            h = embeddings.index_select(0, idx)[:, :Li].contiguous()
+            last, _ = bert._layers(h.view(-1, bert.hidden), None, mask, idx.numel(), Li, False, cls_only=True)
+        else:
             ids = input_ids.index_select(0, idx)[:, :Li]
             tt = token_type_ids.index_select(0, idx)[:, :Li] if token_type_ids is not None else None
-            mask = attention_mask.index_select(0, idx)[:, :Li]
-            last, _ = self.bert_model(ids, tt, mask, False, cls_only=True)
-            out.index_copy_(0, idx, last[:, 0, :])
+            last, _ = bert(ids, tt, mask, False, cls_only=True)
+        out.index_copy_(0, idx, last[:, 0, :])
 
-        first = 0
-        warm_key = (str(dev), self.bert_model.w_word.data_ptr(), _gemm_mode())
-        if self.__dict__.get("_weights_split") != warm_key:
-            # the (hi, lo) weight splits are built lazily by the first forward: build them on the caller's stream before
-            # two other streams start reading them
-            run(*plan[0])
-            first = 1
-            ready.record(main)
-            self.__dict__["_weights_split"] = warm_key
-        for n, (idx, Li) in enumerate(plan[first:]):
-            st = streams[n % len(streams)]
-            st.wait_event(ready)
-            with torch.cuda.stream(st):
-                run(idx, Li)
-        for st in streams:
-            main.wait_stream(st)
-        return out
+    first = 0
+    warm_key = (str(dev), bert.w_word.data_ptr(), _gemm_mode())
+    if bert.__dict__.get("_weights_split") != warm_key:
+        # the (hi, lo) weight splits are built lazily by the first forward: build them on the caller's stream before
+        # two other streams start reading them
+        run(*plan[0])
+        first = 1
+        ready.record(main)
+        bert.__dict__["_weights_split"] = warm_key
+    for n, (idx, Li) in enumerate(plan[first:]):
+        st = streams[n % len(streams)]
+        st.wait_event(ready)
+        with torch.cuda.stream(st):
+            run(idx, Li)
+    for st in streams:
+        main.wait_stream(st)
+    return out
 
 
 class DPRContextEncoder(_DPREncoder):
@@ -850,6 +860,19 @@ class ECAEncoder(_MMEmbeddings):
         h = torch.cat(parts, dim=1).contiguous()
         full_mask = torch.cat(masks, dim=1).contiguous()
         Lt = h.shape[1]
+        if not output_hidden_states and return_dict and os.environ.get("MQ_ENC_PAD_SKIP", "1") != "0" and bool((full_mask[:, 0] != 0).all()):
+            # The text is padded to max_length in the MIDDLE of the joint sequence (text | faces | images).  The layers are
+            # permutation-equivariant (positions were added by the embeddings), so the attended tokens are moved to the
+            # front in their original order ([CLS] stays row 0) and the padding-aware forward applies.  Masked keys add
+            # exact zeros, but the surviving keys sit in other MFMA k-groups: equal to the dense forward up to fp32
+            # summation order (~1e-6), not bit for bit.
+            order = torch.argsort((full_mask == 0).to(torch.int8), dim=1, stable=True)
+            cmask = torch.gather(full_mask, 1, order)
+            plan = _length_buckets(cmask)
+            if plan is not None:
+                hc = torch.gather(h, 1, order[:, :, None].expand(-1, -1, H))
+                pooled = _pooled_by_groups(bert, plan, None, cmask, embeddings=hc)
+                return ModelOutput(pooler_output=pooled, last_hidden_state=pooled[:, None, :], hidden_states=None, attentions=None)
         last, hidden = bert._layers(h.view(B * Lt, H), None, full_mask, B, Lt, output_hidden_states, cls_only=not output_hidden_states)
         pooled = last[:, 0, :]
         if not return_dict:
@@ -887,9 +910,14 @@ class IntermediateLinearFusion(_MMEmbeddings):
     def forward(self, text_inputs=None, face_inputs=None, image_inputs=None, **unused):
         mmc = self.mm
         lib = _lib.load()
-        last, _ = self.bert_model(text_inputs["input_ids"], text_inputs.get("token_type_ids"), text_inputs.get("attention_mask"),
-                                  cls_only=True)
-        pooled = last[:, 0, :].contiguous()
+        plan = _length_buckets(text_inputs.get("attention_mask"))
+        if plan is not None:
+            pooled = _pooled_by_groups(self.bert_model, plan, text_inputs["input_ids"], text_inputs["attention_mask"],
+                                       text_inputs.get("token_type_ids"))
+        else:
+            last, _ = self.bert_model(text_inputs["input_ids"], text_inputs.get("token_type_ids"),
+                                      text_inputs.get("attention_mask"), cls_only=True)
+            pooled = last[:, 0, :].contiguous()
         B, H = pooled.shape
         out = gemm_nt(pooled, self.p_w, self.p_b, None, EPI_BIAS, wsplit=self._ws("p_w"))
         fo, fmask = self._faces(face_inputs, B)
