@@ -74,3 +74,55 @@ def test_world2_sharded_equals_unsharded(tmp_path, metric, n):
     z = np.load(out)
     D, I = ok.knn(z["X"], z["Q"], 20, metric=metric)
     assert np.array_equal(z["I"], I) and np.array_equal(z["D"], D)
+
+
+# ---------------------------------------------------------------------------------------------------
+# multi-process embedding: every rank embeds its contiguous block of rows, rank 0 stitches the blocks
+# ---------------------------------------------------------------------------------------------------
+class _FakeTokenizer:
+    sep_token = "[SEP]"
+
+    def __call__(self, texts, **kw):
+        L = max(len(t) for t in texts)
+        ids = torch.zeros((len(texts), L), dtype=torch.int64)
+        for i, t in enumerate(texts):
+            ids[i, :len(t)] = torch.tensor([ord(c) for c in t])
+        return {"input_ids": ids, "attention_mask": (ids != 0).to(torch.int64)}
+
+
+class _FakeEncoder:
+    """A callable with the encoder's surface: the 'embedding' is a function of the text only."""
+
+    def __call__(self, input_ids=None, attention_mask=None, **kw):
+        x = input_ids.to(torch.float32)
+        return {"pooler_output": torch.stack([x.sum(1), (x * x).sum(1), attention_mask.sum(1).float()], dim=1)}
+
+
+def _embed_worker(rank, world, port, src, dst):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from viquae_amd.ir.embedding import dataset_embed
+        out = dataset_embed(src, output_path=dst, model=_FakeEncoder(), tokenizer=_FakeTokenizer(), key="passage",
+                            save_as="emb", output_key="pooler_output", map_kwargs={"batch_size": 4})
+        assert len(out) == 23 and "emb" in out.column_names   # every rank gets the stitched dataset back
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_dataset_embed_stitches_rank_blocks_in_order(tmp_path):
+    import datasets
+    from viquae_amd.ir.embedding import dataset_embed
+    datasets.disable_progress_bars()
+    texts = ["passage number %d %s" % (i, "x" * (i % 7)) for i in range(23)]
+    src = str(tmp_path / "kb")
+    datasets.Dataset.from_dict({"passage": texts, "id": list(range(23))}).save_to_disk(src)
+    single = dataset_embed(src, output_path=str(tmp_path / "single"), model=_FakeEncoder(), tokenizer=_FakeTokenizer(),
+                           key="passage", save_as="emb", output_key="pooler_output", map_kwargs={"batch_size": 4})
+    dst = str(tmp_path / "multi")
+    mp.spawn(_embed_worker, args=(2, _free_port(), src, dst), nprocs=2, join=True)
+    multi = datasets.load_from_disk(dst)
+    assert multi["id"] == single["id"] == list(range(23))
+    assert np.array_equal(np.asarray(multi["emb"], np.float32), np.asarray(single["emb"], np.float32))
+    assert not [p for p in os.listdir(tmp_path) if "mq_rank" in p]   # the per-rank blocks are cleaned up

@@ -65,7 +65,13 @@ def dataset_embed(dataset_path, map_kwargs={}, model_kwargs={}, transform_kwargs
         dataset = dataset.remove_columns([c for c in dataset.column_names if c not in keep_columns])
     fn_kwargs.update(get_model_and_transform(model_kwargs=model_kwargs, transform_kwargs=transform_kwargs))
     fn_kwargs["pool"] = None if processes is None else Pool(processes=processes)
+    from ..ir.embedding import _rank_shard, _save_rank_shards, process_rank_and_world
+    rank, world = process_rank_and_world()
+    if world > 1:  # one process per GPU: every rank embeds its contiguous block of rows (see viquae_amd/ir/embedding.py)
+        dataset = _rank_shard(dataset, rank, world)
     dataset = dataset.map(embed, batched=True, fn_kwargs=fn_kwargs, **map_kwargs)
+    if world > 1:
+        return _save_rank_shards(dataset, dataset_path, output_path, rank, world)
     return _save(dataset, dataset_path, output_path)
 
 
@@ -96,4 +102,6 @@ if __name__ == "__main__":
     ap.add_argument("--output")
     a = ap.parse_args()
     cfg = json.load(open(a.config)) if a.config else {}
+    from ..ir.embedding import init_process_group_from_env
+    init_process_group_from_env()   # torchrun: one process per GPU, every rank embeds its block of rows
     dataset_embed(a.dataset, output_path=a.output, **cfg)

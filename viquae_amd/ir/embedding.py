@@ -145,8 +145,66 @@ def dataset_embed(dataset_path, map_kwargs={}, output_path=None, keep_columns=No
         dataset = dataset.add_column(qe_predictions_key, qe_predictions)
     fn_kwargs["run"] = run
     fn_kwargs["qe_predictions_key"] = qe_predictions_key
+    rank, world = process_rank_and_world()
+    if world > 1:
+        dataset = _rank_shard(dataset, rank, world)
     dataset = dataset.map(embed, batched=True, fn_kwargs=fn_kwargs, **map_kwargs)
+    if world > 1:
+        return _save_rank_shards(dataset, dataset_path, output_path, rank, world)
     return _save(dataset, dataset_path, output_path)
+
+
+# ---------------------------------------------------------------------------------------------------
+# One process per GPU (encoding shards by rows, the weights are replicas, no collective on the data
+# path).  The reference wraps the model in nn.DataParallel (meerqat/ir/embedding.py:288); here every rank of an initialised
+# torch.distributed group embeds ITS contiguous block of rows, writes it next to the output, and rank 0 stitches the blocks
+# back together in order once everybody is done (two barriers, no tensors exchanged).
+# ---------------------------------------------------------------------------------------------------
+def init_process_group_from_env():
+    """Under ``python -m torch.distributed.run --nproc-per-node N -m viquae_amd.ir.embedding ...``: bind this process to
+    GPU LOCAL_RANK and join the group (RCCL on GPUs); a plain single-process call does nothing."""
+    import os
+    import torch.distributed as dist
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.init_process_group("gloo")
+
+
+def process_rank_and_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _rank_shard(dataset, rank, world):
+    from datasets import DatasetDict
+    if isinstance(dataset, DatasetDict):
+        raise NotImplementedError("multi-process embedding of a DatasetDict: embed its splits one by one")
+    return dataset.shard(num_shards=world, index=rank, contiguous=True)
+
+
+def _save_rank_shards(shard, dataset_path, output_path, rank, world):
+    import shutil
+    import torch.distributed as dist
+    from datasets import concatenate_datasets, load_from_disk
+    base = str(output_path).rstrip("/")
+    part = lambda r: f"{base}.mq_rank{r:03d}"  # noqa: E731
+    shutil.rmtree(part(rank), ignore_errors=True)
+    shard.save_to_disk(part(rank))
+    dist.barrier()
+    whole = None
+    if rank == 0:
+        whole = _save(concatenate_datasets([load_from_disk(part(r)) for r in range(world)]), dataset_path, output_path)
+        for r in range(world):
+            shutil.rmtree(part(r), ignore_errors=True)
+    dist.barrier()
+    return whole if rank == 0 else load_from_disk(output_path)
 
 
 
@@ -171,6 +229,7 @@ def main(dataset_path, config_path, kb_path=None, output_path=None):
     """The reference's ``python -m meerqat.ir.embedding <dataset> <config> [--kb --output]``."""
     from datasets import load_from_disk
     from ..data.loading import load_pretrained_in_kwargs
+    init_process_group_from_env()
     from ..utils import device
     with open(config_path, "rt") as file:
         config = load_pretrained_in_kwargs(json.load(file))
