@@ -705,7 +705,7 @@ int num_cus() {
 }
 
 struct Geometry {
-    int nqt, S, dpad, qpx;
+    int nqt, S, dpad, qpx, qpx_screen;
     int64_t nqpad, nchunks;
     size_t off_qp, off_qn, off_qtmp, off_lists, total;
     // screened path extras
@@ -732,6 +732,7 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
     // each XCD `qpx` query tiles so that their Q panels (qpx * 256 * dpad * 4 B, re-read once per KB
     // chunk) stay in that XCD's 4 MiB L2, and let the XCDs that share those query tiles split the slabs.
     g.qpx = 0;
+    g.qpx_screen = 0;
     {
         int want = 0;
         const char* e = getenv("MQ_KNN_QPX");
@@ -742,9 +743,12 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
             if (ngroups > 8 || 8 % ngroups) continue;
             const int xpg = 8 / ngroups;
             if (g.S % xpg) continue;
-            if (want > 0) { if (q == want) g.qpx = q; continue; }
-            // default: the largest Q working set that still leaves half of L2 to the KB stream
+            if (want > 0) { if (q == want) g.qpx = g.qpx_screen = q; continue; }
+            // default: the largest Q working set that still leaves half of L2 to the KB stream (the screening scan's
+            // queries are bf16: twice as many tiles fit, and every XCD group then streams a smaller part of the shard:
+            // 4 tiles per XCD instead of 2 took 2.7 % off the 4096-query scan)
             if ((size_t)q * TQ * g.dpad * 4 <= (size_t)2 << 20 || g.qpx == 0) g.qpx = q;
+            if ((size_t)q * TQ * g.dpad * 2 <= (size_t)2 << 20 || g.qpx_screen == 0) g.qpx_screen = q;
         }
     }
     size_t o = 0;
@@ -1003,7 +1007,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         a.Xb = bf16_dev; a.Qb = Qb; a.margin = margin; a.pools = pools; a.pcount = pcount; a.ovf = ovf; a.gthr = (unsigned*)(ws + g.off_gthr);
         a.smax = (unsigned*)(ws + g.off_smax); a.ms = g.ms; a.sps = g.sps;
         a.dbg = getenv("MQ_DBG_PTR") ? (unsigned long long*)strtoull(getenv("MQ_DBG_PTR"), nullptr, 0) : nullptr;
-        a.N = N; a.dp = dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx; a.nchunks = g.nchunks;
+        a.N = N; a.dp = dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx_screen; a.nchunks = g.nchunks;
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
         MQ_HIP(hipFuncSetAttribute((const void*)screen_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_TOTAL));
         hipLaunchKernelGGL(screen_scan_kernel, dim3((unsigned)(g.nqt * g.S)), dim3(1024), S_LDS_TOTAL, st, a);
