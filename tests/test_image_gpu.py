@@ -128,3 +128,28 @@ def test_image_embed_seam_runs_the_device_transform(tmp_path, monkeypatch):
     want = oe.clip_vision_forward(state, cfg, px)
     got = np.stack([out["clip"][i] for i in (0, 2, 3)])
     assert np.abs(got - want).max() < 1e-3
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_geometries_and_configs_fuzz(seed):
+    """Random image sizes, shortest-edge / exact resize targets, square and non-square crop windows, both filters, in one
+    ragged batch per seed: bit-equal to the Pillow / transformers restatement."""
+    from oracle import image as oi
+    from viquae_amd.image.preprocess import CLIPImageProcessorHIP
+    rng = np.random.default_rng(1000 + seed)
+    kind = int(rng.integers(2, 4))
+    if seed % 2 == 0:
+        size = int(rng.integers(16, 260))
+        crop = (int(rng.integers(1, size + 1)), int(rng.integers(1, size + 1)))
+        hip_size, o_size = {"shortest_edge": size}, size
+    else:
+        size = (int(rng.integers(8, 200)), int(rng.integers(8, 300)))
+        crop = (int(rng.integers(1, size[0] + 1)), int(rng.integers(1, size[1] + 1)))
+        hip_size, o_size = {"height": size[0], "width": size[1]}, size
+    ims = [rng.integers(0, 256, (int(h), int(w), 3), dtype=np.uint8) for h, w in rng.integers(1, 700, (9, 2))]
+    ims.append(np.full((33, 47, 3), 255, np.uint8))   # saturated: overshoot clipping on every tap
+    ims.append(np.zeros((5, 900, 3), np.uint8))
+    p = CLIPImageProcessorHIP(size=hip_size, crop_size={"height": crop[0], "width": crop[1]}, resample=kind)
+    got = p(ims)["pixel_values"].cpu().numpy()
+    want = oi.clip_preprocess(ims, size=o_size, crop=crop, kind=kind)
+    assert got.shape == want.shape and np.array_equal(got, want)
