@@ -74,7 +74,16 @@ def load_image(file_name):
     return image
 
 
-def load_image_batch(file_names, pool=None):
+def load_image_array(file_name):
+    """``load_image`` as a uint8 [H, W, 3] array (what the device-side image processor packs): in a process pool the
+    PIL -> numpy conversion (0.6 ms per 500 x 375 image) then runs in the workers, and an array pickles as one memcpy."""
+    import numpy as np
+    image = load_image(file_name)
+    return None if image is None else np.asarray(image)
+
+
+def load_image_batch(file_names, pool=None, as_arrays=False):
+    loader = load_image_array if as_arrays else load_image
     if pool is None:
-        return [load_image(file_name) for file_name in file_names]
-    return pool.map(load_image, file_names)
+        return [loader(file_name) for file_name in file_names]
+    return pool.map(loader, file_names)

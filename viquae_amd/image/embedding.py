@@ -27,7 +27,7 @@ def get_model_and_transform(model_kwargs={}, transform_kwargs={}):
 def embed(batch, model, transform, save_as="image_embedding", image_key="image", call=None, pool=None):
     """Loads ``batch[image_key]`` (file names), preprocesses, encodes; ``batch[save_as]`` gets one
     vector per image and ``None`` where the image could not be read."""
-    images = load_image_batch(batch[image_key], pool=pool)
+    images = load_image_batch(batch[image_key], pool=pool, as_arrays=getattr(transform, "on_device", False))
     kept = [i for i, image in enumerate(images) if image is not None]
     output = [None] * len(images)
     if not kept:
