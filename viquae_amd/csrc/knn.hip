@@ -114,11 +114,13 @@ __device__ __forceinline__ void load_tile64(const float* __restrict__ src, int64
 // one workgroup (256 threads) per 64-row panel
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src, int64_t n, int d, int dpad,
                                                         int64_t row_offset, int l2norm, float* __restrict__ packed,
-                                                        float* __restrict__ sqnorm) {
+                                                        float* __restrict__ sqnorm, const int* __restrict__ only_tiles = nullptr) {
     __shared__ float tile[64][65];
     __shared__ float nrm[64];
     const int t = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * PANEL;  // within this call's rows
+    // screened search: the panel copy of the queries only serves the exact-scan fallback of flagged query tiles
+    if (only_tiles && !only_tiles[(row0 + row_offset) / TQ]) return;
     const int64_t panel = (row_offset / PANEL) + blockIdx.x;
     if (l2norm) {
         float acc = 0.f;
@@ -761,14 +763,15 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
     g.off_qb = o;     o += (size_t)round_up((int64_t)g.nqpad * g.dp * 2, 256);
     g.off_margin = o; o += (size_t)g.nqpad * 4;
     g.off_pcount = o; o += (size_t)g.nqt * g.S * TQ * NSL * 4;
+    g.sps = g.S <= SMAX_SLOTS / 16 ? 16 : (SMAX_SLOTS / g.S > 0 ? SMAX_SLOTS / g.S : 1);
+    g.ms = g.S * g.sps < SMAX_SLOTS ? g.S * g.sps : SMAX_SLOTS;
+    // ovf | gthr | smax are zeroed by ONE memset per search: keep them adjacent
     g.off_ovf = o;    o += (size_t)round_up((int64_t)g.nqt * 4, 256);
     g.off_gthr = o;   o += (size_t)g.nqpad * 4;
+    g.off_smax = o;   o += (size_t)g.nqpad * g.ms * 4;
     g.off_cand = o;   o += nq1 * RMAX * 4;
     g.off_ckeys = o;  o += nq1 * RMAX * 8;
     g.off_ccount = o; o += (size_t)round_up((int64_t)nq1 * 4, 256);
-    g.sps = g.S <= SMAX_SLOTS / 16 ? 16 : (SMAX_SLOTS / g.S > 0 ? SMAX_SLOTS / g.S : 1);
-    g.ms = g.S * g.sps < SMAX_SLOTS ? g.S * g.sps : SMAX_SLOTS;
-    g.off_smax = o;   o += (size_t)g.nqpad * g.ms * 4;
     g.total = round_up((int64_t)o, 256);
     return g;
 }
@@ -985,13 +988,17 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         MQ_HIP(hipGetLastError());
         q_rm = qtmp;
     }
-    MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
-    MQ_HIP(hipMemsetAsync(Qb, 0, (size_t)g.nqpad * dp * 2, st));
-    MQ_HIP(hipMemsetAsync(ovf, 0, (size_t)round_up((int64_t)g.nqt * 4, 256) + (size_t)g.nqpad * 4, st));  // ovf + gthr
-    MQ_HIP(hipMemsetAsync(ws + g.off_smax, 0, (size_t)g.nqpad * g.ms * 4, st));
-    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((nq + PANEL - 1) / PANEL)), dim3(256), 0, st, q_rm, (int64_t)nq, d,
-                       g.dpad, (int64_t)0, 0, Qp, qn);
-    MQ_HIP(hipGetLastError());
+    // The fp32 panel copy of the queries (+ ||q||^2) serves the exact-scan fallback -- and, for the L2 metric, the
+    // re-scoring (||q||^2).  With the inner product it is made after the screened pipeline, for flagged tiles only.
+    if (l2) {
+        MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
+        hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((nq + PANEL - 1) / PANEL)), dim3(256), 0, st, q_rm, (int64_t)nq, d,
+                           g.dpad, (int64_t)0, 0, Qp, qn, (const int*)nullptr);
+        MQ_HIP(hipGetLastError());
+    }
+    if (g.nqpad > nq)  // bf16 rows of the padding queries of the last tile
+        MQ_HIP(hipMemsetAsync(Qb + (size_t)nq * dp, 0, (size_t)(g.nqpad - nq) * dp * 2, st));
+    MQ_HIP(hipMemsetAsync(ovf, 0, g.off_smax + (size_t)g.nqpad * g.ms * 4 - g.off_ovf, st));  // ovf + gthr + smax
     {
         const int64_t quads = (int64_t)nq * (dp / 4);
         hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, q_rm, (int64_t)nq, d, dp, Qb,
@@ -1027,6 +1034,12 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     // 5. query tiles whose bounded buffers overflowed are recomputed by the exact scan (no-op otherwise:
     //    every workgroup of an unflagged tile returns at once)
     {
+        if (!l2) {
+            MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
+            hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((nq + PANEL - 1) / PANEL)), dim3(256), 0, st, q_rm, (int64_t)nq, d,
+                               g.dpad, (int64_t)0, 0, Qp, qn, (const int*)ovf);
+            MQ_HIP(hipGetLastError());
+        }
         ScanArgs a;
         a.Xp = packed_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = pools;
         a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = nullptr; a.only = ovf;
