@@ -175,3 +175,29 @@ def test_length_partition_is_optimal_and_covers_everything():
     got = _partition_by_length(small, 3)
     assert sum((p.stop - p.start) * small[p].max() for p in got) == best
     assert _partition_by_length(np.array([5, 5, 5]), 4) == [slice(0, 3)]
+
+
+def test_padding_plan_host_logic_on_cpu_tensors():
+    """_length_buckets is plain tensor logic: right-padded masks with something to cut get a plan that covers every
+    sequence once, each group cut at its longest length; everything else declines."""
+    import torch
+    from viquae_amd.encoders import _length_buckets
+    rng = np.random.default_rng(0)
+    lens = rng.integers(8, 200, 4000)
+    mask = torch.from_numpy((np.arange(256)[None] < lens[:, None]).astype(np.int64))
+    plan = _length_buckets(mask)
+    assert plan is not None and 1 <= len(plan) <= 8
+    seen = np.concatenate([idx.numpy() for idx, _ in plan])
+    assert sorted(seen.tolist()) == list(range(4000))
+    for idx, L in plan:
+        assert L == lens[idx.numpy()].max()
+    assert _length_buckets(torch.ones((4000, 256), dtype=torch.int64)) is None           # nothing to cut
+    assert _length_buckets(mask.flip(1)) is None                                         # left padding
+    assert _length_buckets(None) is None
+    few = _length_buckets(mask[:50])                                                      # small batch: one group at its longest
+    assert few is not None and len(few) == 1 and few[0][1] == lens[:50].max()
+    os.environ["MQ_ENC_PAD_SKIP"] = "0"
+    try:
+        assert _length_buckets(mask) is None
+    finally:
+        del os.environ["MQ_ENC_PAD_SKIP"]
