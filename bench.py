@@ -312,7 +312,7 @@ def main():
                 d = bench_encoders.dpr_throughput(B=2048, L=100, steps=2)
                 try:
                     dp = bench_encoders.dpr_padded_throughput()
-                    dq = bench_encoders.dpr_padded_throughput(mean_len=16, std_len=5)
+                    dq = bench_encoders.dpr_padded_throughput(mean_len=16, std_len=5, steps=5)
                 except Exception as e:
                     dp = dq = {"error": repr(e)}
                 c = bench_encoders.clip_throughput(B=3072, steps=2)

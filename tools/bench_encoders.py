@@ -111,6 +111,7 @@ def dpr_padded_throughput(B=2048, L=256, mean_len=130, std_len=30, steps=2, devi
     ids = torch.randint(1000, 30000, (B, L), generator=g, device=device) * mask
     tt = torch.zeros((B, L), dtype=torch.int64, device=device)
     run = lambda: model(input_ids=ids, token_type_ids=tt, attention_mask=mask)["pooler_output"]  # noqa: E731
+    run()  # builds the weight splits and the side streams
     t_skip = time_it(run, steps)
     a = run()
     os.environ["MQ_ENC_PAD_SKIP"] = "0"
