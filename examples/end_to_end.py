@@ -55,10 +55,19 @@ def main():
     # text embeddings through the reference's embed()
     kb = text_embedding.embed({"passage": passages}, ctx, tok, key="passage", save_as="dpr", output_key="pooler_output")
     qs = text_embedding.embed({"input": questions}, qst, tok, key="input", save_as="dpr_q", output_key="pooler_output")
-    # image embeddings (synthetic pixels straight into the tower: the PIL / feature-extractor step is host code)
+    # image embeddings: decoded RGB images of ragged sizes (synthetic uint8 arrays standing in for PIL images) through
+    # the device-side CLIP image processor (Pillow-exact bicubic resize + centre crop + normalise, csrc/image.hip), then
+    # the vision tower -- what viquae_amd.image.embedding.embed does with the files of a dataset
+    from viquae_amd.image.preprocess import CLIPImageProcessorHIP
+    processor = CLIPImageProcessorHIP(size=64, crop_size=64)
+
+    def fake_images(n):
+        sizes = rng.integers(48, 160, (n, 2))
+        return [rng.integers(0, 256, (int(h), int(w), 3), dtype=np.uint8) for h, w in sizes]
+
     with torch.no_grad():
-        kb_img = clip.get_image_features(pixel_values=torch.from_numpy(rng.standard_normal((n_kb, 3, 64, 64)).astype(np.float32)).cuda())
-        q_img = clip.get_image_features(pixel_values=torch.from_numpy(rng.standard_normal((n_q, 3, 64, 64)).astype(np.float32)).cuda())
+        kb_img = torch.cat([clip.get_image_features(**processor(fake_images(1000))) for _ in range(n_kb // 1000)])
+        q_img = clip.get_image_features(**processor(fake_images(n_q)))
     with tempfile.TemporaryDirectory() as tmp:
         kb_path = os.path.join(tmp, "kb")
         datasets.Dataset.from_dict({"passage": passages, "dpr": list(kb["dpr"]), "clip": list(kb_img.cpu().numpy())}).save_to_disk(kb_path)
