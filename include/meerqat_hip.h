@@ -97,8 +97,13 @@ int mq_knn_search_f32_ev(const float *packed_dev, const float *sqnorm_dev, int64
  * The bf16 copy is metric-specific: pass the same `metric` to the three calls.  Extra shard buffers:
  *   rowmajor_dev [N, d] fp32  : the stored rows in row-major order (re-scoring operand)
  *   bf16_dev                  : mq_knn_screen_bytes(N, d, metric) bytes, bf16 copy (rows padded to 256, d (+2) to 64)
- *   xstats_dev                : two floats kept by mq_knn_screen_prepare (zero them before its first call):
- *                               max ||x||^2 and max ||x - bf16(x)||^2 over the shard, the inputs of the error bound
+ *   xstats_dev                : THREE floats kept by mq_knn_screen_prepare (zero them before its first call):
+ *                               max ||x||^2, max ||xc - bf16(xc)||^2 and max ||xc||^2 over the shard (xc = x - centre),
+ *                               the inputs of the error bound
+ *   center_dev                : NULL, or d floats subtracted from every row before the bf16 rounding (inner product
+ *                               only; ANY fixed vector is valid: q.(x - c) ranks the rows of a query like q.x, and for
+ *                               embeddings with a large shared component the screen's margin then follows ||x - c||);
+ *                               the same vector must be passed for every row range of a shard
  * mq_knn_screen_prepare fills rowmajor/bf16 for rows [row_offset, row_offset+n) from the panel buffer.
  * Query tiles whose bounded candidate buffers overflow are recomputed by the exact scan inside the
  * same call.  Workspace: mq_knn_workspace_bytes (covers both paths).
@@ -106,7 +111,7 @@ int mq_knn_search_f32_ev(const float *packed_dev, const float *sqnorm_dev, int64
 size_t mq_knn_screen_bytes(int64_t n_rows, int d, int metric);
 int mq_knn_screen_prepare(const float *packed_dev, const float *sqnorm_dev, int64_t capacity_rows, int d, int metric,
                           int64_t row_offset, int64_t n, float *rowmajor_dev, uint16_t *bf16_dev, float *xstats_dev,
-                          void *stream);
+                          const float *center_dev, void *stream);
 int mq_knn_search_screened_f32(const float *packed_dev, const float *sqnorm_dev, const float *rowmajor_dev,
                                const uint16_t *bf16_dev, const float *xstats_dev, int64_t N, int d,
                                const float *queries_dev, int nq, int k, int metric, int l2norm_queries, int64_t id_offset,

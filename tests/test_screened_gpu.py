@@ -3,6 +3,7 @@ exactly what the exact fp32 scan and the CPU oracle return -- scores bit-for-bit
 friendly data (no fallback) and on data built to defeat the screen (fallback to the exact scan)."""
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -165,7 +166,7 @@ def test_margin_dominates_the_measured_screening_error(kind):
     """The lossless argument needs |S~ - S| <= margin / 2 for every (query, row).  S~ is recomputed here as the exact
     (float64) product of the bf16-rounded operands and S as the exact float64 product; the kernel's largest margin
     (screen_stats) must dominate twice the largest deviation, and must itself equal the documented formula
-    2 (||q|| max||x - x~|| + ||q - q~|| max||x~|| + dp 2.98e-7 ||q|| max||x||) up to its slack factors."""
+    2 (||q|| max||xc - xc~|| + ||q - q~|| max||xc~|| + dp 2.98e-7 ||q|| max||x||), xc = x - centre, up to its slack factors."""
     import torch
     from viquae_amd.index import MI355XFlatIndex
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -190,10 +191,14 @@ def test_margin_dominates_the_measured_screening_error(kind):
     D2, I2 = ex.search_device(Q, k)
     assert torch.equal(D, D2) and torch.equal(I, I2)
     stats = idx.screen_stats(nq, k)
-    Xb, Qb = X.to(torch.bfloat16).double(), Q.to(torch.bfloat16).double()
-    dev = ((Q.double() @ X.double().T) - (Qb @ Xb.T)).abs().amax(dim=1)          # per query, over all rows
+    # the screen rounds the CENTRED rows xc = x - c (c = mean of the first rows added; any fixed c ranks alike)
+    c = idx._center if idx._center is not None else torch.zeros(d, device="cuda")
+    Xc = X - c                                                                   # fp32, as the kernel forms it
+    Xb, Qb = Xc.to(torch.bfloat16).double(), Q.to(torch.bfloat16).double()
+    dev = ((Q.double() @ Xc.double().T) - (Qb @ Xb.T)).abs().amax(dim=1)         # per query, over all rows
     qn, dqn = Q.double().norm(dim=1), (Q.double() - Qb).norm(dim=1)
-    xn, dxn = X.double().norm(dim=1).max(), (X.double() - Xb).norm(dim=1).max()
+    xn = torch.maximum(X.double().norm(dim=1).max(), Xc.double().norm(dim=1).max())
+    dxn = (Xc.double() - Xb).norm(dim=1).max()
     dp = (d + 63) // 64 * 64
     eps = qn * dxn + dqn * Xb.norm(dim=1).max() + dp * 2.98e-7 * qn * xn
     assert torch.all(dev <= eps), float((dev / eps).max())
@@ -201,3 +206,61 @@ def test_margin_dominates_the_measured_screening_error(kind):
     assert kernel_max_margin >= 2 * float(dev.max()) * 0.999
     assert 2 * float(eps.max()) * 0.99 <= kernel_max_margin * (1 + 1e-3) + 1e-6
     assert kernel_max_margin <= 2 * float(eps.max()) * 1.02 + 2e-6   # slack factors stay within 2 %
+
+
+def _anisotropic(n, d, nq, seed, shift=9.0, noise=0.25):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    mu = torch.randn((1, d), generator=g, device="cuda")
+    mu = shift * mu / mu.norm()
+    X = mu + noise * torch.randn((n, d), generator=g, device="cuda")
+    Q = mu + noise * torch.randn((nq, d), generator=g, device="cuda")
+    return X, Q
+
+
+
+@pytest.mark.parametrize("factory", ["Flat", "L2norm,Flat"])
+def test_centred_screen_on_embeddings_with_a_shared_component(factory, monkeypatch):
+    """DPR / CLIP-like data: every vector = a large common direction + small isotropic noise.  The index centres its bf16
+    screening copy on the mean of the first rows (q.(x - c) ranks like q.x): results stay bit-identical to the exact
+    scan and the candidate sets shrink against the uncentred screen."""
+    from viquae_amd.index import MI355XFlatIndex
+    X, Q = _anisotropic(40000, 256, 300, 3)
+
+    def run(center):
+        monkeypatch.setenv("MQ_KNN_CENTER", "1" if center else "0")
+        idx = MI355XFlatIndex(string_factory=factory, metric_type=0, screen=True)
+        idx.add(X[:25600])
+        idx.add(X[25600:])          # the centre chosen at the first add is kept for later rows
+        assert (idx._center is not None) == center
+        D, I = idx.search_device(Q, 100)
+        return D, I, idx.screen_stats(300, 100)
+
+    Dc, Ic, sc = run(True)
+    Du, Iu, su = run(False)
+    ex = MI355XFlatIndex(string_factory=factory, metric_type=0, screen=False)
+    ex.add(X)
+    De, Ie = ex.search_device(Q, 100)
+    assert torch.equal(Dc, De) and torch.equal(Ic, Ie) and torch.equal(Du, De) and torch.equal(Iu, Ie)
+    assert sc[0] == 0 and sc[1] < 0.8 * su[1], (sc[:3], su[:3])   # fewer rows re-scored, nothing fell back
+
+
+def test_centred_margin_dominates_the_measured_screening_error():
+    """|S~c - Sc| <= margin / 2 with S~c = bf16(q) . bf16(x - c) and Sc = q . (x - c) in float64, for every (query, row);
+    and the centred margin is well below the uncentred one on such data."""
+    from viquae_amd.index import MI355XFlatIndex
+    X, Q = _anisotropic(6000, 200, 200, 5)
+    idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
+    idx.add(X)
+    idx.search_device(Q, 10)
+    margin = idx.screen_stats(200, 10)[5] * 1e-6
+    c = idx._center.double()
+    Xc32 = (X - idx._center)                       # fp32, as the kernel forms it
+    screen = Q.to(torch.bfloat16).double() @ Xc32.to(torch.bfloat16).double().T
+    exact = Q.double() @ (X.double() - c).T
+    dev = (screen - exact).abs().max().item()
+    assert margin >= 2 * dev, (margin, dev)
+    qn, dqn = Q.double().norm(dim=1), (Q.double() - Q.to(torch.bfloat16).double()).norm(dim=1)
+    unc = 2 * (qn * (X.double() - X.to(torch.bfloat16).double()).norm(dim=1).max() + dqn * X.double().norm(dim=1).max()).max().item()
+    assert margin < 0.8 * unc, (margin, unc)
+    s = idx._xmax2.cpu().numpy()
+    assert abs(s[0] - float((X.double() ** 2).sum(1).max())) < 1e-3 * s[0] and s[2] < 0.6 * s[0]

@@ -1,0 +1,27 @@
+"""Screened search on a DPR-like synthetic KB: every vector = a shared direction (norm 9) + isotropic noise (sd 0.25 per
+component), so that scores sit at ~81 +- a few units like real DPR inner products, instead of zero-mean Gaussians.
+Reports time, candidates re-scored per query and query tiles that fell back to the exact scan."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from viquae_amd.index import MI355XFlatIndex
+N, d, nq, k = int(os.environ.get("N", 1500000)), 768, int(os.environ.get("NQ", 4096)), 100
+dev = torch.device("cuda")
+g = torch.Generator(device=dev); g.manual_seed(0)
+mu = torch.randn((1, d), generator=g, device=dev); mu = 9.0 * mu / mu.norm()
+idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
+for s in range(0, N, 1 << 16):
+    n = min(1 << 16, N - s)
+    idx.add(mu + 0.25 * torch.randn((n, d), generator=g, device=dev), total_hint=N)
+Q = mu + 0.25 * torch.randn((nq, d), generator=g, device=dev)
+for _ in range(2): D, I = idx.search_device(Q, k)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): D, I = idx.search_device(Q, k)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+st = idx.screen_stats(nq, k)
+ex = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=False)
+ex._packed, ex._sqnorm, ex.ntotal = idx._packed, idx._sqnorm, idx.ntotal  # share the panel buffer
+print(f"DPR-like N={N} nq={nq}: {ms:.2f} ms -> {nq / ms * 1e3:.0f} q/s; tiles recomputed exactly {st[0]}, candidates/query {st[1] / nq:.0f}, max {st[2]}; top score {float(D[0,0]):.2f} k-th {float(D[0,-1]):.2f}")

@@ -928,12 +928,13 @@ size_t mq_knn_screen_bytes(int64_t n_rows, int d, int metric) {
 
 int mq_knn_screen_prepare(const float* packed_dev, const float* sqnorm_dev, int64_t capacity_rows, int d, int metric,
                           int64_t row_offset, int64_t n, float* rowmajor_dev, uint16_t* bf16_dev, float* xstats_dev,
-                          void* stream) {
+                          const float* center_dev, void* stream) {
     if (n == 0) return MQ_OK;
     if (!packed_dev || !sqnorm_dev || !rowmajor_dev || !bf16_dev || !xstats_dev || n < 0 || d <= 0 || row_offset < 0 ||
         row_offset + n > capacity_rows)
         return MQ_EINVAL;
     if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
+    if (center_dev && metric != MQ_METRIC_IP) return MQ_EUNSUPPORTED;  // the L2 screen's extra columns assume uncentred rows
     hipStream_t st = (hipStream_t)stream;
     const int dpad = mq_padded_dim(d), dp = screen_dp(d, metric);
     float* rm = rowmajor_dev + (size_t)row_offset * d;
@@ -942,10 +943,11 @@ int mq_knn_screen_prepare(const float* packed_dev, const float* sqnorm_dev, int6
     MQ_HIP(hipGetLastError());
     const int64_t quads = n * (int64_t)(dp / 4);
     hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, rm, n, d, dp,
-                       (unsigned short*)bf16_dev + (size_t)row_offset * dp, metric == MQ_METRIC_L2 ? 1 : 0, sqnorm_dev + row_offset);
+                       (unsigned short*)bf16_dev + (size_t)row_offset * dp, metric == MQ_METRIC_L2 ? 1 : 0, sqnorm_dev + row_offset,
+                       center_dev);
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(row_err_stats_kernel, dim3((unsigned)((n + 3) / 4 < 2048 ? (n + 3) / 4 : 2048)), dim3(256), 0, st, rm,
-                       (const unsigned short*)bf16_dev + (size_t)row_offset * dp, n, d, dp, (unsigned*)xstats_dev);
+                       (const unsigned short*)bf16_dev + (size_t)row_offset * dp, n, d, dp, (unsigned*)xstats_dev, center_dev);
     MQ_HIP(hipGetLastError());
     return MQ_OK;
 }

@@ -118,7 +118,8 @@ class MI355XFlatIndex(BaseIndex):
         self.screen = bool(screen)  # both metrics: the L2 screen ranks by q.x - ||x||^2/2 (two extra bf16 columns)
         self._rowmajor = None  # torch.float32 [capacity, d] (screened path only)
         self._bf16 = None      # torch.uint8 bf16 copy
-        self._xmax2 = None     # torch.float32 [2]: max ||x||^2, max ||x - bf16(x)||^2 (kept by mq_knn_screen_prepare)
+        self._xmax2 = None     # torch.float32 [3]: max ||x||^2, max ||xc - bf16(xc)||^2, max ||xc||^2 (kept by mq_knn_screen_prepare)
+        self._center = None    # torch.float32 [d]: the vector the bf16 screening copy is centred on (inner product only)
 
     # ------------------------------------------------------------------ construction
     def _ensure_capacity(self, n_total, d):
@@ -186,14 +187,30 @@ class MI355XFlatIndex(BaseIndex):
                                                 stream), "mq_pack_rows_f32")
                 if self.screen:
                     if self._xmax2 is None:
-                        self._xmax2 = torch.zeros(2, dtype=torch.float32, device=self._torch_device)
+                        self._xmax2 = torch.zeros(3, dtype=torch.float32, device=self._torch_device)
+                        self._center = self._choose_center(dev)
                     _lib.check(lib.mq_knn_screen_prepare(self._packed.data_ptr(), self._sqnorm.data_ptr(), self._capacity, self.d,
                                                          self.metric_type, self.ntotal, dev.shape[0], self._rowmajor.data_ptr(),
-                                                         self._bf16.data_ptr(), self._xmax2.data_ptr(), stream),
+                                                         self._bf16.data_ptr(), self._xmax2.data_ptr(),
+                                                         self._center.data_ptr() if self._center is not None else None, stream),
                                "mq_knn_screen_prepare")
                 self.ntotal += dev.shape[0]
                 # `dev` must outlive the kernel: synchronise before it is released
                 torch.cuda.current_stream(self._torch_device).synchronize()
+
+    def _choose_center(self, first_rows):
+        """Centre of the bf16 screening copy: the mean of the first rows added (as stored, i.e. after "L2norm,").  Any
+        fixed vector keeps the screen lossless -- q.(x - c) ranks like q.x -- and dense-retrieval embeddings share a large
+        common component, so the rounding error (hence the margin, hence the candidates per query) then follows ||x - c||
+        instead of ||x||.  Inner product only; MQ_KNN_CENTER=0 disables it."""
+        import torch
+        if self.metric_type != 0 or os.environ.get("MQ_KNN_CENTER", "1") == "0":
+            return None
+        x = first_rows.to(torch.float32)
+        if self.do_l2norm:
+            x = x / x.norm(dim=1, keepdim=True)
+        c = torch.nan_to_num(x, nan=0.0, posinf=0.0, neginf=0.0).mean(dim=0)
+        return c.contiguous() if bool(torch.isfinite(c).all()) else None
 
     def add_vectors(self, vectors, column: Optional[str] = None, batch_size: int = 1000,
                     train_size: Optional[int] = None, faiss_verbose: Optional[bool] = None):
