@@ -100,8 +100,8 @@ int mq_knn_search_f32_ev(const float *packed_dev, const float *sqnorm_dev, int64
  *   xstats_dev                : THREE floats kept by mq_knn_screen_prepare (zero them before its first call):
  *                               max ||x||^2, max ||xc - bf16(xc)||^2 and max ||xc||^2 over the shard (xc = x - centre),
  *                               the inputs of the error bound
- *   center_dev                : NULL, or d floats subtracted from every row before the bf16 rounding (inner product
- *                               only; ANY fixed vector is valid: q.(x - c) ranks the rows of a query like q.x, and for
+ *   center_dev                : NULL, or d floats subtracted from every row before the bf16 rounding (both metrics;
+ *                               ANY fixed vector is valid: q.(x - c) ranks the rows of a query like q.x, and for
  *                               embeddings with a large shared component the screen's margin then follows ||x - c||);
  *                               the same vector must be passed for every row range of a shard
  * mq_knn_screen_prepare fills rowmajor/bf16 for rows [row_offset, row_offset+n) from the panel buffer.

@@ -138,10 +138,11 @@ def test_l2_margin_dominates_the_measured_screening_error():
     v = -0.5 * idx._sqnorm[:n]
     h = v.to(torch.bfloat16)
     l = (v - h.float()).to(torch.bfloat16)
-    screen = Q.to(torch.bfloat16).double() @ X.to(torch.bfloat16).double().T + (h.double() + l.double())[None]
+    c = idx._center if idx._center is not None else torch.zeros(d, device="cuda")   # the screen rounds x - c
+    screen = Q.to(torch.bfloat16).double() @ (X - c).to(torch.bfloat16).double().T + (h.double() + l.double())[None]
     qn = (Q.double() ** 2).sum(1)
     d_exact = (qn[:, None] + xn[None]) - 2 * (Q.double() @ X.double().T)
-    target = (qn[:, None] - d_exact) / 2
+    target = (qn[:, None] - d_exact) / 2 - (Q.double() @ c.double())[:, None]       # the same ranking, shifted by q.c
     dev = (screen - target).abs().max().item()
     assert kernel_max_margin >= 2 * dev, (kernel_max_margin, dev)
     assert kernel_max_margin <= 40 * dev   # and it is not vacuous
@@ -218,8 +219,8 @@ def _anisotropic(n, d, nq, seed, shift=9.0, noise=0.25):
 
 
 
-@pytest.mark.parametrize("factory", ["Flat", "L2norm,Flat"])
-def test_centred_screen_on_embeddings_with_a_shared_component(factory, monkeypatch):
+@pytest.mark.parametrize("factory,metric", [("Flat", 0), ("L2norm,Flat", 0), ("Flat", 1)])
+def test_centred_screen_on_embeddings_with_a_shared_component(factory, metric, monkeypatch):
     """DPR / CLIP-like data: every vector = a large common direction + small isotropic noise.  The index centres its bf16
     screening copy on the mean of the first rows (q.(x - c) ranks like q.x): results stay bit-identical to the exact
     scan and the candidate sets shrink against the uncentred screen."""
@@ -228,7 +229,7 @@ def test_centred_screen_on_embeddings_with_a_shared_component(factory, monkeypat
 
     def run(center):
         monkeypatch.setenv("MQ_KNN_CENTER", "1" if center else "0")
-        idx = MI355XFlatIndex(string_factory=factory, metric_type=0, screen=True)
+        idx = MI355XFlatIndex(string_factory=factory, metric_type=metric, screen=True)
         idx.add(X[:25600])
         idx.add(X[25600:])          # the centre chosen at the first add is kept for later rows
         assert (idx._center is not None) == center
@@ -237,7 +238,7 @@ def test_centred_screen_on_embeddings_with_a_shared_component(factory, monkeypat
 
     Dc, Ic, sc = run(True)
     Du, Iu, su = run(False)
-    ex = MI355XFlatIndex(string_factory=factory, metric_type=0, screen=False)
+    ex = MI355XFlatIndex(string_factory=factory, metric_type=metric, screen=False)
     ex.add(X)
     De, Ie = ex.search_device(Q, 100)
     assert torch.equal(Dc, De) and torch.equal(Ic, Ie) and torch.equal(Du, De) and torch.equal(Iu, Ie)

@@ -934,7 +934,6 @@ int mq_knn_screen_prepare(const float* packed_dev, const float* sqnorm_dev, int6
         row_offset + n > capacity_rows)
         return MQ_EINVAL;
     if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
-    if (center_dev && metric != MQ_METRIC_IP) return MQ_EUNSUPPORTED;  // the L2 screen's extra columns assume uncentred rows
     hipStream_t st = (hipStream_t)stream;
     const int dpad = mq_padded_dim(d), dp = screen_dp(d, metric);
     float* rm = rowmajor_dev + (size_t)row_offset * d;

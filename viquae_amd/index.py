@@ -202,9 +202,9 @@ class MI355XFlatIndex(BaseIndex):
         """Centre of the bf16 screening copy: the mean of the first rows added (as stored, i.e. after "L2norm,").  Any
         fixed vector keeps the screen lossless -- q.(x - c) ranks like q.x -- and dense-retrieval embeddings share a large
         common component, so the rounding error (hence the margin, hence the candidates per query) then follows ||x - c||
-        instead of ||x||.  Inner product only; MQ_KNN_CENTER=0 disables it."""
+        instead of ||x||.  Both metrics (the L2 screen ranks by q.x - ||x||^2/2); MQ_KNN_CENTER=0 disables it."""
         import torch
-        if self.metric_type != 0 or os.environ.get("MQ_KNN_CENTER", "1") == "0":
+        if os.environ.get("MQ_KNN_CENTER", "1") == "0":
             return None
         x = first_rows.to(torch.float32)
         if self.do_l2norm:
