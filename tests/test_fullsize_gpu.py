@@ -102,3 +102,29 @@ def test_returned_scores_are_the_fma_chain_and_nothing_better_was_missed(big):
     for j in range(len(qs)):
         if ids_blk[Iall[j, 0]] not in I[j]:
             assert Dall[j, 0] <= D[j, -1]
+
+
+def test_fullsize_embedding_like_kb_with_a_shared_component():
+    """1.5M x 768 DPR-like KB (every vector = one large common direction + small noise, scores ~ 90): the centred screen
+    must return the exact scan's answer bit for bit (first 512 queries compared -- the exact scan takes ~10 ms for them),
+    without falling back, and re-score fewer rows than the uncentred screen's ~420 per query."""
+    import torch
+    from viquae_amd.index import MI355XFlatIndex
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    mu = torch.randn((1, D), generator=g, device=dev)
+    mu = 9.0 * mu / mu.norm()
+    scr = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
+    ex = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=False)
+    for s in range(0, N, 1 << 16):
+        x = mu + 0.25 * torch.randn((min(1 << 16, N - s), D), generator=g, device=dev)
+        scr.add(x, total_hint=N)
+        ex.add(x, total_hint=N)
+    Q = mu + 0.25 * torch.randn((512, D), generator=g, device=dev)
+    D1, I1 = scr.search_device(Q, K)
+    D2, I2 = ex.search_device(Q, K)
+    assert torch.equal(D1, D2) and torch.equal(I1, I2)
+    flagged, rescored = scr.screen_stats(512, K)[:2]
+    assert flagged == 0 and rescored / 512 < 330
+    assert float(D1.min()) > 80.0          # the scores really sit on top of the shared component
