@@ -13,12 +13,18 @@ Two exact paths exist and return bit-identical results (checked in every run):
   --mode exact_f32: mq_knn_search_f32 = fp32 MFMA scan with the top-k fused (csrc/knn.hip).
 The headline `value` is the selected mode; the other path is timed next to it (`other_exact_path`).
 
-N > 1 (BASELINE configs[4] shape): the KB is row-sharded, one 1.5M-row
-shard per rank (weak scaling: per-GPU work fixed), queries replicated; each step = local scan +
-one RCCL all-gather of the per-shard [nq,100] lists + merge on every rank.  `value` counts the
-units all ranks processed: one unit = one query's exact top-100 over one 1.5M x 768 shard (the
-BASELINE metric's unit), so value = N * nq * K / t; the end-to-end rate of finished queries over
-the N x 1.5M KB is reported next to it as `global_queries_per_s`.
+N > 1 (BASELINE configs[4]: 12M x 768 over 8 GPUs, 16k queries): the KB is
+row-sharded, one 1.5M-row shard per rank (weak scaling: per-GPU work fixed), 16,384 replicated
+queries per step; a step = ShardedFlatIndex.search_device = per 4096-query chunk {local scan into the
+rank's shard record, ONE RCCL all-gather of the records (async, overlapping the next chunk's scan),
+merge on every rank}.  `value` counts the units all ranks processed: one unit = one query's exact
+top-100 over one 1.5M x 768 shard (the BASELINE metric's unit), so value = N * nq * K / t; the
+end-to-end rate of finished queries over the N x 1.5M KB is `global_queries_per_s`.  Rank 0 also
+reports the per-chunk scan / all-gather / merge times of an un-overlapped pass, the RCCL rank count
+it saw, and the same search with the TOTAL KB fixed at 1.5M rows (strong scaling).
+
+`python bench.py --gpus N` without WORLD_SIZE in the environment starts the N ranks itself (a
+`torch.distributed.run` child process, before this process touches any GPU) and relays their line.
 
 Prints ONE JSON line on rank 0.
 """
@@ -27,6 +33,8 @@ import json
 import os
 import sys
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -46,7 +54,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=KB_ROWS, help="KB rows per GPU (default: BASELINE size)")
-    ap.add_argument("--nq", type=int, default=NQ)
+    ap.add_argument("--nq", type=int, default=None, help="queries per step (default: 4096 on one GPU = configs[1]; 16384 on several = configs[4])")
     ap.add_argument("--mode", choices=["screened", "exact_f32"], default="screened",
                     help="screened: bf16 screening scan + exact fp32 re-scoring (default, same results); exact_f32: fp32 MFMA scan")
     ap.add_argument("--no-other-path", action="store_true", help="do not time the other exact path next to the headline")
@@ -68,47 +76,113 @@ def build_shard(idx, rows, seed, device):
 
 
 def cpu_baseline(idx, Q, seconds):
-    """Times the CPU oracle (oracle/knn_oracle.c, OpenMP over 32-query blocks) on a bounded sample of
-    the same workload: ALL queries of the step (so every host core has a block) against the first
-    `rows_s` KB rows, sized by a calibration run for ~`seconds` of CPU work, then scaled by rows to
-    the metric's unit (queries/s over the full 1.5M x 768 KB)."""
+    """CPU legs on the GPU box's host cores, each on a BOUNDED sample of the same workload (ALL queries of the step, so
+    every core has work, against the first `rows` KB rows sized by a calibration run), scaled by rows to the metric's
+    unit (queries/s over the full 1.5M x 768 KB):
+      * fmaf_chain_oracle: oracle/knn_oracle.c, the bit-exact checker (OpenMP over 32-query blocks);
+      * blas_sgemm_topk:   oracle.knn.knn_blas, FAISS's own organisation for >= 20 queries (sgemm blocks + k best per
+                           query) on torch's CPU BLAS, all cores -- the faster leg, and the one `value` reports.
+    Neither is FAISS itself (not installable here): kind = "port"."""
     from oracle import knn as ok
+    import torch
     threads = ok.num_threads()
     Qh = Q.cpu().numpy()
     nq = Qh.shape[0]
-    cal_rows = min(idx.ntotal, 4096)
-    X = idx.reconstruct_n(0, cal_rows)
-    ok.knn(X[:256], Qh, TOPK, metric=0)  # warm the thread pool
-    t0 = time.perf_counter()
-    ok.knn(X, Qh, TOPK, metric=0)
-    tc = time.perf_counter() - t0
-    rows_s = int(min(idx.ntotal, max(cal_rows, cal_rows * seconds / max(tc, 1e-4))))
-    X = idx.reconstruct_n(0, rows_s)
-    t0 = time.perf_counter()
-    ok.knn(X, Qh, TOPK, metric=0)
-    t = time.perf_counter() - t0
-    value = (nq / t) * rows_s / idx.ntotal  # the same queries against the full KB cost ntotal/rows_s more
-    return {
-        "value": round(value, 2), "unit": "queries/s", "cores": threads, "kind": "port",
-        "sample": f"oracle/knn_oracle.c (fmaf-chain restatement of FAISS IndexFlatIP, OpenMP x{threads}) on {nq} queries x "
-                  f"the first {rows_s} KB rows, top-{TOPK}: {t:.2f} s ({2.0 * nq * rows_s * DIM / t / 1e9:.0f} GFLOP/s); "
-                  f"scaled by rows to {idx.ntotal} x {DIM}",
+
+    def leg(fn, cal_rows, budget, name):
+        X = idx.reconstruct_n(0, min(idx.ntotal, cal_rows))
+        fn(X[:256], Qh)  # warm the thread pool
+        t0 = time.perf_counter()
+        fn(X, Qh)
+        tc = time.perf_counter() - t0
+        rows_s = int(min(idx.ntotal, max(X.shape[0], X.shape[0] * budget / max(tc, 1e-4))))
+        if rows_s > X.shape[0]:
+            X = idx.reconstruct_n(0, rows_s)
+            t0 = time.perf_counter()
+            fn(X, Qh)
+            tc = time.perf_counter() - t0
+        value = (nq / tc) * rows_s / idx.ntotal  # the same queries against the full KB cost ntotal/rows_s more
+        return {"value": round(value, 2), "seconds": round(tc, 2), "kb_rows_sampled": rows_s,
+                "gflops": round(2.0 * nq * rows_s * DIM / tc / 1e9, 1), "what": name}
+
+    legs = {"fmaf_chain_oracle": leg(lambda X, Qq: ok.knn(X, Qq, TOPK, metric=0), 4096, seconds * 0.6,
+                                     f"oracle/knn_oracle.c (k-ordered fmaf chain = the bit-exact checker), OpenMP x{threads}")}
+    try:
+        tt = torch.get_num_threads()
+        legs["blas_sgemm_topk"] = leg(lambda X, Qq: ok.knn_blas(X, Qq, TOPK, metric=0), 1 << 16, seconds * 0.6,
+                                      f"oracle.knn.knn_blas (torch CPU sgemm blocks + topk, FAISS's >= 20-query organisation), {tt} threads")
+    except Exception as e:
+        legs["blas_sgemm_topk"] = {"value": 0.0, "what": f"failed: {e!r}"}
+    best = max(legs, key=lambda n: legs[n]["value"])
+    rec = {
+        "value": legs[best]["value"], "unit": "queries/s", "cores": threads, "kind": "port",
+        "sample": f"{best}: {legs[best]['what']}; {nq} queries x the first {legs[best]['kb_rows_sampled']} KB rows, top-{TOPK}: "
+                  f"{legs[best]['seconds']} s ({legs[best]['gflops']} GFLOP/s); scaled by rows to {idx.ntotal} x {DIM}",
+        "legs": legs,
     }
+    return rec
+
+
+def cpu_encoder_baseline(n=64):
+    """the CPU restatement of the encoders (oracle/encoders.py: numpy fp32, op order of
+    meerqat/models/bert.py) on `n` passages of 100 tokens (BERT-base) and `n` 224x224 images (CLIP ViT-B/32), seeded weights."""
+    from oracle import encoders as oe
+    rng = np.random.default_rng(0)
+    out = {"cores": os.cpu_count(), "kind": "port", "sample": f"oracle/encoders.py (numpy fp32 on the host BLAS), {n} passages x 100 tokens / {n} images"}
+    state = oe.seeded_state(oe.bert_param_shapes(oe.BERT_BASE), 1)
+    ids = rng.integers(1000, 30000, (n, 100)).astype(np.int64)
+    oe.bert_forward(state, oe.BERT_BASE, ids[:4], None, np.ones_like(ids[:4]))
+    t0 = time.perf_counter()
+    oe.bert_forward(state, oe.BERT_BASE, ids, None, np.ones_like(ids))
+    out["dpr_passages_per_s"] = round(n / (time.perf_counter() - t0), 2)
+    del state
+    state = oe.seeded_state(oe.clip_vision_param_shapes(oe.CLIP_VITB32), 2)
+    px = rng.standard_normal((n, 3, 224, 224)).astype(np.float32)
+    oe.clip_vision_forward(state, oe.CLIP_VITB32, px[:4])
+    t0 = time.perf_counter()
+    oe.clip_vision_forward(state, oe.CLIP_VITB32, px)
+    out["clip_images_per_s"] = round(n / (time.perf_counter() - t0), 2)
+    return out
 
 
 def load_traffic(workload_key):
-    """HBM bytes per scan launch from a committed rocprofv3 --pmc pass (profiles/knn_traffic.json)."""
+    """(bytes per scan launch, provenance).  PMC counters cannot be read from inside this process: the figure is the one
+    committed with the rocprofv3 --pmc passes of THIS command (profiles/knn_traffic.json, written by
+    tools/summarize_profiles.py; FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), tagged with its profile run."""
     p = os.path.join(ROOT, "profiles", "knn_traffic.json")
     try:
         with open(p) as f:
             t = json.load(f)
-        return t.get(workload_key, {}).get("hbm_bytes_per_launch")
+        e = t.get(workload_key, {})
+        return e.get("hbm_bytes_per_launch"), (f"profiles/knn_traffic.json[{workload_key}] from {e.get('profile', t.get('_profile', '?'))}"
+                                                if e else None)
     except Exception:
-        return None
+        return None, None
+
+
+def spawn_ranks(args):
+    """`bench.py --gpus N` started by hand: run the N ranks as children of a torch.distributed.run launcher.  Nothing in
+    THIS process has touched a GPU (torch.cuda.device_count() does not initialise HIP on this image), and it never will:
+    it only waits for the launcher and passes the ranks' JSON line through."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout when the process
     # exits: keep a private handle on the real stdout for the JSON line and point fd 1 at stderr for everything else.
     sys.stdout.flush()
@@ -138,46 +212,51 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     lib = _lib.load()
 
-    rows, nq, k = args.rows, args.nq, TOPK
+    multi = world > 1 or force_dist
+    rows, k = args.rows, TOPK
+    nq = args.nq or (4 * NQ if multi else NQ)
     local = MI355XFlatIndex(device=local_rank, string_factory="Flat", metric_type=0, id_offset=rank * rows, screen=True)
     build_shard(local, rows, seed=rank, device=device)
-    index = ShardedFlatIndex(string_factory="Flat", metric_type=0, local_index=local) if (world > 1 or force_dist) else None
+    index = ShardedFlatIndex(string_factory="Flat", metric_type=0, local_index=local, always_gather=force_dist) if multi else None
     if index is not None:
-        index.ntotal = rows * world
+        index.ntotal, index.d = rows * world, DIM
     g = torch.Generator(device=device)
     g.manual_seed(100)
     Q = torch.randn((nq, DIM), generator=g, device=device, dtype=torch.float32)  # same on every rank
 
     stream = torch.cuda.current_stream(device)
-    ws_bytes = int(lib.mq_knn_workspace_bytes(rows, DIM, nq, k))
+    nqc = min(nq, NQ)  # queries per C-ABI call (the screened scan's 4096-query chunk)
+    ws_bytes = int(lib.mq_knn_workspace_bytes(rows, DIM, nqc, k))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-    D = torch.empty((nq, k), dtype=torch.float32, device=device)
-    I = torch.empty((nq, k), dtype=torch.int64, device=device)
+    D = torch.empty((nqc, k), dtype=torch.float32, device=device)
+    I = torch.empty((nqc, k), dtype=torch.int64, device=device)
 
     mode = args.mode
-    def local_step(ev0=None, ev1=None, which=None):
+    def local_step(ev0=None, ev1=None, which=None, q=None, out=None):
+        """ONE C-ABI search call over (at most) 4096 queries with HIP events around its dominant kernel."""
         e0 = ev0.cuda_event if ev0 is not None else None
         e1 = ev1.cuda_event if ev1 is not None else None
+        q = Q[:nqc] if q is None else q
+        Dq, Iq = (D, I) if out is None else out
         if (which or mode) == "screened":
             _lib.check(lib.mq_knn_search_screened_f32(
                 local._packed.data_ptr(), local._sqnorm.data_ptr(), local._rowmajor.data_ptr(), local._bf16.data_ptr(),
-                local._xmax2.data_ptr(), rows, DIM, Q.data_ptr(), nq, k, 0, 0, local.id_offset, D.data_ptr(), I.data_ptr(),
+                local._xmax2.data_ptr(), rows, DIM, q.data_ptr(), q.shape[0], k, 0, 0, local.id_offset, Dq.data_ptr(), Iq.data_ptr(),
                 ws.data_ptr(), ws_bytes, stream.cuda_stream, e0, e1), "mq_knn_search_screened_f32")
         else:
-            _lib.check(lib.mq_knn_search_f32_ev(local._packed.data_ptr(), local._sqnorm.data_ptr(), rows, DIM, Q.data_ptr(),
-                                                nq, k, 0, 0, local.id_offset, D.data_ptr(), I.data_ptr(), ws.data_ptr(),
+            _lib.check(lib.mq_knn_search_f32_ev(local._packed.data_ptr(), local._sqnorm.data_ptr(), rows, DIM, q.data_ptr(),
+                                                q.shape[0], k, 0, 0, local.id_offset, Dq.data_ptr(), Iq.data_ptr(), ws.data_ptr(),
                                                 ws_bytes, stream.cuda_stream, e0, e1), "mq_knn_search_f32_ev")
-        return D, I
+        return Dq, Iq
+
+    if multi:
+        local.screen = mode == "screened"
+        local._ws = ws  # the index's own search_device reuses the bench workspace
 
     def step(ev0=None, ev1=None):
-        Dl, Il = local_step(ev0, ev1)
-        if world == 1 and not force_dist:
-            return Dl, Il
-        Ds = torch.empty((world * nq, k), dtype=Dl.dtype, device=device)
-        Is = torch.empty((world * nq, k), dtype=Il.dtype, device=device)
-        dist.all_gather_into_tensor(Ds, Dl)
-        dist.all_gather_into_tensor(Is, Il)
-        return index.merge_fn(Ds.view(world, nq, k), Is.view(world, nq, k), 0)
+        if not multi:
+            return local_step(ev0, ev1)
+        return index.search_device(Q, k)  # scan chunks | async all-gather | merge, software-pipelined
 
     def make_events(n):
         evs_ = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
@@ -207,7 +286,73 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    scan_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
+    if multi:
+        # un-overlapped pass: per 4096-query chunk, HIP events around the scan kernel (through the C ABI), the collective
+        # and the merge -- what the pipelined step hides is the difference to `ms_per_step`
+        from viquae_amd.sharded import record_layout, _record_views, _hip_merge_records
+        nb = 3
+        chunks = [(s0, min(s0 + nqc, nq)) for s0 in range(0, nq, nqc)]
+        tev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+        marks = []
+        for _ in range(nb):
+            for s0, e0_ in chunks:
+                n = e0_ - s0
+                rec_bytes, _ = record_layout(n, k)
+                record = torch.empty(rec_bytes, dtype=torch.uint8, device=device)
+                gathered = torch.empty(world * rec_bytes, dtype=torch.uint8, device=device)
+                Dv, Iv = _record_views(record, n, k)
+                ka, kb_, a0, a1, a2, a3 = tev(), tev(), tev(), tev(), tev(), tev()
+                ka.record(stream); kb_.record(stream)
+                a0.record(stream)
+                local_step(ka, kb_, q=Q[s0:e0_], out=(Dv, Iv))
+                a1.record(stream)
+                dist.all_gather_into_tensor(gathered, record)
+                a2.record(stream)
+                _hip_merge_records(gathered, world, n, k, 0)
+                a3.record(stream)
+                marks.append((ka, kb_, a0, a1, a2, a3))
+        torch.cuda.synchronize()
+        marks = marks[len(chunks):]  # first pass = warm-up
+        per = lambda i, j: sum(m[i].elapsed_time(m[j]) for m in marks) / len(marks)  # noqa: E731
+        scan_ms = per(0, 1)
+        breakdown = {"per_chunk_of_queries": nqc, "chunks_per_step": len(chunks), "scan_call_ms": round(per(2, 3), 3),
+                     "scan_kernel_ms": round(scan_ms, 3), "all_gather_ms": round(per(3, 4), 3), "merge_ms": round(per(4, 5), 3),
+                     "all_gather_bytes_per_rank": record_layout(nqc, k)[0],
+                     "unoverlapped_ms_per_step": round(len(chunks) * per(2, 5), 3)}
+        t = torch.tensor([breakdown["all_gather_ms"], breakdown["merge_ms"], breakdown["scan_call_ms"]], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        breakdown["max_over_ranks"] = {"all_gather_ms": round(float(t[0]), 3), "merge_ms": round(float(t[1]), 3), "scan_call_ms": round(float(t[2]), 3)}
+    else:
+        scan_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
+        breakdown = None
+
+    # strong scaling ("N total fixed"): the SAME 1.5M-row KB cut into `world` shards
+    fixed_total = None
+    if world > 1:
+        from viquae_amd.sharded import shard_bounds
+        lo, hi = shard_bounds(rows, world, rank)
+        small = MI355XFlatIndex(device=local_rank, string_factory="Flat", metric_type=0, id_offset=lo, screen=mode == "screened")
+        gs = torch.Generator(device=device)
+        gs.manual_seed(1000 + rank)
+        for s0 in range(0, hi - lo, 1 << 16):
+            small.add(torch.randn((min(1 << 16, hi - lo - s0), DIM), generator=gs, device=device), total_hint=hi - lo)
+        sidx = ShardedFlatIndex(string_factory="Flat", metric_type=0, local_index=small)
+        sidx.ntotal, sidx.d = rows, DIM
+        sidx.search_device(Q, k)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ts = time.perf_counter()
+        n_s = max(2, min(5, args.steps))
+        for _ in range(n_s):
+            sidx.search_device(Q, k)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ts = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=device)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        fixed_total = {"kb_rows_total": rows, "kb_rows_per_gpu": hi - lo, "queries_per_step": nq, "steps": n_s,
+                       "ms_per_step": round(float(ts.item()) / n_s * 1e3, 3),
+                       "queries_per_s": round(nq * n_s / float(ts.item()), 1)}
+        del small, sidx
 
     # the other exact path, timed next to the headline (rank 0, N = 1): a few steps are enough
     other = None
@@ -216,6 +361,7 @@ def main():
         D_head, I_head = D.clone(), I.clone()
         n2 = max(2, min(5, args.steps))
         local_step(which=which)
+        torch.cuda.synchronize()
         evs2 = make_events(n2)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -231,11 +377,13 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         units = world * nq * args.steps
         value = units / elapsed
-        flops = 2.0 * nq * rows * DIM  # algorithmic FLOPs of one scan launch (2.304 GFLOP/query)
+        flops = 2.0 * nqc * rows * DIM  # algorithmic FLOPs of one scan launch (2.304 GFLOP/query)
         achieved = flops / (scan_ms * 1e-3) / 1e12
         info = (ctypes_i64 * 8)()
-        lib.mq_knn_launch_info(rows, DIM, nq, k, info)
-        workload = f"{rows}x{DIM} fp32 KB per GPU, {nq} queries, exact IP top-{k}"
+        lib.mq_knn_launch_info(rows, DIM, nqc, k, info)
+        workload = (f"{rows}x{DIM} fp32 KB per GPU, {nq} queries, exact IP top-{k}" if not multi else
+                    f"{rows * world}x{DIM} fp32 KB row-sharded over {world} GPU(s) ({rows} rows each), {nq} replicated queries per step, "
+                    f"exact IP top-{k} (BASELINE configs[4] shape)")
         if mode == "screened":
             peak, kernel = PEAK_BF16_MFMA_TFLOPS, "screen_scan_kernel (v_mfma_f32_32x32x16_bf16, relaxed top-k fused)"
             alg_bytes = rows * DIM * 2  # bf16 copy of the shard, one pass
@@ -244,6 +392,7 @@ def main():
             peak, kernel = PEAK_F32_MFMA_TFLOPS, "knn_scan_kernel<IP> (v_mfma_f32_32x32x2_f32, top-k fused)"
             alg_bytes = rows * DIM * 4
             dtype = "f32"
+        traffic = load_traffic(f"{mode}_{rows}x{DIM}_nq{nqc}_k{k}")
         rec = {
             "metric": "queries/sec exact top-100 over 1.5M x 768 KB",
             "value": round(value, 1),
@@ -263,7 +412,8 @@ def main():
                 "kb_rows_total": rows * world,
                 "queries_per_step": nq,
                 "k": k,
-                "sharding": "single GPU" if world == 1 else f"row-sharded x{world}, RCCL all-gather of per-shard top-{k} + merge",
+                "sharding": "single GPU" if not multi else f"row-sharded x{world}: per 4096-query chunk one RCCL all-gather of the shard records "
+                            f"{{f32 score, i64 id}}[nq,{k}] (async, overlapping the next chunk's scan) + merge on every rank",
                 "unit_definition": "one query's exact top-100 over one 1.5M x 768 shard",
                 "global_queries_per_s": round(nq * args.steps / elapsed, 1),
                 "scan_launch": {"workgroups": int(info[0]), "threads": int(info[6] if mode == "screened" else info[1]),
@@ -281,12 +431,19 @@ def main():
                 "algorithmic_flops_per_launch": flops,
                 "algorithmic_hbm_bytes_per_launch": alg_bytes,
                 "hbm_frac_at_one_pass": round(alg_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                "traffic": load_traffic(f"{mode}_{rows}x{DIM}_nq{nq}_k{k}"),
+                "traffic": traffic[0],
+                "traffic_from_profile": traffic[1],
             },
         }
+        if multi:
+            rec["config"]["rccl"] = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
+                                     "launched_by": "torch.distributed.run"}
+            rec["config"]["step_breakdown_ms"] = breakdown
+        if fixed_total is not None:
+            rec["config"]["fixed_total_kb"] = fixed_total
         if mode == "screened":
             local._ws, keep = ws, local._ws
-            st = local.screen_stats(nq, k)
+            st = local.screen_stats(nqc, k)
             local._ws = keep
             rec["config"]["screen"] = {"query_tiles_recomputed_exactly": st[0], "candidates_rescored_per_query": round(st[1] / nq, 1),
                                        "max_candidates_of_a_query": st[2]}
@@ -302,6 +459,11 @@ def main():
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 rec["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e!r}"}
+            if not args.no_encoders:
+                try:
+                    rec["cpu_baseline"]["encoders"] = cpu_encoder_baseline()
+                except Exception as e:
+                    rec["cpu_baseline"]["encoders"] = {"error": repr(e)}
         if world == 1 and not args.no_encoders:
             # secondary BASELINE figures (configs[2], configs[3]); the headline `value` stays queries/s
             try:

@@ -11,7 +11,12 @@
  *   - return value: MQ_OK (0) or a negative MQ_E* code; no exceptions cross the boundary;
  *     kernels are enqueued on `stream` and NOT synchronised (results are valid after the caller
  *     synchronises the stream);
- *   - re-entrant per stream: no global mutable state.
+ *   - re-entrant per stream.  The library keeps no state about a caller's data; what it does keep
+ *     is process-wide bookkeeping that never changes a result: the last HIP error code of the
+ *     calling THREAD (thread-local, mq_last_hip_error()), the CU count of the device (read once),
+ *     one "dynamic-LDS limit raised" bit per (kernel, device), and the MQ_KNN_QPX tuning knob read
+ *     from the environment once.  No environment variable is ever turned into a pointer in this
+ *     build (cycle-accounting builds compiled with -DMQ_TIMING are a developer tool).
  */
 #ifndef MEERQAT_HIP_H
 #define MEERQAT_HIP_H
@@ -33,6 +38,13 @@ extern "C" {
 #define MQ_METRIC_L2 1 /* faiss.METRIC_L2 (FAISS default when metric_type is None) */
 
 #define MQ_KNN_MAX_K 128 /* largest k of the fused scan; the reference uses k=100 (ir/search.py:12) */
+
+/* faiss::distance_compute_blas_threshold.  A METRIC_L2 search of FEWER queries than this takes FAISS's
+ * sequential path: distances are the direct sums of (q[k] - x[k])^2 (faiss fvec_L2sqr), not the BLAS form
+ * ||q||^2 + ||x||^2 - 2<q,x> clamped at 0 that larger batches get (faiss/utils/distances.cpp, knn_L2sqr).
+ * Both search entries below switch form on the `nq` of the CALL, so a host that cuts a large batch into
+ * several calls must not leave a piece of fewer than 20 queries (viquae_amd.index.query_chunks). */
+#define MQ_KNN_L2_DIRECT_BELOW 20
 
 const char *mq_version(void);
 const char *mq_strerror(int code);
@@ -131,6 +143,18 @@ int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[8]);
  * counterpart): Ds/Is [nshards, nq, k] with GLOBAL ids -> the k best per query. */
 int mq_topk_merge_f32(const float *Ds_dev, const int64_t *Is_dev, int nshards, int nq, int k, int metric,
                       float *D_dev, int64_t *I_dev, void *stream);
+
+/* The same merge over the buffer ONE all-gather delivers ("one RCCL all-gather of
+ * (score f32, id i64)[nq,k] per rank").  A rank's record is mq_shard_record_bytes(nq, k) bytes:
+ *   [0, nq*k*4)                                   fp32 scores [nq,k]
+ *   [mq_shard_record_ids_offset(nq,k), + nq*k*8)  int64 GLOBAL ids [nq,k]
+ * (offsets rounded so that ids are 8-byte and records 16-byte aligned).  A shard's search writes D / I
+ * straight into its record (D_dev = record, I_dev = record + ids offset), the collective concatenates the
+ * records rank-major, and records_dev = that [nshards * record_bytes] buffer (8-byte aligned). */
+size_t mq_shard_record_bytes(int nq, int k);
+size_t mq_shard_record_ids_offset(int nq, int k);
+int mq_topk_merge_records_f32(const void *records_dev, int nshards, int nq, int k, int metric, float *D_dev,
+                              int64_t *I_dev, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Encoder building blocks (fp32): the arithmetic of Hugging Face DPRContextEncoder /

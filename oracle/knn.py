@@ -33,6 +33,9 @@ def lib():
         L.oracle_knn_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_int64, fp, fp]
         L.oracle_knn_f32.restype = ctypes.c_int
+        L.oracle_knn_f32_ex.argtypes = [fp, ctypes.c_int64, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int64, fp, fp]
+        L.oracle_knn_f32_ex.restype = ctypes.c_int
         L.oracle_l2norm_rows_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int]
         L.oracle_l2norm_rows_f32.restype = None
         L.oracle_sqnorm_rows_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int, fp]
@@ -68,11 +71,17 @@ def sqnorm_rows(x):
     return out
 
 
-def knn(X, Q, k, metric=0, id_offset=0, l2norm=False):
+FLT_MAX = float(np.finfo(np.float32).max)  # FAISS's heap neutral value: what an unfilled slot reports (+ for L2, - for IP)
+L2_FORMS = {"auto": 0, "expanded": 1, "direct": 2}
+
+
+def knn(X, Q, k, metric=0, id_offset=0, l2norm=False, l2_form="auto"):
     """Brute-force top-k of Q against X; returns (D f32 [nq,k], I i64 [nq,k]).
 
     ``l2norm=True`` applies the "L2norm," transform to both sides first (FAISS
-    NormalizationTransform on add and on search)."""
+    NormalizationTransform on add and on search).  ``l2_form`` (metric 1): "auto" = FAISS's rule
+    (fewer than 20 queries: direct sum of (q-x)^2; otherwise ||q||^2+||x||^2-2<q,x> clamped at 0),
+    or force "expanded" / "direct"."""
     X, Q = _f32(X), _f32(Q)
     if Q.ndim != 2 or X.ndim != 2 or Q.shape[1] != X.shape[1]:
         raise ValueError("shape mismatch")
@@ -81,10 +90,10 @@ def knn(X, Q, k, metric=0, id_offset=0, l2norm=False):
     nq, d = Q.shape
     D = np.empty((nq, k), dtype=np.float32)
     I = np.empty((nq, k), dtype=np.int64)
-    rc = lib().oracle_knn_f32(X.ctypes.data, X.shape[0], d, Q.ctypes.data, nq, k, int(metric), int(id_offset),
-                              D.ctypes.data, I.ctypes.data)
+    rc = lib().oracle_knn_f32_ex(X.ctypes.data, X.shape[0], d, Q.ctypes.data, nq, k, int(metric), L2_FORMS[l2_form],
+                                 int(id_offset), D.ctypes.data, I.ctypes.data)
     if rc != 0:
-        raise ValueError(f"oracle_knn_f32 failed: {rc}")
+        raise ValueError(f"oracle_knn_f32_ex failed: {rc}")
     return D, I
 
 
@@ -101,25 +110,61 @@ def topk_merge(Ds, Is, metric=0):
     return D, I
 
 
+def knn_blas(X, Q, k, metric=0, block=1 << 16, threads=None):
+    """The same search organised the way FAISS's IndexFlat runs it for 20 or more queries
+    (faiss/utils/distances.cpp, exhaustive_inner_product_blas / exhaustive_L2sqr_blas): database blocks
+    through sgemm, then the k best per query.  Scores carry the BLAS library's summation order, not the
+    fmaf chain of knn(): this is bench.py's fast CPU leg (all cores through torch's BLAS), and it is
+    compared with knn() only up to float64 near-ties (tests/test_oracle_cpu.py)."""
+    import torch
+    if threads:
+        torch.set_num_threads(int(threads))
+    X, Q = _f32(X), _f32(Q)
+    Xt, Qt = torch.from_numpy(X), torch.from_numpy(Q)
+    nq, N = Qt.shape[0], Xt.shape[0]
+    qn = (Qt * Qt).sum(1) if metric == 1 else None
+    best_v = torch.full((nq, 0), 0.0)
+    best_i = torch.zeros((nq, 0), dtype=torch.int64)
+    for s in range(0, N, block):
+        xb = Xt[s:s + block]
+        S = Qt @ xb.T
+        if metric == 1:
+            S = -(qn[:, None] + (xb * xb).sum(1)[None, :] - 2.0 * S).clamp_min_(0.0)
+        v, i = torch.topk(S, min(k, S.shape[1]), dim=1)
+        best_v = torch.cat([best_v, v], 1)
+        best_i = torch.cat([best_i, i + s], 1)
+        if best_v.shape[1] > k:
+            best_v, sel = torch.topk(best_v, k, dim=1)
+            best_i = torch.gather(best_i, 1, sel)
+    order = torch.argsort(best_v, dim=1, descending=True, stable=True)
+    D, I = torch.gather(best_v, 1, order), torch.gather(best_i, 1, order)
+    if D.shape[1] < k:
+        pad = k - D.shape[1]
+        D = torch.cat([D, torch.full((nq, pad), -FLT_MAX)], 1)
+        I = torch.cat([I, torch.full((nq, pad), -1, dtype=torch.int64)], 1)
+    D = D.numpy()
+    return (-D if metric == 1 else D).astype(np.float32), I.numpy()
+
+
 # ----------------------------------------------------------------------------------------------
 # independent cross-checks (slow; small cases only)
 # ----------------------------------------------------------------------------------------------
 def knn_numpy_f64(X, Q, k, metric=0):
     """float64 scores + (score, id) lexicographic order. Independent of knn_oracle.c."""
     X64, Q64 = np.asarray(X, np.float64), np.asarray(Q, np.float64)
-    S = Q64 @ X64.T
     if metric == 1:
-        S = (Q64 ** 2).sum(1)[:, None] + (X64 ** 2).sum(1)[None, :] - 2 * S
-        S = np.maximum(S, 0)
+        S = ((Q64[:, None, :] - X64[None, :, :]) ** 2).sum(2) if Q64.shape[0] * X64.shape[0] * X64.shape[1] <= 1 << 24 else \
+            np.maximum((Q64 ** 2).sum(1)[:, None] + (X64 ** 2).sum(1)[None, :] - 2 * (Q64 @ X64.T), 0)
         order = np.lexsort((np.broadcast_to(np.arange(S.shape[1]), S.shape), S), axis=1)
     else:
+        S = Q64 @ X64.T
         order = np.lexsort((np.broadcast_to(np.arange(S.shape[1]), S.shape), -S), axis=1)
     I = order[:, :k]
     D = np.take_along_axis(S, I, axis=1)
     if I.shape[1] < k:
         pad = k - I.shape[1]
         I = np.concatenate([I, -np.ones((I.shape[0], pad), np.int64)], 1)
-        D = np.concatenate([D, np.full((D.shape[0], pad), np.inf if metric == 1 else -np.inf)], 1)
+        D = np.concatenate([D, np.full((D.shape[0], pad), FLT_MAX if metric == 1 else -FLT_MAX)], 1)
     return D, I.astype(np.int64)
 
 

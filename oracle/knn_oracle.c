@@ -20,13 +20,24 @@
  *   - METRIC_INNER_PRODUCT (metric_type 0, experiments/ir/viquae/dpr/search/
  *     config.json:18): score = <q, x>, larger is better, rows sorted descending.
  *   - METRIC_L2 (metric_type 1 / FAISS default): squared distance, smaller is
- *     better, ascending.  FAISS's BLAS path (nq >= 20; the reference searches
- *     256 queries per batch, dpr/search/config.json:25) evaluates
- *     ||q||^2 + ||x||^2 - 2<q,x>, clamped at 0.
- *   - a result-heap per query, initialised with (-inf | +inf, id -1), scanned
- *     over ascending database ids with a STRICT comparison: an equal score never
- *     displaces an earlier id, so the lower id wins membership at the k-th
- *     boundary; unfilled slots keep id -1.  NaN scores never enter.
+ *     better, ascending.  FAISS switches form on the batch size
+ *     (faiss/utils/distances.cpp, knn_L2sqr: `nx < distance_compute_blas_threshold`
+ *     with the threshold's default 20):
+ *       nq >= 20  (the reference searches 256 queries per batch,
+ *                 dpr/search/config.json:25): the BLAS path evaluates
+ *                 ||q||^2 + ||x||^2 - 2<q,x>, clamped at 0;
+ *       nq <  20  (the last Dataset.map batch of a run, meerqat/ir/search.py:482,
+ *                 or interact/system.py's single query): the sequential path sums
+ *                 (q[k] - x[k])^2 directly -- no cancellation, no clamp.
+ *     The two forms differ in the last bits of every distance and markedly near 0
+ *     (near-duplicates), so both are restated; `l2_form` selects (0 = FAISS's rule).
+ *   - a result-heap per query, initialised with (-FLT_MAX | +FLT_MAX, id -1)
+ *     (faiss heap neutral values: CMin::neutral() = lowest(), CMax::neutral() =
+ *     max()), scanned over ascending database ids with a STRICT comparison: an
+ *     equal score never displaces an earlier id, so the lower id wins membership
+ *     at the k-th boundary; unfilled slots keep id -1 and +-FLT_MAX
+ *     (3.4028235e+38, what FAISS prints when k > ntotal).  NaN, +-inf on the
+ *     wrong side and the neutral value itself never enter.
  *   - output order: best first; equal scores by ascending id (documented
  *     choice; FAISS's order inside an equal-score run is version dependent).
  *
@@ -37,6 +48,7 @@
  * (cdna_hip_programming.md section 3), so the HIP path is compared BIT-EXACTLY
  * (scores and ids) with this file on arbitrary fp32 data.
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -94,12 +106,18 @@ static inline void list_insert(ent_t *list, int k, float g, int64_t id) {
  * X [N,d] row-major, Q [nq,d] row-major, D [nq,k] fp32, I [nq,k] int64.
  * ids are reported as row + id_offset.  Returns 0, or -1 on bad arguments.
  */
-int oracle_knn_f32(const float *X, int64_t N, int d, const float *Q, int nq, int k, int metric,
-                   int64_t id_offset, float *D, int64_t *I) {
+#define FAISS_BLAS_THRESHOLD 20 /* faiss::distance_compute_blas_threshold */
+
+/* l2_form (metric 1 only): 0 = FAISS's rule (direct below 20 queries, expanded otherwise),
+ * 1 = expanded ||q||^2 + ||x||^2 - 2<q,x> clamped at 0, 2 = direct sum of (q-x)^2. */
+int oracle_knn_f32_ex(const float *X, int64_t N, int d, const float *Q, int nq, int k, int metric, int l2_form,
+                      int64_t id_offset, float *D, int64_t *I) {
     if (N < 0 || d <= 0 || nq < 0 || k <= 0 || (metric != 0 && metric != 1)) return -1;
+    if (l2_form < 0 || l2_form > 2) return -1;
+    const int direct = metric == 1 && (l2_form == 2 || (l2_form == 0 && nq < FAISS_BLAS_THRESHOLD));
     int nblk = (nq + QB - 1) / QB;
     float *xn = NULL;
-    if (metric == 1) {
+    if (metric == 1 && !direct) {
         xn = (float *)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1));
         oracle_sqnorm_rows_f32(X, N, d, xn);
     }
@@ -113,12 +131,12 @@ int oracle_knn_f32(const float *X, int64_t N, int d, const float *Q, int nq, int
         float qn[QB], thr[QB];
         for (int j = 0; j < nb; ++j) {
             for (int kk = 0; kk < d; ++kk) Qt[(size_t)kk * QB + j] = Q[(size_t)(q0 + j) * d + kk];
-            qn[j] = metric == 1 ? chain_dot(Q + (size_t)(q0 + j) * d, Q + (size_t)(q0 + j) * d, d) : 0.0f;
+            qn[j] = (metric == 1 && !direct) ? chain_dot(Q + (size_t)(q0 + j) * d, Q + (size_t)(q0 + j) * d, d) : 0.0f;
         }
         for (int j = 0; j < QB; ++j) {
-            thr[j] = -INFINITY;
+            thr[j] = -FLT_MAX;
             for (int s = 0; s < k; ++s) {
-                lists[(size_t)j * k + s].g = -INFINITY;
+                lists[(size_t)j * k + s].g = -FLT_MAX;
                 lists[(size_t)j * k + s].id = -1;
             }
         }
@@ -126,12 +144,25 @@ int oracle_knn_f32(const float *X, int64_t N, int d, const float *Q, int nq, int
             const float *x = X + i * (int64_t)d;
             float acc[QB];
             for (int j = 0; j < QB; ++j) acc[j] = 0.0f;
-            for (int kk = 0; kk < d; ++kk) {
-                const float xv = x[kk];
-                const float *qr = Qt + (size_t)kk * QB;
-                for (int j = 0; j < QB; ++j) acc[j] = fmaf(xv, qr[j], acc[j]);
+            if (direct) {
+                /* faiss fvec_L2sqr: tmp = x[i] - y[i]; res += tmp * tmp (x = query, y = database row) */
+                for (int kk = 0; kk < d; ++kk) {
+                    const float xv = x[kk];
+                    const float *qr = Qt + (size_t)kk * QB;
+                    for (int j = 0; j < QB; ++j) {
+                        const float t = qr[j] - xv;
+                        acc[j] = fmaf(t, t, acc[j]);
+                    }
+                }
+                for (int j = 0; j < QB; ++j) acc[j] = -acc[j];
+            } else {
+                for (int kk = 0; kk < d; ++kk) {
+                    const float xv = x[kk];
+                    const float *qr = Qt + (size_t)kk * QB;
+                    for (int j = 0; j < QB; ++j) acc[j] = fmaf(xv, qr[j], acc[j]);
+                }
             }
-            if (metric == 1) {
+            if (metric == 1 && !direct) {
                 for (int j = 0; j < QB; ++j) {
                     float dis = (qn[j] + xn[i]) - 2.0f * acc[j];
                     if (dis < 0.0f) dis = 0.0f;
@@ -142,7 +173,7 @@ int oracle_knn_f32(const float *X, int64_t N, int d, const float *Q, int nq, int
                 if (acc[j] > thr[j]) { /* strict; false for NaN */
                     ent_t *l = lists + (size_t)j * k;
                     list_insert(l, k, acc[j], i);
-                    thr[j] = l[k - 1].id < 0 ? -INFINITY : l[k - 1].g;
+                    thr[j] = l[k - 1].id < 0 ? -FLT_MAX : l[k - 1].g;
                 }
             }
         }
@@ -151,7 +182,7 @@ int oracle_knn_f32(const float *X, int64_t N, int d, const float *Q, int nq, int
                 const ent_t e = lists[(size_t)j * k + s];
                 float out;
                 if (e.id < 0)
-                    out = metric == 1 ? INFINITY : -INFINITY;
+                    out = metric == 1 ? FLT_MAX : -FLT_MAX;
                 else
                     out = metric == 1 ? -e.g : e.g;
                 D[(size_t)(q0 + j) * k + s] = out + 0.0f; /* -0 -> +0 */
@@ -163,6 +194,11 @@ int oracle_knn_f32(const float *X, int64_t N, int d, const float *Q, int nq, int
     }
     free(xn);
     return 0;
+}
+
+int oracle_knn_f32(const float *X, int64_t N, int d, const float *Q, int nq, int k, int metric,
+                   int64_t id_offset, float *D, int64_t *I) {
+    return oracle_knn_f32_ex(X, N, d, Q, nq, k, metric, 0, id_offset, D, I);
 }
 
 /*
@@ -191,7 +227,7 @@ int oracle_topk_merge(const float *Ds, const int64_t *Is, int nshards, int nq, i
                 }
             }
             if (best < 0) {
-                D[(size_t)q * k + s] = metric == 1 ? INFINITY : -INFINITY;
+                D[(size_t)q * k + s] = metric == 1 ? FLT_MAX : -FLT_MAX;
                 I[(size_t)q * k + s] = -1;
             } else {
                 D[(size_t)q * k + s] = (metric == 1 ? -bg : bg) + 0.0f;

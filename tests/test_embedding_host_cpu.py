@@ -216,3 +216,36 @@ def test_multimodal_input_builders_match_the_reference_shapes():
     assert im["clip-RN50"]["input"].shape == (3, 1, 2) and im["clip-RN50"]["attention_mask"].tolist() == [[1], [1], [1]]
     zero = IE.get_face_inputs(batch, n_faces=0, face_dim=3, bbox_dim=7)
     assert zero["face"].shape == (3, 1, 0, 3)
+
+
+def test_main_keeps_the_kb_columns_a_multimodal_model_reads(tmp_path, monkeypatch):
+    """ADVICE r1 / meerqat/ir/embedding.py:289-293: with --kb, a multimodal (MMConfig) model needs the KB's face and image
+    columns; a text-only model only the title."""
+    import datasets
+    import json
+    from viquae_amd.ir import embedding as E
+    from viquae_amd.data import loading
+
+    class MMConfig:
+        image_kwargs = {"clip-RN50": {}}
+
+    class Model:
+        def __init__(self, config):
+            self.config = config
+
+        def to(self, device):
+            return self
+
+        def eval(self):
+            return self
+
+    kb = datasets.Dataset.from_dict({"wikidata_label": ["a"], "face_embedding": [[0.0]], "face_box": [[0.0]], "clip-RN50": [[0.0]],
+                                     "passage_index": [[0]]})
+    kb.save_to_disk(str(tmp_path / "kb"))
+    (tmp_path / "config.json").write_text(json.dumps({"key": "passage"}))
+    seen = {}
+    monkeypatch.setattr(E, "dataset_embed", lambda path, model=None, kb=None, output_path=None, **kw: seen.update(cols=set(kb.column_names)))
+    for cfg, want in ((MMConfig(), {"face_embedding", "face_box", "clip-RN50"}), (object(), {"wikidata_label"})):
+        monkeypatch.setattr(loading, "load_pretrained_in_kwargs", lambda c, cfg=cfg: dict(c, model=Model(cfg)))
+        E.main("unused", str(tmp_path / "config.json"), kb_path=str(tmp_path / "kb"))
+        assert seen["cols"] == want

@@ -128,3 +128,41 @@ def test_fullsize_embedding_like_kb_with_a_shared_component():
     flagged, rescored = scr.screen_stats(512, K)[:2]
     assert flagged == 0 and rescored / 512 < 330
     assert float(D1.min()) > 80.0          # the scores really sit on top of the shared component
+
+
+def test_config3_search_half_1p5M_x_512_l2norm_flat():
+    """BASELINE configs[3], search half: 1.5M x 512 CLIP-like vectors under "L2norm,Flat" + inner product
+    (experiments/ir/viquae/clip/config.json), 4096 queries, top-100.  The screened search must equal the exact fp32 scan
+    bit for bit over the whole batch; planted neighbours, sortedness, id validity / uniqueness and the cosine range are the
+    size-independent properties."""
+    import torch
+    from viquae_amd.index import MI355XFlatIndex
+    d = 512
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    scr = MI355XFlatIndex(string_factory="L2norm,Flat", metric_type=0, screen=True)
+    ex = MI355XFlatIndex(string_factory="L2norm,Flat", metric_type=0, screen=False)
+    keep = {}
+    planted = (torch.arange(64) * 23431 + 7).tolist()
+    for s in range(0, N, 1 << 16):
+        x = torch.randn((min(1 << 16, N - s), d), generator=g, device=dev)
+        scr.add(x, total_hint=N)
+        ex.add(x, total_hint=N)
+        for p in planted:
+            if s <= p < s + x.shape[0]:
+                keep[p] = x[p - s].clone()
+    Q = torch.randn((NQ, d), generator=g, device=dev)
+    for i, p in enumerate(planted):
+        Q[i] = 5.0 * keep[p]          # any positive multiple: "L2norm," normalises the query as well
+    D1, I1 = scr.search_device(Q, K)
+    D2, I2 = ex.search_device(Q, K)
+    torch.cuda.synchronize()
+    assert torch.equal(I1, I2) and torch.equal(D1, D2)
+    assert scr.screen_stats(NQ, K)[0] == 0                        # no query tile fell back to the exact scan
+    assert (I1[:64, 0].cpu() == torch.tensor(planted)).all()
+    assert ((D1[:64, 0] - 1.0).abs() < 1e-5).all()                # cosine of a vector with itself
+    assert (D1[:, :-1] >= D1[:, 1:]).all() and (D1.abs() <= 1.0 + 1e-5).all()
+    assert (I1 >= 0).all() and (I1 < N).all()
+    srt = I1.sort(dim=1).values
+    assert (srt[:, 1:] != srt[:, :-1]).all()

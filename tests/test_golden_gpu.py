@@ -30,7 +30,7 @@ def _tags(z):
             yield tag, l2, int(m[1:]), int(k[1:])
 
 
-@pytest.mark.parametrize("name", ["random", "small_nq", "lattice", "ties"])
+@pytest.mark.parametrize("name", ["random", "small_nq", "lattice", "ties", "lattice_small_nq", "ties_small_nq"])
 def test_knowledge_base_reproduces_reference_goldens(name):
     z = np.load(os.path.join(GOLDEN, f"knn_{name}.npz"))
     X, Q = z["X"].astype(np.float32), z["Q"].astype(np.float32)

@@ -101,13 +101,14 @@ def test_index_kwargs_accept_legacy_keys_and_reject_sparse_kinds(monkeypatch):
     made = {}
 
     class FakeIndex:
-        def __init__(self, device=None, string_factory=None, metric_type=None):
+        def __init__(self, device=None, string_factory=None, metric_type=None, screen=None):
             made.update(device=device, string_factory=string_factory, metric_type=metric_type)
 
         def add_vectors(self, ds, column=None, **kw):
             made["column"] = column
 
-    monkeypatch.setattr(S, "MI355XFlatIndex", FakeIndex)
+    from viquae_amd import sharded
+    monkeypatch.setattr(sharded, "MI355XFlatIndex", FakeIndex)  # what make_flat_index builds for one GPU
     ds = datasets.Dataset.from_dict({"DPR_few_shot": [[0.0, 1.0]]})
     kw = {"column": "DPR_few_shot", "es": False, "kind_str": "TEXT", "key": "DPR_few_shot",
           "normalization": {"method": "normalize", "mean": 71.3295, "std": 2.16671}, "string_factory": "Flat",
@@ -120,6 +121,78 @@ def test_index_kwargs_accept_legacy_keys_and_reject_sparse_kinds(monkeypatch):
         kb.add_or_load_index(column="x", kind="ES")
     with pytest.raises(KeyError):
         kb.add_or_load_index(column="x", kind="NOPE")
+
+
+def test_make_flat_index_follows_the_reference_device_convention(monkeypatch):
+    """datasets/search.py:315-347: int >= 0 -> that GPU, int < 0 -> all GPUs, list -> those GPUs (b2)."""
+    from viquae_amd import sharded
+
+    class One:
+        def __init__(self, device=None, **kw):
+            self.device = device
+
+    class Many:
+        def __init__(self, devices, **kw):
+            self.devices = list(devices)
+
+    monkeypatch.setattr(sharded, "MI355XFlatIndex", One)
+    monkeypatch.setattr(sharded, "LocalShardsFlatIndex", Many)
+    monkeypatch.setattr(sharded, "visible_gpus", lambda: [0, 1, 2, 3])
+    assert sharded.make_flat_index(device=None).device is None
+    assert sharded.make_flat_index(device=2).device == 2
+    assert sharded.make_flat_index(device=[3]).device == [3]
+    assert sharded.make_flat_index(device=-1).devices == [0, 1, 2, 3]
+    assert sharded.make_flat_index(device=[1, 3]).devices == [1, 3]
+    monkeypatch.setattr(sharded, "visible_gpus", lambda: [0])
+    assert sharded.make_flat_index(device=-1).device == 0   # "all GPUs" of a one-GPU box
+
+
+def test_shard_record_layout_matches_the_c_abi():
+    from viquae_amd import _lib
+    from viquae_amd.sharded import record_layout, _record_views, _gathered_views
+    import torch
+    lib = _lib.load()
+    for nq, k in ((1, 1), (3, 5), (4096, 100), (7, 128), (255, 33)):
+        rec, ids = record_layout(nq, k)
+        assert rec == lib.mq_shard_record_bytes(nq, k) and ids == lib.mq_shard_record_ids_offset(nq, k)
+        assert rec % 16 == 0 and ids % 8 == 0 and ids >= nq * k * 4 and rec >= ids + nq * k * 8
+        buf = torch.zeros(2 * rec, dtype=torch.uint8)
+        for r in range(2):
+            D, I = _record_views(buf[r * rec:(r + 1) * rec], nq, k)
+            D.fill_(r + 0.5)
+            I.fill_(r + 7)
+        Ds, Is = _gathered_views(buf, 2, nq, k)
+        assert Ds.shape == (2, nq, k) and float(Ds[1, -1, -1]) == 1.5 and int(Is[0, 0, 0]) == 7 and int(Is[1, -1, -1]) == 8
+
+
+def test_faiss_flat_files_of_the_reference_can_be_read(tmp_path):
+    """save_path / save_faiss_index of the reference write faiss.write_index files: IndexFlat ("Flat") or
+    IndexPreTransform + NormalizationTransform + IndexFlat ("L2norm,Flat").  Layout per FAISS's published
+    index_write.cpp (files assembled by hand: no FAISS binary in this image)."""
+    import struct
+    from viquae_amd.index import read_index_file_header
+    X = np.arange(12, dtype=np.float32).reshape(4, 3)
+
+    def hdr(d, n, metric):
+        return struct.pack("<iqqq?i", d, n, 1 << 20, 1 << 20, True, metric)
+
+    flat = b"IxF2" + hdr(3, 4, 1) + struct.pack("<Q", 12) + X.tobytes()
+    p = tmp_path / "flat.faiss"
+    p.write_bytes(flat)
+    n, d, metric, l2norm, off = read_index_file_header(str(p))
+    assert (n, d, metric, l2norm) == (4, 3, 1, False)
+    assert np.array_equal(np.fromfile(str(p), dtype=np.float32, count=12, offset=off).reshape(4, 3), X)
+    pre = (b"IxPT" + hdr(3, 4, 0) + struct.pack("<i", 1) + b"VNrm" + struct.pack("<f", 2.0) + struct.pack("<ii?", 3, 3, True)
+           + b"IxFI" + hdr(3, 4, 0) + struct.pack("<Q", 12) + X.tobytes())
+    p2 = tmp_path / "pre.faiss"
+    p2.write_bytes(pre)
+    n, d, metric, l2norm, off = read_index_file_header(str(p2))
+    assert (n, d, metric, l2norm) == (4, 3, 0, True)
+    assert np.array_equal(np.fromfile(str(p2), dtype=np.float32, count=12, offset=off).reshape(4, 3), X)
+    bad = tmp_path / "ivf.faiss"
+    bad.write_bytes(b"IwFl" + hdr(3, 4, 1))
+    with pytest.raises(ValueError):
+        read_index_file_header(str(bad))
 
 
 def test_shard_bounds_cover_rows_once():

@@ -3,6 +3,8 @@ KnowledgeBase, tools/make_golden.py) and against independent computations."""
 import os
 
 import numpy as np
+
+FLT_MAX = np.finfo(np.float32).max  # FAISS heap neutral value reported by unfilled slots
 import pytest
 
 from oracle import knn as ok
@@ -24,7 +26,7 @@ def _cases(g):
             yield tag, l2, int(parts[0][1:]), int(parts[1][1:])
 
 
-@pytest.mark.parametrize("name", ["random", "small_nq", "lattice", "ties"])
+@pytest.mark.parametrize("name", ["random", "small_nq", "lattice", "ties", "lattice_small_nq", "ties_small_nq"])
 def test_oracle_reproduces_golden(name):
     g = _load(name)
     X, Q = g["X"].astype(np.float32), g["Q"].astype(np.float32)
@@ -62,6 +64,57 @@ def test_golden_lattice_is_order_independent(name, metric):
     assert np.array_equal(np.take_along_axis(S, order, 1), g[f"D_m{metric}_k{k}"])
 
 
+@pytest.mark.parametrize("name", ["lattice_small_nq", "ties_small_nq"])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_small_batch_goldens_are_order_independent(name, metric):
+    """Fewer than 20 queries: FAISS's sequential path (direct sum of (q-x)^2 for L2).  On these integer fixtures every
+    partial sum is exact in fp32, so the golden must equal an independent float64 brute force of that form."""
+    g = _load(name)
+    X, Q = g["X"].astype(np.float32), g["Q"].astype(np.float32)
+    assert Q.shape[0] < 20
+    D64, I64 = ok.knn_numpy_f64(X, Q, 100, metric)
+    assert np.array_equal(g[f"I_m{metric}_k100"], I64)
+    assert np.array_equal(g[f"D_m{metric}_k100"].astype(np.float64), D64)
+
+
+def test_l2_form_follows_faiss_blas_threshold():
+    """19 queries -> direct form, 20 -> expanded form (faiss::distance_compute_blas_threshold = 20).  A KB row equal to
+    the query separates the forms: the direct sum is exactly 0, and distances to near-duplicates keep their relative
+    accuracy instead of the cancellation error of ||q||^2 + ||x||^2 - 2<q,x>."""
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((500, 96)).astype(np.float32) * 7
+    Q = X[:20].copy()
+    X[100:120] = Q * np.float32(1 + 2 ** -12)            # near-duplicates of the queries
+    Dd, Id = ok.knn(X, Q[:19], 3, metric=1)
+    Da, Ia = ok.knn(X, Q[:19], 3, metric=1, l2_form="direct")
+    assert np.array_equal(Dd, Da) and np.array_equal(Id, Ia)
+    assert (Dd[:, 0] == 0).all() and (Id[:, 0] == np.arange(19)).all()
+    De, Ie = ok.knn(X, Q, 3, metric=1)
+    Df, If = ok.knn(X, Q, 3, metric=1, l2_form="expanded")
+    assert np.array_equal(De, Df) and np.array_equal(Ie, If)
+    D64, _ = ok.knn_numpy_f64(X, Q[:19], 3, 1)
+    rel_direct = np.abs(Dd[:, 1] - D64[:, 1]) / D64[:, 1]
+    rel_expanded = np.abs(Df[:19, 1] - D64[:, 1]) / D64[:, 1]
+    assert rel_direct.max() < 1e-5 and rel_expanded.max() > 1e-3   # the forms are observably different
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_blas_leg_agrees_with_the_chain_oracle_up_to_near_ties(metric):
+    """bench.py's fast CPU leg (sgemm blocks + top-k, FAISS's own organisation for >= 20 queries) against the fmaf-chain
+    oracle: same neighbours except float64 near-ties, scores within fp32 summation error."""
+    rng = np.random.default_rng(12)
+    X = rng.standard_normal((5000, 96), dtype=np.float32)
+    Q = rng.standard_normal((40, 96), dtype=np.float32)
+    D, I = ok.knn(X, Q, 50, metric=metric)
+    Db, Ib = ok.knn_blas(X, Q, 50, metric=metric, block=1024)
+    assert np.allclose(D, Db, rtol=1e-4, atol=1e-3)
+    D64, _ = ok.knn_numpy_f64(X, Q, 5000, metric)
+    for q in range(len(Q)):
+        for i in set(I[q]) ^ set(Ib[q]):
+            s64 = dict(zip(ok.knn_numpy_f64(X, Q[q:q + 1], 5000, metric)[1][0], D64[q]))
+            assert abs(s64[i] - D64[q][49]) < 1e-3
+
+
 def test_free_form_golden_matches_float64_within_ties():
     """Free-form fp32 data: two correct fp32 implementations may swap near-ties; every index mismatch vs
     float64 must be such a near-tie (|score diff| tiny)."""
@@ -89,9 +142,9 @@ def test_fewer_rows_than_k_and_empty():
     X = np.eye(3, 8, dtype=np.float32)
     Q = np.ones((2, 8), np.float32)
     D, I = ok.knn(X, Q, 5)
-    assert (I[:, 3:] == -1).all() and np.isneginf(D[:, 3:]).all() and (I[:, :3] == [0, 1, 2]).all()
+    assert (I[:, 3:] == -1).all() and (D[:, 3:] == -FLT_MAX).all() and (I[:, :3] == [0, 1, 2]).all()
     D, I = ok.knn(X, Q, 5, metric=1)
-    assert (I[:, 3:] == -1).all() and np.isposinf(D[:, 3:]).all()
+    assert (I[:, 3:] == -1).all() and (D[:, 3:] == FLT_MAX).all()
     D, I = ok.knn(np.zeros((0, 8), np.float32), Q, 2)
     assert (I == -1).all()
 

@@ -62,3 +62,30 @@ def test_find_relevant_whole_word_matching():
     assert orig == [0] and rel == [0, 2]
     with pytest.raises(NotImplementedError):
         find_relevant([0], "1", ["1"], kb, question_type="Numerical")
+
+
+def test_cut_at_k_with_an_article_that_maps_to_no_passage_ranked_first():
+    """the cut-at-k test never fired when the first hit had an empty index_mapping entry, so the run grew past
+    k.  Expected = the reference's loop (meerqat/ir/search.py:413-440): insert every passage of a hit, then test the cut."""
+    from viquae_amd.ir.search import KnowledgeBase
+    from viquae_amd.ir.searcher import Searcher
+    import datasets
+    kb = KnowledgeBase(dataset=datasets.Dataset.from_dict({"vec": [[0.0]] * 5}))
+    kb.index_mapping = {0: [], 1: [10, 11], 2: [], 3: [12, 13, 14], 4: [15]}
+    s = Searcher(kb_kwargs={"a": {}}, k=3, kbs={"a": kb}, reference_kb=datasets.Dataset.from_dict({"passage": ["x"]}))
+    for many2one in (None, "max"):
+        kb.many2one = many2one
+        for indices in ([0, 1, 2, 3, 4], [0, 2, 1, 3, 4], [1, 0, 3, 2, 4], [0, 2], [3, 0, 1]):
+            scores = [5.0 - 0.5 * r for r in range(len(indices))]
+            want = {}
+            for score, i in zip(scores, indices):           # the reference's loop
+                for n, j in enumerate(kb.index_mapping[i]):
+                    if many2one is None:
+                        want[str(j)] = float(np.float32(score) - n * 1e-8)   # float32 arithmetic, like the reference under NumPy 2
+                    elif str(j) not in want or want[str(j)] < score:
+                        want[str(j)] = score
+                if len(want) >= s.k:
+                    break
+            got = {}
+            s._fill_run(kb, got, scores, indices)
+            assert list(got) == list(want) and np.allclose(list(got.values()), list(want.values()), rtol=0, atol=1e-9), (many2one, indices)

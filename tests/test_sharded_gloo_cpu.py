@@ -31,6 +31,13 @@ class _OracleLocal:
         rows = np.asarray(rows, np.float32)
         self.rows = rows if self.rows is None else np.concatenate([self.rows, rows])
 
+    @property
+    def ntotal(self):
+        return 0 if self.rows is None else len(self.rows)
+
+    def reconstruct_n(self):
+        return self.rows
+
     def search_device(self, q, k):
         from oracle import knn as ok
         X = self.rows if self.rows is not None else np.zeros((0, q.shape[1]), np.float32)
@@ -59,6 +66,17 @@ def _worker(rank, world, port, metric, n, out):
         lo, hi = shard_bounds(n, world, rank)
         assert idx.local.id_offset == lo and (idx.local.rows is None or len(idx.local.rows) == hi - lo)
         D, I = idx.search_batch(Q, 20)
+        # chunked (software-pipelined) search: several collectives in flight one after the other
+        D2, I2 = idx.search_device(torch.from_numpy(Q), 20, chunk=4)
+        assert np.array_equal(D2.numpy(), D) and np.array_equal(I2.numpy(), I)
+        # save (every rank writes its rows into ONE file) -> load_rows (every rank reads its range back)
+        path = out + ".index"
+        idx.save(path)
+        again = ShardedFlatIndex(string_factory="Flat", metric_type=metric, local_index=_OracleLocal(metric),
+                                 merge_fn=_oracle_merge).load_rows(path)
+        assert again.ntotal == n and again.local.id_offset == lo
+        D3, I3 = again.search_batch(Q, 20)
+        assert np.array_equal(D3, D) and np.array_equal(I3, I)
         if rank == 0:
             np.savez(out, D=D, I=I, X=X, Q=Q)
         dist.barrier()
@@ -66,7 +84,7 @@ def _worker(rank, world, port, metric, n, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("metric,n", [(0, 1000), (1, 1000), (0, 70)])
+@pytest.mark.parametrize("metric,n", [(0, 1000), (1, 1000), (0, 70), (1, 40), (0, 5)])  # 40, 5: rank 1 holds NO rows
 def test_world2_sharded_equals_unsharded(tmp_path, metric, n):
     from oracle import knn as ok
     out = str(tmp_path / "res.npz")

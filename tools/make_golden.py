@@ -62,6 +62,13 @@ def make_knn():
         "ties": (rng.integers(-2, 3, (3000, 16)).astype(np.float32), rng.integers(-2, 3, (21, 16)).astype(np.float32),
                  (100,), True),
     }
+    # fewer than 20 queries: FAISS's sequential L2 path (direct sum of (q-x)^2).  Values in [-64, 64] keep every
+    # partial sum of squares below 2^24, so the fp32 result is exact in any order = what FAISS itself returns.
+    # (drawn after the cases above so that their data, hence their fixtures, stay what they were)
+    cases["lattice_small_nq"] = (rng.integers(-64, 65, (1024, 768)).astype(np.float32),
+                                 rng.integers(-64, 65, (7, 768)).astype(np.float32), (100,), True)
+    cases["ties_small_nq"] = (rng.integers(-2, 3, (3000, 16)).astype(np.float32), rng.integers(-2, 3, (19, 16)).astype(np.float32),
+                              (100,), True)
     with tempfile.TemporaryDirectory() as tmp:
         for name, (X, Q, ks, exact) in cases.items():
             out = {"X": X.astype(np.int16) if exact else X, "Q": Q.astype(np.int16) if exact else Q}

@@ -54,7 +54,7 @@ def traffic(kernel):
             "write_kb_raw": write_kb}
 
 
-out = {"_note": "L2<->fabric bytes per full-size launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH "
+out = {"_profile": f"profiles/{tag}_pmc.json", "_note": "L2<->fabric bytes per full-size launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH "
                 "doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams; Infinity-Cache hits are included, so this is "
                 f"an upper bound of HBM bytes.  Raw counters: profiles/{tag}_pmc.json."}
 for key, kernel in (("screened_1500000x768_nq4096_k100", "screen_scan_kernel"), ("exact_f32_1500000x768_nq4096_k100", "knn_scan_kernel<0>")):

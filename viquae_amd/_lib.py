@@ -59,6 +59,9 @@ SIGNATURES = {
                                        c_int, c_ptr]),
     "mq_sum_groups_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
     "mq_topk_merge_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    "mq_shard_record_bytes": (c_sz, [c_int, c_int]),
+    "mq_shard_record_ids_offset": (c_sz, [c_int, c_int]),
+    "mq_topk_merge_records_f32": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "mq_image_plan": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "mq_image_preprocess_u8": (c_int, [c_ptr, c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_int, ctypes.c_double, c_ptr, c_ptr,
                                        c_ptr, c_ptr, c_sz, c_ptr]),

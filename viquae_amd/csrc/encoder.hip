@@ -18,6 +18,7 @@
 #include <math.h>
 
 #include "../../include/meerqat_hip.h"
+#include "launch_attr.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -999,7 +1000,7 @@ int mq_gemm_nt_f32(const float* A_dev, const float* W_dev, const float* bias_dev
     hipStream_t st = (hipStream_t)stream;
 #define MQ_LAUNCH(E)                                                                                                  \
     case E:                                                                                                           \
-        ENC_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES)); \
+        MQ_DYNAMIC_LDS_WITH(ENC_HIP, G_LDS_BYTES, gemm_nt_kernel<E>); \
         hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, block, G_LDS_BYTES, st, A_dev, W_dev, bias_dev, residual_dev, C_dev, M, N, K, ntm, ntn); \
         break;
     switch (epilogue) {
@@ -1036,7 +1037,7 @@ int mq_gemm_nt_bf16x3_f32(const float* A_dev, const uint16_t* Wh_dev, const uint
     hipStream_t st = (hipStream_t)stream;
 #define MQ_LAUNCH(E)                                                                                                  \
     case E:                                                                                                           \
-        ENC_HIP(hipFuncSetAttribute((const void*)gemm_nt_x3_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES)); \
+        MQ_DYNAMIC_LDS_WITH(ENC_HIP, X_LDS_BYTES, gemm_nt_x3_kernel<E>); \
         hipLaunchKernelGGL(gemm_nt_x3_kernel<E>, grid, block, X_LDS_BYTES, st, A_dev, (const unsigned short*)Wh_dev,    \
                            (const unsigned short*)Wl_dev, bias_dev, residual_dev, C_dev, M, N, K, ntm, ntn);           \
         break;
@@ -1068,7 +1069,7 @@ int mq_gemm_nt_bf16x3s_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const
     hipStream_t st = (hipStream_t)stream;
 #define MQ_LAUNCH2(E, S)                                                                                              \
     {                                                                                                                 \
-        ENC_HIP(hipFuncSetAttribute((const void*)gemm_nt_x3s_kernel<E, S>, hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS_BYTES)); \
+        MQ_DYNAMIC_LDS_WITH(ENC_HIP, XS_LDS_BYTES, gemm_nt_x3s_kernel<E, S>); \
         hipLaunchKernelGGL((gemm_nt_x3s_kernel<E, S>), grid, block, XS_LDS_BYTES, st, (const unsigned short*)Ah_dev,    \
                            (const unsigned short*)Al_dev, (const unsigned short*)Wh_dev, (const unsigned short*)Wl_dev, \
                            bias_dev, residual_dev, C_dev, (unsigned short*)Ch_dev, (unsigned short*)Cl_dev, M, N, K, ntm, ntn); \
@@ -1156,7 +1157,7 @@ int mq_attention_split_f32(const float* qkv_dev, const int64_t* attention_mask_d
 #define MQ_ATT(NKT, MULTI)                                                                                                   \
     {                                                                                                                 \
         const size_t lds = (size_t)(32 * NKT) * (65 + 64 + 1) * 4 > (size_t)4 * 32 * 65 * 4 ? (size_t)(32 * NKT) * (65 + 64 + 1) * 4 : (size_t)4 * 32 * 65 * 4; \
-        ENC_HIP(hipFuncSetAttribute((const void*)attention_mfma_kernel<NKT, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        MQ_DYNAMIC_LDS_WITH(ENC_HIP, mq_detail::LDS_PER_CU, attention_mfma_kernel<NKT, MULTI>); \
         hipLaunchKernelGGL((attention_mfma_kernel<NKT, MULTI>), grid, dim3(nthr), lds, st, qkv_dev, (const long long*)attention_mask_dev,    \
                            out_dev, (unsigned short*)out_h_dev, (unsigned short*)out_l_dev, L, heads, scale, causal ? 1 : 0); \
     }
@@ -1164,7 +1165,7 @@ int mq_attention_split_f32(const float* qkv_dev, const int64_t* attention_mask_d
     {                                                                                                                 \
         const size_t need = (size_t)(32 * NKT) * 128 * 2 + (size_t)64 * (32 * NKT) * 2 * 2 + (size_t)(32 * NKT) * 4;    \
         const size_t lds = need > (size_t)4 * 32 * 65 * 4 ? need : (size_t)4 * 32 * 65 * 4;                           \
-        ENC_HIP(hipFuncSetAttribute((const void*)attention_x3_kernel<NKT, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        MQ_DYNAMIC_LDS_WITH(ENC_HIP, mq_detail::LDS_PER_CU, attention_x3_kernel<NKT, MULTI>); \
         hipLaunchKernelGGL((attention_x3_kernel<NKT, MULTI>), grid, dim3(nthr), lds, st, qkv_dev, (const long long*)attention_mask_dev,    \
                            out_dev, (unsigned short*)out_h_dev, (unsigned short*)out_l_dev, L, heads, scale, causal ? 1 : 0); \
     }

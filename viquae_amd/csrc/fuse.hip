@@ -24,6 +24,7 @@
 #include <math.h>
 
 #include "../../include/meerqat_hip.h"
+#include "launch_attr.h"
 
 extern "C" void mq_internal_set_hip_error(int e);
 
@@ -294,8 +295,8 @@ extern "C" int mq_fuse_wsum_f64(const int64_t* ids_dev, const double* scores_dev
     A.R = n_runs; A.nq = nq; A.K = K; A.nsort = next_pow2(n_runs * K); A.norm = norm; A.defmin = defmin ? 1 : 0;
     for (int r = 0; r < MQ_FUSE_MAX_RUNS; ++r) A.w[r] = r < n_runs ? weights_host[r] : 0.0;
     const size_t lds = (size_t)A.nsort * 2 * sizeof(uint64_t);
-    FUSE_HIP(hipFuncSetAttribute((const void*)fuse_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    FUSE_HIP(hipFuncSetAttribute((const void*)fuse_combine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MQ_DYNAMIC_LDS_WITH(FUSE_HIP, mq_detail::LDS_PER_CU, fuse_stats_kernel);
+    MQ_DYNAMIC_LDS_WITH(FUSE_HIP, mq_detail::LDS_PER_CU, fuse_combine_kernel);
     hipLaunchKernelGGL(fuse_stats_kernel, dim3(nq), dim3(FT), lds, st, A);
     FUSE_HIP(hipGetLastError());
     if (norm == MQ_FUSE_NORM_GZMUV) {

@@ -19,10 +19,12 @@
 // restates on the CPU, so results are compared bit-exactly.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 
 #include "../../include/meerqat_hip.h"
+#include "launch_attr.h"
 
 typedef unsigned long long u64;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
 
     if (tid < TQ) {
         gcnt[tid] = 0;
-        tau[tid] = -INFINITY;
+        tau[tid] = -FLT_MAX;  // FAISS heap neutral value: a score must beat it strictly to enter (NaN, -inf, -FLT_MAX never do)
     }
 
     const int nkb = a.dpad / BK;
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(128) void slab_merge_kernel(const u64* __restrict__
     const int t = threadIdx.x;
     if (t < k) {
         float d;
-        if (out.id < 0) d = (METRIC == MQ_METRIC_L2) ? INFINITY : -INFINITY;
+        if (out.id < 0) d = (METRIC == MQ_METRIC_L2) ? FLT_MAX : -FLT_MAX;  // unfilled slot: FAISS reports its heap neutral value
         else d = ((METRIC == MQ_METRIC_L2) ? -out.g : out.g) + 0.0f;
         D[(size_t)q * k + t] = d;
         I[(size_t)q * k + t] = out.id < 0 ? -1 : out.id + id_offset;
@@ -653,15 +655,17 @@ __global__ __launch_bounds__(128) void slab_merge_kernel(const u64* __restrict__
 
 template <int METRIC>
 __global__ __launch_bounds__(128) void shard_merge_kernel(const float* __restrict__ Ds, const long long* __restrict__ Is,
-                                                          int nshards, int nq, int k, float* __restrict__ D,
-                                                          long long* __restrict__ I) {
+                                                          size_t d_stride, size_t i_stride, int nshards, int nq, int k,
+                                                          float* __restrict__ D, long long* __restrict__ I) {
+    // d_stride / i_stride: elements between two shards' [nq,k] blocks (nq*k for two dense arrays; the
+    // all-gathered per-rank records {scores | ids} give record_bytes/4 and record_bytes/8)
     __shared__ Ent Ra[128], Rb[128], Ls[128];
     const int q = blockIdx.x;
     auto fetch = [&](int s, int t) {
-        const size_t o = ((size_t)s * nq + q) * (size_t)k + t;
+        const size_t o = (size_t)q * (size_t)k + t;
         Ent e;
-        e.id = Is[o];
-        const float d = Ds[o];
+        e.id = Is[(size_t)s * i_stride + o];
+        const float d = Ds[(size_t)s * d_stride + o];
         e.g = (METRIC == MQ_METRIC_L2) ? -d : d;
         return e;
     };
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(128) void shard_merge_kernel(const float* __restric
     const int t = threadIdx.x;
     if (t < k) {
         float d;
-        if (out.id < 0) d = (METRIC == MQ_METRIC_L2) ? INFINITY : -INFINITY;
+        if (out.id < 0) d = (METRIC == MQ_METRIC_L2) ? FLT_MAX : -FLT_MAX;  // unfilled slot: FAISS reports its heap neutral value
         else d = ((METRIC == MQ_METRIC_L2) ? -out.g : out.g) + 0.0f;
         D[(size_t)q * k + t] = d;
         I[(size_t)q * k + t] = out.id < 0 ? -1 : out.id;
@@ -678,6 +682,7 @@ __global__ __launch_bounds__(128) void shard_merge_kernel(const float* __restric
 }
 
 #include "knn_screen.inc"
+#include "knn_direct.inc"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -695,6 +700,20 @@ inline int hip_fail(hipError_t e) {
     } while (0)
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// Cycle-accounting builds (-DMQ_TIMING, tools/scan_timing.py) hand the kernels a device buffer for their
+// per-wave timestamps through the environment; the shipped library never turns an environment variable
+// into a pointer.
+inline unsigned long long* dbg_ptr() {
+#ifdef MQ_TIMING
+    const char* e = getenv("MQ_DBG_PTR");
+    return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr;
+#else
+    return nullptr;
+#endif
+}
+
+#define MQ_DYNAMIC_LDS(bytes, ...) MQ_DYNAMIC_LDS_WITH(MQ_HIP, bytes, __VA_ARGS__)
 
 int num_cus() {
     static int cached = 0;  // idempotent, benign race
@@ -714,6 +733,9 @@ struct Geometry {
     int dp;
     size_t off_qb, off_margin, off_pcount, off_ovf, off_gthr, off_cand, off_ckeys, off_ccount, off_smax;
     int ms, sps;  // stripe-maxima slots per query / per slab
+    // FAISS's small-batch L2 path (knn_direct.inc): transposed queries + the [nq][npad] distance matrix
+    size_t off_dqt, off_ddist;
+    int64_t npad;
 };
 
 // bf16 row length of the screening copy: d (inner product) or d + 2 (L2: the (h, l) pair of -||x||^2 / 2), padded to 64
@@ -736,9 +758,8 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
     g.qpx = 0;
     g.qpx_screen = 0;
     {
-        int want = 0;
-        const char* e = getenv("MQ_KNN_QPX");
-        if (e) want = atoi(e);
+        static const int want_env = [] { const char* e = getenv("MQ_KNN_QPX"); return e ? atoi(e) : 0; }();  // tuning knob, read once
+        const int want = want_env;
         for (int q = 1; q <= g.nqt; ++q) {
             if (g.nqt % q) continue;
             const int ngroups = g.nqt / q;
@@ -772,6 +793,12 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
     g.off_cand = o;   o += nq1 * RMAX * 4;
     g.off_ckeys = o;  o += nq1 * RMAX * 8;
     g.off_ccount = o; o += (size_t)round_up((int64_t)nq1 * 4, 256);
+    g.npad = round_up(N > 0 ? N : 1, TN);
+    g.off_dqt = g.off_ddist = o;
+    if (nq > 0 && nq < MQ_KNN_L2_DIRECT_BELOW) {
+        g.off_dqt = o;   o += (size_t)round_up((int64_t)g.dpad * DIRECT_NQ * 4, 256);
+        g.off_ddist = o; o += (size_t)nq * (size_t)g.npad * 4;
+    }
     g.total = round_up((int64_t)o, 256);
     return g;
 }
@@ -854,6 +881,40 @@ int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[8]) {
     return MQ_OK;
 }
 
+// metric L2 with fewer than 20 queries: FAISS's sequential path, d = sum_k (q[k] - x[k])^2 (knn_direct.inc)
+static int knn_search_l2_direct(const float* packed_dev, int64_t N, int d, const float* queries_dev, int nq, int k,
+                                int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev, void* ws_dev,
+                                const Geometry& g, hipStream_t st) {
+    char* ws = (char*)ws_dev;
+    float* qtmp = (float*)(ws + g.off_qtmp);
+    float* Qt = (float*)(ws + g.off_dqt);
+    float* dist = (float*)(ws + g.off_ddist);
+    u64* lists = (u64*)(ws + g.off_lists);
+    const float* q_rm = queries_dev;
+    if (l2norm_queries) {
+        MQ_HIP(hipMemcpyAsync(qtmp, queries_dev, (size_t)nq * d * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, qtmp, (int64_t)nq, d);
+        MQ_HIP(hipGetLastError());
+        q_rm = qtmp;
+    }
+    hipLaunchKernelGGL(direct_transpose_queries_kernel, dim3((unsigned)((g.dpad * DIRECT_NQ + 255) / 256)), dim3(256), 0, st, q_rm,
+                       nq, d, g.dpad, Qt);
+    MQ_HIP(hipGetLastError());
+    const long long seg = (long long)((g.nchunks + g.S - 1) / g.S) * TN;  // rows per selection segment
+    if (N > 0) {
+        hipLaunchKernelGGL(l2_direct_dist_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, packed_dev, Qt, (long long)N, d,
+                           g.dpad, nq, (long long)g.npad, dist);
+        MQ_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(l2_direct_select_kernel, dim3((unsigned)g.S, (unsigned)nq), dim3(256), 0, st, dist, (long long)N,
+                       (long long)g.npad, seg, k, lists);
+    MQ_HIP(hipGetLastError());
+    hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(128), 0, st, lists, nq, g.S, k, (long long)id_offset,
+                       D_dev, (long long*)I_dev, (const int*)nullptr);
+    MQ_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
 static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int64_t N, int d, const float* queries_dev,
                            int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev,
                            void* ws_dev, size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
@@ -870,6 +931,8 @@ static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int
     float* qn = (float*)(ws + g.off_qn);
     float* qtmp = (float*)(ws + g.off_qtmp);
     u64* lists = (u64*)(ws + g.off_lists);
+    if (metric == MQ_METRIC_L2 && nq < MQ_KNN_L2_DIRECT_BELOW)
+        return knn_search_l2_direct(packed_dev, N, d, queries_dev, nq, k, l2norm_queries, id_offset, D_dev, I_dev, ws_dev, g, st);
 
     // queries -> panel layout (+ optional "L2norm," transform, + ||q||^2); padded queries are zero
     MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
@@ -882,14 +945,14 @@ static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int
     if (N > 0) {
         ScanArgs a;
         a.Xp = packed_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = lists;
-        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = (unsigned long long*)getenv("MQ_DBG_PTR") ? (unsigned long long*)strtoull(getenv("MQ_DBG_PTR"), nullptr, 0) : nullptr; a.only = nullptr;
+        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = dbg_ptr(); a.only = nullptr;
         const dim3 grid((unsigned)(g.nqt * g.S)), block(1024);
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
         if (metric == MQ_METRIC_IP) {
-            MQ_HIP(hipFuncSetAttribute((const void*)knn_scan_kernel<MQ_METRIC_IP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+            MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<MQ_METRIC_IP>);
             hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_IP>, grid, block, LDS_TOTAL, st, a);
         } else {
-            MQ_HIP(hipFuncSetAttribute((const void*)knn_scan_kernel<MQ_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+            MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<MQ_METRIC_L2>);
             hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_L2>, grid, block, LDS_TOTAL, st, a);
         }
         MQ_HIP(hipGetLastError());
@@ -967,6 +1030,8 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     const Geometry g = geometry(N, d, nq, k, num_cus());
     if (ws_bytes < g.total) return MQ_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (l2 && nq < MQ_KNN_L2_DIRECT_BELOW)
+        return knn_search_l2_direct(packed_dev, N, d, queries_dev, nq, k, l2norm_queries, id_offset, D_dev, I_dev, ws_dev, g, st);
     char* ws = (char*)ws_dev;
     float* Qp = (float*)(ws + g.off_qp);
     float* qn = (float*)(ws + g.off_qn);
@@ -1014,10 +1079,10 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         ScreenArgs a;
         a.Xb = bf16_dev; a.Qb = Qb; a.margin = margin; a.pools = pools; a.pcount = pcount; a.ovf = ovf; a.gthr = (unsigned*)(ws + g.off_gthr);
         a.smax = (unsigned*)(ws + g.off_smax); a.ms = g.ms; a.sps = g.sps;
-        a.dbg = getenv("MQ_DBG_PTR") ? (unsigned long long*)strtoull(getenv("MQ_DBG_PTR"), nullptr, 0) : nullptr;
+        a.dbg = dbg_ptr();
         a.N = N; a.dp = dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx_screen; a.nchunks = g.nchunks;
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
-        MQ_HIP(hipFuncSetAttribute((const void*)screen_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_TOTAL));
+        MQ_DYNAMIC_LDS(S_LDS_TOTAL, screen_scan_kernel);
         hipLaunchKernelGGL(screen_scan_kernel, dim3((unsigned)(g.nqt * g.S)), dim3(1024), S_LDS_TOTAL, st, a);
         MQ_HIP(hipGetLastError());
         if (ev_scan_end) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_end, st));
@@ -1045,13 +1110,13 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         a.Xp = packed_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = pools;
         a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = nullptr; a.only = ovf;
         if (l2) {
-            MQ_HIP(hipFuncSetAttribute((const void*)knn_scan_kernel<MQ_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+            MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<MQ_METRIC_L2>);
             hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_L2>, dim3((unsigned)(g.nqt * g.S)), dim3(1024), LDS_TOTAL, st, a);
             MQ_HIP(hipGetLastError());
             hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(128), 0, st, pools, nq, g.S, k,
                                (long long)id_offset, D_dev, (long long*)I_dev, (const int*)ovf);
         } else {
-            MQ_HIP(hipFuncSetAttribute((const void*)knn_scan_kernel<MQ_METRIC_IP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+            MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<MQ_METRIC_IP>);
             hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_IP>, dim3((unsigned)(g.nqt * g.S)), dim3(1024), LDS_TOTAL, st, a);
             MQ_HIP(hipGetLastError());
             hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, st, pools, nq, g.S, k,
@@ -1099,20 +1164,46 @@ int mq_knn_screen_stats(int64_t N, int d, int nq, int k, const void* ws_dev, int
     return MQ_OK;
 }
 
-int mq_topk_merge_f32(const float* Ds_dev, const int64_t* Is_dev, int nshards, int nq, int k, int metric, float* D_dev,
-                      int64_t* I_dev, void* stream) {
+static int topk_merge_impl(const float* Ds_dev, const int64_t* Is_dev, size_t d_stride, size_t i_stride, int nshards, int nq,
+                           int k, int metric, float* D_dev, int64_t* I_dev, void* stream) {
     if (nq == 0) return MQ_OK;
     if (!Ds_dev || !Is_dev || !D_dev || !I_dev || nshards <= 0 || nq < 0 || k <= 0) return MQ_EINVAL;
     if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
     if (k > MQ_KNN_MAX_K) return MQ_EUNSUPPORTED;
     if (metric == MQ_METRIC_IP)
         hipLaunchKernelGGL(shard_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, (hipStream_t)stream, Ds_dev,
-                           (const long long*)Is_dev, nshards, nq, k, D_dev, (long long*)I_dev);
+                           (const long long*)Is_dev, d_stride, i_stride, nshards, nq, k, D_dev, (long long*)I_dev);
     else
         hipLaunchKernelGGL(shard_merge_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(128), 0, (hipStream_t)stream, Ds_dev,
-                           (const long long*)Is_dev, nshards, nq, k, D_dev, (long long*)I_dev);
+                           (const long long*)Is_dev, d_stride, i_stride, nshards, nq, k, D_dev, (long long*)I_dev);
     MQ_HIP(hipGetLastError());
     return MQ_OK;
+}
+
+int mq_topk_merge_f32(const float* Ds_dev, const int64_t* Is_dev, int nshards, int nq, int k, int metric, float* D_dev,
+                      int64_t* I_dev, void* stream) {
+    const size_t n = (size_t)(nq > 0 ? nq : 0) * (size_t)(k > 0 ? k : 0);
+    return topk_merge_impl(Ds_dev, Is_dev, n, n, nshards, nq, k, metric, D_dev, I_dev, stream);
+}
+
+size_t mq_shard_record_bytes(int nq, int k) {
+    if (nq < 0 || k <= 0) return 0;
+    return (size_t)round_up((int64_t)nq * k * 12, 16);
+}
+
+size_t mq_shard_record_ids_offset(int nq, int k) {
+    if (nq < 0 || k <= 0) return 0;
+    return (size_t)round_up((int64_t)nq * k * 4, 8);
+}
+
+int mq_topk_merge_records_f32(const void* records_dev, int nshards, int nq, int k, int metric, float* D_dev, int64_t* I_dev,
+                              void* stream) {
+    if (nq == 0) return MQ_OK;
+    if (!records_dev || nq < 0 || k <= 0) return MQ_EINVAL;
+    if (((uintptr_t)records_dev & 7) != 0) return MQ_EINVAL;
+    const size_t rec = mq_shard_record_bytes(nq, k), ids = mq_shard_record_ids_offset(nq, k);
+    return topk_merge_impl((const float*)records_dev, (const int64_t*)((const char*)records_dev + ids), rec / 4, rec / 8, nshards,
+                           nq, k, metric, D_dev, I_dev, stream);
 }
 
 }  // extern "C"

@@ -44,6 +44,21 @@ _QUERY_CHUNK = 1 << 14
 _SCREEN_QUERY_CHUNK = 1 << 12
 
 
+L2_DIRECT_BELOW = 20  # faiss::distance_compute_blas_threshold (include/meerqat_hip.h, MQ_KNN_L2_DIRECT_BELOW)
+
+
+def query_chunks(nq, chunk):
+    """[(start, stop)] pieces of at most ``chunk`` queries, one C-ABI call each.  FAISS picks the form of the L2
+    distance from the size of the WHOLE batch (direct sum below 20 queries, BLAS form otherwise) and the C ABI
+    from the size of the call, so a batch of 20 or more queries is never cut into a piece of fewer than 20."""
+    bounds = [(s, min(s + chunk, nq)) for s in range(0, nq, chunk)]
+    if len(bounds) > 1 and bounds[-1][1] - bounds[-1][0] < L2_DIRECT_BELOW and chunk >= 4 * L2_DIRECT_BELOW:
+        cut = bounds[-1][0] - 2 * L2_DIRECT_BELOW
+        bounds[-2] = (bounds[-2][0], cut)
+        bounds[-1] = (cut, nq)
+    return bounds
+
+
 def parse_string_factory(string_factory):
     """Returns do_l2norm for the factories the reference ships; raises for anything else.
 
@@ -76,13 +91,13 @@ def _resolve_device(device):
         return torch.device("cuda", torch.cuda.current_device())
     if isinstance(device, int):
         if device < 0:
-            raise TypeError("device=-1 (all GPUs) is served by viquae_amd.sharded.ShardedFlatIndex "
-                            "(one process per GPU); MI355XFlatIndex is a single-GPU shard")
+            raise TypeError("device=-1 (all GPUs) is served by viquae_amd.sharded.make_flat_index / "
+                            "LocalShardsFlatIndex; MI355XFlatIndex is a single-GPU shard")
         return torch.device("cuda", device)
     if isinstance(device, (list, tuple)):
         if len(device) == 1:
             return torch.device("cuda", int(device[0]))
-        raise TypeError("a device list is served by viquae_amd.sharded.ShardedFlatIndex (one process per GPU)")
+        raise TypeError("a device list is served by viquae_amd.sharded.make_flat_index / LocalShardsFlatIndex")
     if isinstance(device, torch.device):
         return device
     raise TypeError(f"The argument type: {type(device)} is not expected. "
@@ -122,7 +137,7 @@ class MI355XFlatIndex(BaseIndex):
         self._center = None    # torch.float32 [d]: the vector the bf16 screening copy is centred on (inner product only)
 
     # ------------------------------------------------------------------ construction
-    def _ensure_capacity(self, n_total, d):
+    def _ensure_capacity(self, n_total, d, exact=True):
         import torch
         lib = _lib.load()
         if self._torch_device is None:
@@ -134,7 +149,9 @@ class MI355XFlatIndex(BaseIndex):
         cap = int(lib.mq_padded_rows(n_total))
         if cap <= self._capacity:
             return
-        # grow geometrically when appending repeatedly; exact when the total is known up front
+        if not exact and self._capacity:
+            # appending without a known total: grow by 1.5x so that repeated add() calls copy O(N) rows overall
+            cap = int(lib.mq_padded_rows(max(n_total, self._capacity + self._capacity // 2)))
         dpad = int(lib.mq_padded_dim(self.d))
         new_packed = torch.zeros(cap * dpad, dtype=torch.float32, device=self._torch_device)
         new_sqnorm = torch.zeros(cap, dtype=torch.float32, device=self._torch_device)
@@ -170,7 +187,7 @@ class MI355XFlatIndex(BaseIndex):
         if self.ntotal % 64 != 0:
             raise ValueError("MI355XFlatIndex.add: previous adds must total a multiple of 64 rows "
                              "(add_vectors batches accordingly)")
-        self._ensure_capacity(max(self.ntotal + n, total_hint or 0), d)
+        self._ensure_capacity(max(self.ntotal + n, total_hint or 0), d, exact=bool(total_hint))
         stream = torch.cuda.current_stream(self._torch_device).cuda_stream
         with torch.cuda.device(self._torch_device):
             for i in range(0, n, _UPLOAD_ROWS):
@@ -248,9 +265,10 @@ class MI355XFlatIndex(BaseIndex):
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self._torch_device)
         return self._ws
 
-    def search_device(self, queries, k):
+    def search_device(self, queries, k, out=None):
         """queries: CUDA float32 [nq,d] tensor on this index's device -> (D [nq,k] f32, I [nq,k] i64)
-        CUDA tensors.  This is the raw hot path: one mq_knn_search_f32 call per <=16384 queries."""
+        CUDA tensors.  This is the raw hot path: one C-ABI search call per <= 4096 (screened) / 16384 queries.
+        ``out`` = (D, I) preallocated contiguous CUDA tensors to write into (e.g. views of a shard record)."""
         import torch
         lib = _lib.load()
         if self._packed is None:
@@ -266,17 +284,23 @@ class MI355XFlatIndex(BaseIndex):
         if self.ntotal == 0:
             raise ValueError("the index is empty: call add_vectors first")
         queries = queries.to(dtype=torch.float32).contiguous()
-        D = torch.empty((nq, k), dtype=torch.float32, device=self._torch_device)
-        I = torch.empty((nq, k), dtype=torch.int64, device=self._torch_device)
+        if out is not None:
+            D, I = out
+            if (tuple(D.shape) != (nq, k) or tuple(I.shape) != (nq, k) or D.dtype != torch.float32 or I.dtype != torch.int64
+                    or not D.is_contiguous() or not I.is_contiguous() or D.device != self._torch_device):
+                raise ValueError("out must be contiguous (float32 [nq,k], int64 [nq,k]) tensors on the index's device")
+        else:
+            D = torch.empty((nq, k), dtype=torch.float32, device=self._torch_device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=self._torch_device)
         stream = torch.cuda.current_stream(self._torch_device).cuda_stream
         with torch.cuda.device(self._torch_device):
             # screened path: 16 query tiles x 16 KB slabs per call keep 256 stripe maxima per query (tightest thresholds)
             chunk = _SCREEN_QUERY_CHUNK if self.screen else _QUERY_CHUNK
-            for s in range(0, nq, chunk):
-                q = queries[s:s + chunk]
+            for s, e in query_chunks(nq, chunk):
+                q = queries[s:e]
                 nb = int(lib.mq_knn_workspace_bytes(self.ntotal, self.d, q.shape[0], k))
                 ws = self._workspace(nb)
-                Dq, Iq = D[s:s + chunk], I[s:s + chunk]
+                Dq, Iq = D[s:e], I[s:e]
                 if self.screen:
                     _lib.check(lib.mq_knn_search_screened_f32(
                         self._packed.data_ptr(), self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(),
@@ -350,14 +374,14 @@ class MI355XFlatIndex(BaseIndex):
 
     @classmethod
     def load(cls, file: Union[str, PurePath], device=None, storage_options: Optional[dict] = None):
-        """FaissIndex.load (datasets/search.py:399-416)."""
-        with open(os.fspath(file), "rb") as f:
-            if f.read(8) != _MAGIC:
-                raise ValueError(f"{file} is not an MI355XFlatIndex file")
-            n, d, metric, l2norm, _ = struct.unpack("<qiiii", f.read(24))
-            rows = np.frombuffer(f.read(n * d * 4), dtype=np.float32).reshape(n, d)
+        """FaissIndex.load (datasets/search.py:399-416).  Reads this class's own files and the FAISS files
+        the reference's ``save_path`` / ``dataset.save_faiss_index`` wrote for the factories it ships
+        (IndexFlat, and IndexPreTransform(NormalizationTransform, IndexFlat) for "L2norm,Flat")."""
+        path = os.fspath(file)
+        n, d, metric, l2norm, data_off = read_index_file_header(path)
         idx = cls(device=device, string_factory="L2norm,Flat" if l2norm else "Flat", metric_type=metric)
         if n:
+            rows = np.fromfile(path, dtype=np.float32, count=n * d, offset=data_off).reshape(n, d)
             # rows were stored after normalisation: do not normalise twice on load
             idx.do_l2norm = False
             idx.add(rows, total_hint=n)
@@ -365,6 +389,74 @@ class MI355XFlatIndex(BaseIndex):
         else:
             idx.d = d or None
         return idx
+
+
+def _read_faiss_flat(f, path):
+    """FAISS index file (faiss/impl/index_write.cpp, index_read.cpp as published for faiss >= 1.7.1, the
+    reference's pin; no FAISS binary exists in this image, so this reader is checked against files
+    assembled by hand from that published layout, not against FAISS itself):
+
+      IndexFlat             "IxFI" (inner product) | "IxF2" (L2) | "IxFl" (legacy), index header, then the
+                            vectors as {size_t count_of_floats, fp32 data}
+      index header          int d, int64 ntotal, int64 dummy, int64 dummy, bool is_trained, int metric_type
+                            (+ float metric_arg when metric_type > 1)
+      IndexPreTransform     "IxPT", index header, int n_transforms, the transforms, then the sub-index
+      NormalizationTransform "VNrm", float norm, then int d_in, int d_out, bool is_trained
+
+    Returns (n, d, metric, l2norm, offset of the fp32 matrix)."""
+    def rd(fmt):
+        size = struct.calcsize(fmt)
+        b = f.read(size)
+        if len(b) != size:
+            raise ValueError(f"{path}: truncated FAISS index file")
+        return struct.unpack(fmt, b)
+
+    def header():
+        d, ntotal, _, _, _trained, metric = rd("<iqqq?i")
+        if metric > 1:
+            rd("<f")
+        return d, ntotal, metric
+
+    l2norm = False
+    fourcc = f.read(4)
+    if fourcc == b"IxPT":
+        header()
+        (nt,) = rd("<i")
+        for _ in range(nt):
+            vt = f.read(4)
+            if vt != b"VNrm":
+                raise ValueError(f"{path}: FAISS pre-transform {vt!r} is not supported (only the NormalizationTransform "
+                                 "of 'L2norm,Flat')")
+            (norm,) = rd("<f")
+            rd("<ii?")
+            if norm != 2.0:
+                raise ValueError(f"{path}: NormalizationTransform with norm {norm} (only L2 is supported)")
+            l2norm = True
+        fourcc = f.read(4)
+    if fourcc not in (b"IxFI", b"IxF2", b"IxFl"):
+        raise ValueError(f"{path}: FAISS index type {fourcc!r} is not an exact Flat index "
+                         "(MI355XFlatIndex provides 'Flat' and 'L2norm,Flat')")
+    d, n, metric = header()
+    if metric not in (METRIC_INNER_PRODUCT, METRIC_L2):
+        raise ValueError(f"{path}: unsupported FAISS metric_type {metric}")
+    (count,) = rd("<Q")
+    if count != n * d:
+        raise ValueError(f"{path}: FAISS IndexFlat holds {count} floats, expected {n} x {d}")
+    return int(n), int(d), int(metric), l2norm, f.tell()
+
+
+def read_index_file_header(path):
+    """(n, d, metric, l2norm, byte offset of the row-major fp32 matrix) of an index file: this build's
+    "MQFLAT01" format or a FAISS IndexFlat / IndexPreTransform file (see _read_faiss_flat)."""
+    with open(path, "rb") as f:
+        magic = f.read(8)
+        if magic == _MAGIC:
+            n, d, metric, l2norm, _ = struct.unpack("<qiiii", f.read(24))
+            return int(n), int(d), int(metric), bool(l2norm), 32
+        if magic[:4] in (b"IxFI", b"IxF2", b"IxFl", b"IxPT"):
+            f.seek(0)
+            return _read_faiss_flat(f, path)
+    raise ValueError(f"{path} is neither an MI355XFlatIndex file nor a FAISS Flat index file")
 
 
 def iter_arrow_column(dataset, column):

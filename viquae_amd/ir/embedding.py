@@ -242,7 +242,12 @@ def main(dataset_path, config_path, kb_path=None, output_path=None):
     kb = None
     if kb_path:
         kb = load_from_disk(kb_path)
-        kb = kb.remove_columns([c for c in kb.column_names if c not in {"wikidata_label"}])
+        # meerqat/ir/embedding.py:289-293: multimodal models read faces and image vectors from the KB, text-only ones the title
+        if is_multimodal(model):
+            keep_columns = {"face_embedding", "face_box"} | set(model.config.image_kwargs.keys())
+        else:
+            keep_columns = {"wikidata_label"}
+        kb = kb.remove_columns([c for c in kb.column_names if c not in keep_columns])
     return dataset_embed(dataset_path, model=model, kb=kb, output_path=output_path, **config)
 
 

@@ -142,12 +142,25 @@ class KnowledgeBase:
         if index_name is None:
             index_name = column
         do_L2norm = string_factory is not None and "L2norm" in string_factory
+        # which index class serves `device` (one GPU, all GPUs of this process, or this rank's shard of a
+        # torch.distributed job): viquae_amd.sharded.make_flat_index
+        from ..sharded import ShardedFlatIndex, make_flat_index
         if load:
             if file is None:
                 raise ValueError("load=True needs `file` (the path passed to save_faiss_index / save_path)")
-            index = MI355XFlatIndex.load(file, device=device)
+            index = make_flat_index(device=device, string_factory=string_factory, metric_type=metric_type)
+            if isinstance(index, ShardedFlatIndex):
+                index.load_rows(file)  # every rank reads only its own row range
+            elif isinstance(index, MI355XFlatIndex):
+                index = MI355XFlatIndex.load(file, device=device)
+            else:
+                from ..index import read_index_file_header
+                n, d, metric, l2norm, off = read_index_file_header(file)
+                index = make_flat_index(device=device, string_factory="Flat", metric_type=metric)  # rows already normalised
+                index.add_vectors(np.fromfile(file, dtype=np.float32, count=n * d, offset=off).reshape(n, d))
+                index.do_l2norm = bool(l2norm)
         else:
-            index = MI355XFlatIndex(device=device, string_factory=string_factory, metric_type=metric_type)
+            index = make_flat_index(device=device, string_factory=string_factory, metric_type=metric_type)
             index.add_vectors(self.dataset, column=column, batch_size=batch_size, train_size=train_size,
                               faiss_verbose=faiss_verbose)
             if save_path is not None:

@@ -148,8 +148,9 @@ class Searcher:
                     run_q[j] = s
             else:
                 raise ValueError(f"Invalid value for many2one: '{kb.many2one}'. Choose from {{None, 'max'}}")
-            # the reference tests the cut after each HIT (all passages of an article are inserted first)
-            while hit < len(ends) and n + 1 == ends[hit]:
+            # the reference tests the cut after each HIT (all passages of an article are inserted first); `<=` also steps
+            # over hits that map to no passage at all (an empty index_mapping entry, ends[hit] == ends[hit - 1])
+            while hit < len(ends) and ends[hit] <= n + 1:
                 hit += 1
                 if len(run_q) >= self.k:
                     return
