@@ -445,7 +445,7 @@ def main():
             local._ws, keep = ws, local._ws
             st = local.screen_stats(nqc, k)
             local._ws = keep
-            rec["config"]["screen"] = {"query_tiles_recomputed_exactly": st[0], "candidates_rescored_per_query": round(st[1] / nq, 1),
+            rec["config"]["screen"] = {"query_tiles_recomputed_exactly": st[0], "candidates_rescored_per_query": round(st[1] / nqc, 1),
                                        "max_candidates_of_a_query": st[2]}
         if other is not None:
             rec["other_exact_path"] = other
