@@ -499,7 +499,13 @@ def main():
                 torch.cuda.synchronize()
                 t3 = (time.perf_counter() - t3) / 5
                 del clip_idx
+                try:
+                    import bench_host_path
+                    surface = bench_host_path.main(rows=rows)
+                except Exception as e:
+                    surface = {"error": repr(e)}
                 rec["secondary"] = {
+                    "reference_call_surface": surface,
                     "clip_kb_search": {"workload": f"{rows}x512 'L2norm,Flat' inner-product KB, {nq} queries, exact top-{k} (screened path)",
                                        "queries_per_s": round(nq / t3, 1), "ms_per_step": round(t3 * 1e3, 3)},
                     "kb_passages_encoded_per_s": round(d["passages_per_s"], 1),

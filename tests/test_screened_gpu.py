@@ -101,7 +101,8 @@ def test_l2_screen_equals_exact_scan_and_oracle(n, d, nq, k):
     assert np.array_equal(I, I0) and np.array_equal(D, D0)
     assert np.array_equal(I, Io) and np.array_equal(D, Do)
     assert I[0, 0] == 7 and D[0, 0] == 0.0 and (k == 1 or I[0, 1] == 11)
-    assert scr.screen_stats(nq, k)[0] == 0  # no tile needed the exact fallback
+    if nq >= 20:  # fewer than 20 L2 queries take FAISS's sequential form (csrc/knn_direct.inc), not the screen
+        assert scr.screen_stats(nq, k)[0] == 0  # no tile needed the exact fallback
 
 
 def test_l2_screen_with_many_exact_duplicates_of_the_query():

@@ -89,3 +89,41 @@ def test_cut_at_k_with_an_article_that_maps_to_no_passage_ranked_first():
             got = {}
             s._fill_run(kb, got, scores, indices)
             assert list(got) == list(want) and np.allclose(list(got.values()), list(want.values()), rtol=0, atol=1e-9), (many2one, indices)
+
+
+def test_arrow_query_transport_changes_the_transport_not_the_runs(tmp_path):
+    """dataset_search reads the query vectors of a batch straight from the Arrow table (~0.05 ms per 256-query batch instead
+    of ~55 ms of Python-list decoding under the shipped "format": {}); columns with None queries, datasets with an indices
+    mapping and user-chosen formats take the ordinary path; the runs are the same either way."""
+    import datasets
+    from viquae_amd.ir import searcher as S
+    from viquae_amd.ir.search import Index, KnowledgeBase, register_index
+    datasets.disable_progress_bars()
+    rng = np.random.default_rng(0)
+    art = rng.standard_normal((300, 24)).astype(np.float32)
+    Q = rng.standard_normal((37, 24)).astype(np.float32)
+    faces = [None if i % 3 == 0 else list(map(float, Q[i])) for i in range(37)]
+    qs = datasets.Dataset.from_dict({"id": [str(i) for i in range(37)], "vec_q": [q for q in Q], "face_q": faces,
+                                     "vec2_q": [q for q in Q[::-1]], "output": [{"answer": ["a"], "original_answer": "a"}] * 37})
+    (tmp_path / "qrels.json").write_text("{}")
+
+    def kb_kwargs():
+        kb = KnowledgeBase(dataset=datasets.Dataset.from_dict({"vec": [v for v in art]}))
+        register_index(kb.dataset, "dense", oracle_index(art))
+        register_index(kb.dataset, "face", oracle_index(art))
+        register_index(kb.dataset, "dense2", oracle_index(art))
+        kb.indexes["dense"], kb.indexes["face"], kb.indexes["dense2"] = Index(key="vec_q"), Index(key="face_q"), Index(key="vec2_q")
+        return dict(kb_kwargs={"kb": {}}, k=10, kbs={"kb": kb}, qrels=str(tmp_path / "qrels.json"), do_fusion=False)
+
+    with pytest.warns(UserWarning):
+        s_py = S.Searcher(**kb_kwargs())
+    qs.map(s_py, batched=True, batch_size=16, load_from_cache_file=False)           # the reference's own way
+    fast = S.ArrowQueryColumns(qs, s_py)
+    assert list(fast.columns) == ["vec_q", "vec2_q"]                                # face_q holds None: ordinary path
+    assert np.array_equal(fast.batch("vec_q", list(range(5, 21))), Q[5:21])
+    assert np.array_equal(fast.batch("vec_q", [3, 9, 4]), Q[[3, 9, 4]])
+    with pytest.warns(UserWarning):
+        s_fast = S.dataset_search(qs, map_kwargs={"batch_size": 16, "load_from_cache_file": False}, **kb_kwargs())
+    assert s_fast.runs == s_py.runs and len(s_fast.runs["dense"]["5"]) == 10 and s_fast.runs["face"]["0"] == {}
+    assert not S.ArrowQueryColumns(qs.with_format("numpy"), s_py)                   # the user's format stands
+    assert not S.ArrowQueryColumns(qs.select([3, 1, 2]), s_py)                      # indices mapping: ordinary path

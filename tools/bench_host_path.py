@@ -1,0 +1,83 @@
+"""The reference's call surface end to end: how many queries per second survive each layer between
+the scan kernel and `python -m meerqat.ir.search`, at the reference's own batch size (map_kwargs.batch_size = 256,
+experiments/ir/viquae/dpr/search/config.json:25) over a 1.5M x 768 inner-product KB.
+
+  device        MI355XFlatIndex.search_device, queries and results resident in HBM
+  index_numpy   MI355XFlatIndex.search_batch(ndarray [256,768])           = FaissIndex.search_batch (datasets/search.py:369-385)
+  kb_numpy      KnowledgeBase.search_batch(index, ndarray)                  (meerqat/ir/search.py:135-146)
+  kb_lists      KnowledgeBase.search_batch(index, list of 256 lists)       what Dataset.map hands over under "format": {}
+  map_python    Dataset.map(Searcher) over 4096 questions, format {}       the shipped config, bookkeeping included, no relevance
+  map_arrow     the same with the query vectors read from the Arrow table  what viquae_amd.ir.searcher.dataset_search does
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def timed(fn, n):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def main(rows=1_500_000, d=768, nq=256, k=100, n_map=4096, steps=30):
+    import datasets
+    from viquae_amd.index import MI355XFlatIndex
+    from viquae_amd.ir.search import Index, KnowledgeBase, register_index
+    from viquae_amd.ir.searcher import ArrowQueryColumns, Searcher
+    datasets.disable_progress_bars()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    idx = MI355XFlatIndex(string_factory="Flat", metric_type=0)
+    for s in range(0, rows, 1 << 16):
+        idx.add(torch.randn((min(1 << 16, rows - s), d), generator=g, device=dev), total_hint=rows)
+    Qd = torch.randn((n_map, d), generator=g, device=dev)
+    Qh = Qd.cpu().numpy()
+    out = {"workload": f"{rows}x{d} IP KB, top-{k}, {nq}-query batches (the reference's map_kwargs.batch_size)"}
+    t = timed(lambda: idx.search_device(Qd[:nq], k), steps)
+    out["device"] = {"ms_per_batch": round(t * 1e3, 3), "queries_per_s": round(nq / t, 1)}
+    t = timed(lambda: idx.search_batch(Qh[:nq], k), steps)
+    out["index_numpy"] = {"ms_per_batch": round(t * 1e3, 3), "queries_per_s": round(nq / t, 1)}
+    kb = KnowledgeBase(dataset=datasets.Dataset.from_dict({"passage": ["x"]}))
+    register_index(kb.dataset, "dense", idx)
+    kb.indexes["dense"] = Index(key="q")
+    t = timed(lambda: kb.search_batch("dense", Qh[:nq], k), steps)
+    out["kb_numpy"] = {"ms_per_batch": round(t * 1e3, 3), "queries_per_s": round(nq / t, 1)}
+    lists = [list(map(float, q)) for q in Qh[:nq]]
+    t = timed(lambda: kb.search_batch("dense", lists, k), max(3, steps // 5))
+    out["kb_lists"] = {"ms_per_batch": round(t * 1e3, 3), "queries_per_s": round(nq / t, 1)}
+    # Dataset.map(Searcher): the shipped config's format {} (python lists) against the numpy query column
+    qs = datasets.Dataset.from_dict({"id": [str(i) for i in range(n_map)], "q": [r for r in Qh],
+                                     "output": [{"answer": ["a"], "original_answer": "a"}] * n_map})
+    import tempfile
+    import warnings
+    qrels = os.path.join(tempfile.mkdtemp(), "qrels.json")
+    with open(qrels, "wt") as f:
+        f.write("{}")
+    warnings.simplefilter("ignore")
+    for name, ds in (("map_python", qs), ("map_arrow", None)):
+        s = Searcher(kb_kwargs={"kb": {}}, k=k, kbs={"kb": kb}, qrels=qrels)  # no reference KB: relevance judging is off
+        t0 = time.perf_counter()
+        if ds is None:  # what viquae_amd.ir.searcher.dataset_search does
+            s.arrow_queries = ArrowQueryColumns(qs, s)
+            qs.remove_columns(list(s.arrow_queries.columns)).map(s, batched=True, with_indices=True, batch_size=nq, load_from_cache_file=False)
+        else:
+            ds.map(s, batched=True, batch_size=nq, load_from_cache_file=False)
+        t = time.perf_counter() - t0
+        assert len(s.runs["dense"]) == n_map and all(len(r) == k for r in s.runs["dense"].values())
+        out[name] = {"ms_per_batch": round(t / (n_map / nq) * 1e3, 3), "queries_per_s": round(n_map / t, 1)}
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(main()))

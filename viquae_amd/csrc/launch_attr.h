@@ -15,6 +15,12 @@ inline hipError_t ensure_dynamic_lds(const void* fn, int bytes, std::atomic<unsi
     if (e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    if (bytes >= LDS_PER_CU) {  // "as much as the kernel may ever ask for": what its static __shared__ objects leave
+        hipFuncAttributes attr;
+        e = hipFuncGetAttributes(&attr, fn);
+        if (e != hipSuccess) return e;
+        bytes = LDS_PER_CU - (int)attr.sharedSizeBytes;
+    }
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
     return e;

@@ -42,6 +42,7 @@ _MAGIC = b"MQFLAT01"
 _UPLOAD_ROWS = 1 << 16  # rows per host->device staging copy (multiple of 64)
 _QUERY_CHUNK = 1 << 14
 _SCREEN_QUERY_CHUNK = 1 << 12
+_PINNED_IO_MAX_QUERIES = 1 << 15  # larger batches use one-off pageable copies (their transfer time is small beside the scan)
 
 
 L2_DIRECT_BELOW = 20  # faiss::distance_compute_blas_threshold (include/meerqat_hip.h, MQ_KNN_L2_DIRECT_BELOW)
@@ -135,6 +136,12 @@ class MI355XFlatIndex(BaseIndex):
         self._bf16 = None      # torch.uint8 bf16 copy
         self._xmax2 = None     # torch.float32 [3]: max ||x||^2, max ||xc - bf16(xc)||^2, max ||xc||^2 (kept by mq_knn_screen_prepare)
         self._center = None    # torch.float32 [d]: the vector the bf16 screening copy is centred on (inner product only)
+
+    def __reduce__(self):
+        # Like a FAISS GPU index: device-resident, not picklable.  It also keeps `datasets` from hashing the whole shard
+        # (a device -> host copy of every buffer, ~9 s at 1.5M x 768) when it fingerprints a Dataset.map call whose function
+        # captures the index (Searcher -> KnowledgeBase -> index): on this error it falls back to a random fingerprint.
+        raise TypeError(f"{type(self).__name__} lives in HBM and cannot be pickled: use save() / load()")
 
     # ------------------------------------------------------------------ construction
     def _ensure_capacity(self, n_total, d, exact=True):
@@ -324,10 +331,37 @@ class MI355XFlatIndex(BaseIndex):
             raise ValueError("Shape of query must be 2D")
         if self._torch_device is None:
             self._torch_device = _resolve_device(self.device)
-        q = torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32)).to(self._torch_device)
-        D, I = self.search_device(q, k)
-        torch.cuda.current_stream(self._torch_device).synchronize()
-        return BatchedSearchResults(D.cpu().numpy(), I.cpu().numpy().astype(int))
+        nq = queries.shape[0]
+        if nq == 0 or nq > _PINNED_IO_MAX_QUERIES:
+            q = torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32)).to(self._torch_device)
+            D, I = self.search_device(q, k)
+            torch.cuda.current_stream(self._torch_device).synchronize()
+            return BatchedSearchResults(D.cpu().numpy(), I.cpu().numpy().astype(int))
+        # Host boundary of one batch (the reference sends 256 queries at a time): page-locked staging buffers kept by the
+        # index, asynchronous copies on the search stream, ONE synchronisation -- instead of three blocking pageable copies.
+        q_pin, q_dev, D_pin, I_pin = self._host_io(nq, queries.shape[1], k)
+        np.copyto(q_pin[:nq].numpy(), queries, casting="same_kind" if queries.dtype.kind == "f" else "unsafe")
+        stream = torch.cuda.current_stream(self._torch_device)
+        with torch.cuda.device(self._torch_device):
+            q_dev[:nq].copy_(q_pin[:nq], non_blocking=True)
+            D, I = self.search_device(q_dev[:nq], k)
+            D_pin[:nq].copy_(D, non_blocking=True)
+            I_pin[:nq].copy_(I, non_blocking=True)
+        stream.synchronize()
+        return BatchedSearchResults(D_pin[:nq].numpy().copy(), I_pin[:nq].numpy().astype(int))
+
+    def _host_io(self, nq, d, k):
+        """Page-locked (q, D, I) staging + the device query buffer, grown geometrically and reused across calls."""
+        import torch
+        io = getattr(self, "_io", None)
+        if io is None or io[0].shape[0] < nq or io[0].shape[1] != d or io[2].shape[1] != k:
+            cap = max(256, 1 << (int(nq) - 1).bit_length())
+            io = (torch.empty((cap, d), dtype=torch.float32).pin_memory(),
+                  torch.empty((cap, d), dtype=torch.float32, device=self._torch_device),
+                  torch.empty((cap, k), dtype=torch.float32).pin_memory(),
+                  torch.empty((cap, k), dtype=torch.int64).pin_memory())
+            self._io = io
+        return io
 
     def search(self, query, k: int = 10, **kwargs) -> SearchResults:
         """FaissIndex.search (datasets/search.py:349-367)."""

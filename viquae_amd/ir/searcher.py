@@ -131,6 +131,10 @@ class Searcher:
     def _fill_run(self, kb, run_q, scores, indices):
         """One query's hits -> run dict, cut at k entries (reference: search.py:413-440)."""
         if kb.index_mapping is None:
+            if not run_q and len(set(indices[:self.k])) == min(self.k, len(indices)):
+                # distinct hits into an empty run: the loop below keeps exactly the first k of them
+                run_q.update(zip(map(str, indices[:self.k]), scores))
+                return
             for score, i in zip(scores, indices):
                 run_q[str(i)] = score
                 if len(run_q) >= self.k:
@@ -155,11 +159,16 @@ class Searcher:
                 if len(run_q) >= self.k:
                     return
 
-    def __call__(self, batch):
+    arrow_queries = None  # set by dataset_search: query vectors come from the Arrow table, not from `batch`
+
+    def __call__(self, batch, row_indices=None):
         question_types = batch.get("question_type", ["String"] * len(batch["id"]))
         for kb in self.kbs.values():
             for index_name, index in kb.indexes.items():
-                queries = batch[index.key]
+                if self.arrow_queries is not None and row_indices is not None and index.key in self.arrow_queries.columns:
+                    queries = self.arrow_queries.batch(index.key, row_indices)
+                else:
+                    queries = batch[index.key]
                 if any(query is None for query in queries):
                     scores_batch, indices_batch = kb.search_batch_if_not_None(index_name, queries, k=self.k)
                 else:
@@ -181,11 +190,70 @@ class Searcher:
         return batch
 
 
+class ArrowQueryColumns:
+    """The query columns of the searcher's dense indexes, read straight from the dataset's Arrow table.
+
+    Under the shipped configs' ``"format": {}`` (meerqat/ir/search.py:535-536) ``Dataset.map`` decodes every embedding of a
+    batch into Python floats -- 256 x 768 objects, ~50 ms, then ~5 ms more for ``np.array`` in ``search_batch`` (:143) --
+    against ~1 ms for the search itself.  ``dataset_search`` therefore drops these columns from what ``map`` decodes and
+    lets the searcher fetch a batch's vectors by row index as one float32 [batch, d] array (a zero-copy view of the Arrow
+    buffer, ~0.05 ms).  Left to the ordinary path: columns holding None (missing faces, :148-171), datasets with an
+    indices mapping (select / shuffle) and datasets whose format the user chose."""
+
+    def __init__(self, dataset, searcher):
+        import pyarrow as pa
+        self.columns = {}
+        fmt = getattr(dataset, "format", None) or {}
+        if fmt.get("type") is not None or getattr(dataset, "_indices", None) is not None:
+            return
+        for kb in searcher.kbs.values():
+            for index in kb.indexes.values():
+                key = index.key
+                if key in self.columns or key not in dataset.column_names:
+                    continue
+                col = dataset.data.column(key)
+                t = col.type
+                if not (pa.types.is_list(t) or pa.types.is_large_list(t) or pa.types.is_fixed_size_list(t)):
+                    continue
+                if not pa.types.is_floating(t.value_type) or col.null_count:
+                    continue
+                self.columns[key] = col
+
+    def __bool__(self):
+        return bool(self.columns)
+
+    def batch(self, key, indices):
+        """float32 [len(indices), d] of column ``key`` (indices: what ``map(with_indices=True)`` hands over)."""
+        col = self.columns[key]
+        n = len(indices)
+        first = int(indices[0])
+        if n and int(indices[-1]) - first + 1 == n:
+            part = col.slice(first, n)
+        else:
+            part = col.take(list(map(int, indices)))
+        part = part.combine_chunks()
+        flat = part.flatten().to_numpy(zero_copy_only=False)
+        if flat.size % max(n, 1):
+            raise ValueError(f"column '{key}' holds vectors of different lengths")
+        return np.ascontiguousarray(flat.reshape(n, -1), dtype=np.float32)
+
+
 def dataset_search(dataset, k=100, metric_save_path=None, map_kwargs={}, **kwargs):
     """Searcher over ``dataset.map``; saves qrels / runs (JSON) under ``metric_save_path``; with ``ranx`` installed
     also computes and saves the metric report like the reference."""
     searcher = Searcher(k=k, **kwargs)
-    dataset = dataset.map(searcher, batched=True, **map_kwargs)
+    queries = ArrowQueryColumns(dataset, searcher)
+    # the mapped dataset is not kept (neither does the reference keep it): no point in fingerprinting the searcher
+    map_kwargs = dict(map_kwargs)
+    if "new_fingerprint" not in map_kwargs:
+        from datasets.fingerprint import generate_random_fingerprint
+        map_kwargs["new_fingerprint"] = generate_random_fingerprint()
+    if queries:
+        searcher.arrow_queries = queries
+        dataset = dataset.remove_columns(list(queries.columns)).map(searcher, batched=True, with_indices=True, **map_kwargs)
+        searcher.arrow_queries = None
+    else:
+        dataset = dataset.map(searcher, batched=True, **map_kwargs)
     if metric_save_path is not None:
         metric_save_path = Path(metric_save_path)
         metric_save_path.mkdir(exist_ok=True)

@@ -115,6 +115,9 @@ class _ShardedBase(BaseIndex):
     def _query_device(self):
         raise NotImplementedError
 
+    def __reduce__(self):  # see MI355XFlatIndex.__reduce__
+        raise TypeError(f"{type(self).__name__} lives in HBM and cannot be pickled: use save()")
+
     def search_batch(self, queries, k: int = 10, **kwargs) -> BatchedSearchResults:
         import torch
         queries = np.asarray(queries)
