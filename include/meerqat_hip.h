@@ -241,6 +241,23 @@ int mq_attention_split_f32(const float *qkv_dev, const int64_t *attention_mask_d
                            uint16_t *out_l_dev, int B, int L, int heads, int head_dim, float scale, int causal, int bf16x3,
                            void *stream);
 
+/* Packed (variable-length) batch: the REAL tokens of all sequences, concatenated -- row r of every activation
+ * matrix is one token, sequence b = rows [cu_seqlens[b], cu_seqlens[b+1]).  The reference pads every passage to
+ * max_length 256 (experiments/ir/viquae/dpr/passages/config.json:11-14) although a passage has ~130 tokens; GEMMs and
+ * LayerNorm are row-wise, so on the packed matrix they simply skip the padding, and these two entries supply the only
+ * sequence-aware operations:
+ *   mq_bert_embed_ln_packed_f32: BertEmbeddings + LayerNorm with an explicit position id per row;
+ *   mq_attention_packed_f32: attention of the n_seqs sequences listed in seq_ids_dev (one launch per length class:
+ *     max_len = the longest of them, it selects the key-tile count), each over exactly its own keys.  A padded key
+ *     of the dense forward contributes exactly 0 to every sum, so the outputs equal the dense forward's bit for bit. */
+int mq_bert_embed_ln_packed_f32(const int64_t *input_ids_dev, const int64_t *token_type_ids_dev, const int32_t *position_ids_dev,
+                                const float *word_dev, const float *pos_dev, const float *type_dev, const float *gamma_dev,
+                                const float *beta_dev, float *out_dev, uint16_t *out_h_dev, uint16_t *out_l_dev, int T, int H,
+                                float eps, void *stream);
+int mq_attention_packed_f32(const float *qkv_dev, const int32_t *cu_seqlens_dev, const int32_t *seq_ids_dev, int n_seqs,
+                            int max_len, float *out_dev, uint16_t *out_h_dev, uint16_t *out_l_dev, int heads, int head_dim,
+                            float scale, int causal, int bf16x3, void *stream);
+
 /* Multimodal encoders of the reference (meerqat/models/mm.py: ECAEncoder :557-754, IntermediateLinearFusion :773-861) reuse
  * the entry points above; the only extra arithmetic is the sum of an example's face embeddings into its text vector
  * (mm.py:838-843): out[g, :] = init[g, :] + sum_j x[g, j, :], x [G, n, H], init (may be NULL) and out [G, H]. */

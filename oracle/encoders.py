@@ -136,6 +136,33 @@ def seeded_state(shapes, seed):
     return out
 
 
+def heavy_tailed_state(shapes, seed):
+    """seeded_state() reshaped like trained checkpoints: every golden before this one used
+    N(0, 0.02) weights with LayerNorm gains ~1, where every GEMM operand is benign.  Trained DPR / CLIP weights are not:
+    a few hidden channels carry activations tens of times larger than the rest (LayerNorm gains of 5-10 on 4 channels
+    here, log-normal elsewhere), a few input channels of every projection are scaled x20-x50, biases and LayerNorm
+    offsets are O(0.1).  Deterministic in (shapes, seed), regenerated on both sides like seeded_state."""
+    out = seeded_state(shapes, seed)
+    rng = np.random.default_rng(seed + 7919)
+    for name in sorted(out):
+        w = out[name]
+        is_ln = ("LayerNorm" in name or "layer_norm" in name or "layernorm" in name or "layrnorm" in name)
+        if is_ln and name.endswith("weight"):
+            g = np.exp(rng.normal(0.0, 0.25, w.shape))
+            g[rng.choice(w.size, 4, replace=False)] = rng.uniform(5.0, 10.0, 4)
+            out[name] = g.astype(F32)
+        elif is_ln:
+            out[name] = rng.normal(0.0, 0.1, w.shape).astype(F32)
+        elif w.ndim == 2 and "embedding" not in name:
+            w = w.copy()
+            cols = rng.choice(w.shape[1], 3, replace=False)
+            w[:, cols] *= rng.uniform(20.0, 50.0, 3).astype(F32)
+            out[name] = w
+        elif w.ndim == 1 and name.endswith("bias"):
+            out[name] = rng.normal(0.0, 0.05, w.shape).astype(F32)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # building blocks (fp32 throughout, op order of meerqat/models/bert.py)
 # ----------------------------------------------------------------------------------------------

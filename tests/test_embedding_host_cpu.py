@@ -149,6 +149,23 @@ def test_encoder_oracle_matches_hf_goldens(name, cfgname, kind):
         assert np.abs(out - z["image_features"]).max() < 2e-5
 
 
+@pytest.mark.parametrize("name,cfgname,kind", [("dpr_tiny_heavy", "BERT_TINY", "dpr"), ("clip_tiny_heavy", "CLIP_TINY", "clip")])
+def test_encoder_oracle_matches_hf_goldens_on_checkpoint_like_weights(name, cfgname, kind):
+    """The same pin on heavy-tailed weights (outlier channels x20-x50, LayerNorm gains up to 10, outputs up to |24|):
+    the restatement stays within 5e-5 of Hugging Face."""
+    from oracle import encoders as oe
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{name}.npz"))
+    cfg = getattr(oe, cfgname)
+    if kind == "dpr":
+        state = oe.heavy_tailed_state(oe.bert_param_shapes(cfg), int(z["seed"]))
+        out = oe.bert_forward(state, cfg, z["input_ids"], None, z["attention_mask"])
+        assert np.abs(z["pooler_output"]).max() > 5 and np.abs(out - z["pooler_output"]).max() < 5e-5
+    else:
+        state = oe.heavy_tailed_state(oe.clip_vision_param_shapes(cfg), int(z["seed"]))
+        out = oe.clip_vision_forward(state, cfg, z["pixel_values"].astype(np.float32))
+        assert np.abs(z["image_features"]).max() > 3 and np.abs(out - z["image_features"]).max() < 5e-5
+
+
 @pytest.mark.parametrize("name,eos", [("clip_text_tiny", 2), ("clip_text_tiny_eos", 299)])
 def test_clip_text_oracle_matches_hf_goldens(name, eos):
     """CLIP text tower: numpy oracle vs HF CLIPModel.get_text_features driven through the reference's embed()."""

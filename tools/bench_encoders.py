@@ -114,6 +114,13 @@ def dpr_padded_throughput(B=2048, L=256, mean_len=130, std_len=30, steps=2, devi
     run()  # builds the weight splits and the side streams
     t_skip = time_it(run, steps)
     a = run()
+    os.environ["MQ_ENC_PACKED"] = "0"   # the round-1 forward: <= 8 length groups, each dense at its longest length
+    try:
+        run()
+        t_groups = time_it(run, steps)
+        g_same = bool(torch.equal(a, run()))
+    finally:
+        del os.environ["MQ_ENC_PACKED"]
     os.environ["MQ_ENC_PAD_SKIP"] = "0"
     try:
         t_dense = time_it(run, steps)
@@ -122,7 +129,9 @@ def dpr_padded_throughput(B=2048, L=256, mean_len=130, std_len=30, steps=2, devi
         del os.environ["MQ_ENC_PAD_SKIP"]
     return {"passages_per_s": B / t_skip, "ms_per_batch": t_skip * 1e3, "dense_passages_per_s": B / t_dense,
             "dense_ms_per_batch": t_dense * 1e3, "batch": B, "padded_to": L, "mean_tokens": float(lens.mean()),
-            "identical_to_dense": bool(torch.equal(a, b))}
+            "identical_to_dense": bool(torch.equal(a, b)), "forward": "packed (real tokens only, attention per sequence)",
+            "length_groups_passages_per_s": B / t_groups, "length_groups_ms_per_batch": t_groups * 1e3,
+            "length_groups_identical": g_same}
 
 
 def clip_throughput(B=3072, steps=2, device="cuda"):

@@ -31,7 +31,7 @@ class _FakeTokenizer:
         return {k: torch.as_tensor(v) for k, v in self.enc.items()}
 
 
-def _dpr(cfg, seed, ids, tt, mask, via_reference_embed):
+def _dpr(cfg, seed, ids, tt, mask, via_reference_embed, make_state=None):
     from transformers import DPRConfig, DPRContextEncoder
     hf = DPRConfig(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], num_hidden_layers=cfg["num_hidden_layers"],
                    num_attention_heads=cfg["num_attention_heads"], intermediate_size=cfg["intermediate_size"],
@@ -39,7 +39,7 @@ def _dpr(cfg, seed, ids, tt, mask, via_reference_embed):
                    layer_norm_eps=cfg["layer_norm_eps"], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
                    projection_dim=0)
     model = DPRContextEncoder(hf).eval()
-    state = oe.seeded_state(oe.bert_param_shapes(cfg), seed)
+    state = (make_state or oe.seeded_state)(oe.bert_param_shapes(cfg), seed)
     missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=False)
     assert not unexpected and all("position_ids" in m for m in missing), (missing, unexpected)
     enc = {"input_ids": ids, "token_type_ids": tt, "attention_mask": mask}
@@ -54,7 +54,7 @@ def _dpr(cfg, seed, ids, tt, mask, via_reference_embed):
     return out.pooler_output.numpy().astype(np.float32), state
 
 
-def _clip(cfg, seed, pixels):
+def _clip(cfg, seed, pixels, make_state=None):
     from transformers import CLIPConfig, CLIPModel, CLIPVisionConfig, CLIPTextConfig
     v = CLIPVisionConfig(hidden_size=cfg["hidden_size"], num_hidden_layers=cfg["num_hidden_layers"],
                          num_attention_heads=cfg["num_attention_heads"], intermediate_size=cfg["intermediate_size"],
@@ -63,7 +63,7 @@ def _clip(cfg, seed, pixels):
     t = CLIPTextConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64, vocab_size=100,
                        projection_dim=cfg["projection_dim"])
     model = CLIPModel(CLIPConfig(text_config=t.to_dict(), vision_config=v.to_dict(), projection_dim=cfg["projection_dim"])).eval()
-    state = oe.seeded_state(oe.clip_vision_param_shapes(cfg), seed)
+    state = (make_state or oe.seeded_state)(oe.clip_vision_param_shapes(cfg), seed)
     missing, unexpected = model.load_state_dict({k: torch.from_numpy(v_) for k, v_ in state.items()}, strict=False)
     assert not unexpected, unexpected
     assert all(m.startswith(("text_model", "text_projection", "logit_scale")) or "position_ids" in m for m in missing), missing
@@ -178,8 +178,34 @@ def main():
                         seed=22)
 
 
+def main_heavy_tailed():
+    """Goldens on checkpoint-like weights (oracle.encoders.heavy_tailed_state): outlier channels, large LayerNorm gains."""
+    rng = np.random.default_rng(41)
+    for tag, cfg, B, L in (("dpr_tiny_heavy", oe.BERT_TINY, 6, 37), ("dpr_base_heavy_8x100", oe.BERT_BASE, 8, 100)):
+        lo = 1 if cfg is oe.BERT_TINY else 1000
+        ids = rng.integers(lo, min(cfg["vocab_size"], 30000), (B, L)).astype(np.int64)
+        mask = np.ones_like(ids)
+        mask[1, L // 2:] = 0
+        mask[B - 1, L - 5:] = 0
+        out, state = _dpr(cfg, 51, ids, np.zeros_like(ids), mask, via_reference_embed=True, make_state=oe.heavy_tailed_state)
+        mine = oe.bert_forward(state, cfg, ids, None, mask)
+        print(tag, "|oracle - HF| max", np.abs(mine - out).max(), "output range", float(np.abs(out).max()), "rms", float(np.sqrt((out ** 2).mean())))
+        np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), input_ids=ids, attention_mask=mask, pooler_output=out, seed=51)
+    for tag, cfg, B in (("clip_tiny_heavy", oe.CLIP_TINY, 5), ("clip_vitb32_heavy_4", oe.CLIP_VITB32, 4)):
+        S = cfg["image_size"]
+        px = rng.standard_normal((B, 3, S, S)).astype(np.float16).astype(np.float32)
+        out, state = _clip(cfg, 52, px, make_state=oe.heavy_tailed_state)
+        mine = oe.clip_vision_forward(state, cfg, px)
+        print(tag, "|oracle - HF| max", np.abs(mine - out).max(), "output range", float(np.abs(out).max()), "rms", float(np.sqrt((out ** 2).mean())))
+        np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), pixel_values=px.astype(np.float16), image_features=out, seed=52)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
+    if "--heavy-only" in sys.argv:
+        main_heavy_tailed()
+        sys.exit(0)
     if "--clip-text-only" not in sys.argv:
         main()
     main_clip_text()
+    main_heavy_tailed()

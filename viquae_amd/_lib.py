@@ -57,6 +57,10 @@ SIGNATURES = {
                                            c_int, ctypes.c_float, c_ptr]),
     "mq_attention_split_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, ctypes.c_float, c_int,
                                        c_int, c_ptr]),
+    "mq_bert_embed_ln_packed_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int,
+                                            ctypes.c_float, c_ptr]),
+    "mq_attention_packed_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_int, c_int, ctypes.c_float, c_int,
+                                        c_int, c_ptr]),
     "mq_sum_groups_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
     "mq_topk_merge_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "mq_shard_record_bytes": (c_sz, [c_int, c_int]),

@@ -564,13 +564,13 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const long long* __r
                                                             const float* __restrict__ type, const float* __restrict__ g,
                                                             const float* __restrict__ b, float* __restrict__ out,
                                                             unsigned short* __restrict__ oh, unsigned short* __restrict__ ol, int M,
-                                                            int L, int H, float eps) {
+                                                            int L, int H, float eps, const int* __restrict__ pos_ids = nullptr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
     const long long id = ids[row];
     const long long tt = tts ? tts[row] : 0;
-    const int t_pos = row % L;
+    const int t_pos = pos_ids ? pos_ids[row] : row % L;  // packed rows carry their position inside their sequence
     float v[LN_MAXPER];
 #pragma unroll
     for (int t = 0; t < LN_MAXPER; ++t) {
@@ -629,15 +629,25 @@ template <int NKT, bool MULTI>  // key tiles of 32 per key block; MULTI: sequenc
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, const long long* __restrict__ mask,
                                                              float* __restrict__ out, unsigned short* __restrict__ out_h,
                                                              unsigned short* __restrict__ out_l, int L, int heads, float scale,
-                                                             int causal) {
+                                                             int causal, const int* __restrict__ cu = nullptr,
+                                                             const int* __restrict__ seq_ids = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NK = 32 * NKT;
     float* Ks = reinterpret_cast<float*>(smem);        // [NK][65]
     float* Vs = Ks + NK * 65;                           // [NK][64]
     float* addm = Vs + NK * 64;                         // [NK] 0 or -inf
-    const int bi = blockIdx.x / heads, h = blockIdx.x % heads;
+    // dense batch: sequence bi = rows [bi L, bi L + L).  Packed batch (cu != NULL): this launch covers the sequences
+    // listed in seq_ids (one length class); sequence bi = rows [cu[bi], cu[bi + 1]) of the packed token matrix, every key
+    // is real (no mask), and L is the class's longest length (grid / wave count only).
+    const int h = blockIdx.x % heads;
+    const int bi = seq_ids ? seq_ids[blockIdx.x / heads] : (int)(blockIdx.x / heads);
+    const size_t row0 = cu ? (size_t)cu[bi] : (size_t)bi * L;
+    if (cu) {
+        L = cu[bi + 1] - cu[bi];
+        if ((int)blockIdx.y * 128 >= L) return;  // block-uniform: no query of this sequence in the block
+    }
     const int H = heads * DH, ld = 3 * H;
-    const float* base = qkv + (size_t)bi * L * ld + h * DH;
+    const float* base = qkv + row0 * ld + h * DH;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nthr = blockDim.x;  // 64 * min(4, ceil(queries of this block / 32)) threads: no wave without queries
     const int i = lane & 31, kh = lane >> 5;
@@ -665,7 +675,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         *reinterpret_cast<float4*>(Vs + j * 64 + c4) = vf;
     }
     for (int j = tid; j < NK; j += nthr)
-        addm[j] = (kb0 + j < L && (!mask || mask[(size_t)bi * L + kb0 + j] != 0)) ? 0.f : -INFINITY;
+        addm[j] = (kb0 + j < L && (!mask || mask[row0 + kb0 + j] != 0)) ? 0.f : -INFINITY;
     __syncthreads();
 
     f32x16 sacc[NKT];
@@ -739,7 +749,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     for (int e = lane; e < 32 * 64; e += 64) {
         const int r = e >> 6, c = e & 63;  // c = lane: lanes l, l^1 hold adjacent columns
         const int qr = blockIdx.y * 128 + 32 * w + r;
-        const size_t at = ((size_t)bi * L + qr) * H + h * DH;
+        const size_t at = (row0 + qr) * H + h * DH;
         const float val = Ot[r * 65 + c];
         if (out && qr < L) out[at + c] = val;
         if (out_h) store_split_pair(val, qr < L, out_h, out_l, at + (c & ~1), lane);
@@ -761,7 +771,8 @@ template <int NKT, bool MULTI>
 __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ qkv, const long long* __restrict__ mask,
                                                            float* __restrict__ out, unsigned short* __restrict__ out_h,
                                                            unsigned short* __restrict__ out_l, int L, int heads, float scale,
-                                                           int causal) {
+                                                           int causal, const int* __restrict__ cu = nullptr,
+                                                           const int* __restrict__ seq_ids = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NK = 32 * NKT, NCH = NK / 8;           // 16-byte chunks (8 keys) per V^T row
     constexpr int K_BYTES = NK * 128, V_BYTES = 64 * NK * 2;
@@ -770,9 +781,18 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
     char* Vth = Kl + K_BYTES;
     char* Vtl = Vth + V_BYTES;
     float* addm = reinterpret_cast<float*>(Vtl + V_BYTES);  // [NK] 0 or -inf
-    const int bi = blockIdx.x / heads, h = blockIdx.x % heads;
+    // dense batch: sequence bi = rows [bi L, bi L + L).  Packed batch (cu != NULL): this launch covers the sequences
+    // listed in seq_ids (one length class); sequence bi = rows [cu[bi], cu[bi + 1]) of the packed token matrix, every key
+    // is real (no mask), and L is the class's longest length (grid / wave count only).
+    const int h = blockIdx.x % heads;
+    const int bi = seq_ids ? seq_ids[blockIdx.x / heads] : (int)(blockIdx.x / heads);
+    const size_t row0 = cu ? (size_t)cu[bi] : (size_t)bi * L;
+    if (cu) {
+        L = cu[bi + 1] - cu[bi];
+        if ((int)blockIdx.y * 128 >= L) return;  // block-uniform: no query of this sequence in the block
+    }
     const int H = heads * DH, ld = 3 * H;
-    const float* base = qkv + (size_t)bi * L * ld + h * DH;
+    const float* base = qkv + row0 * ld + h * DH;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nthr = blockDim.x;
     const int i = lane & 31, kg = lane >> 5;
@@ -818,7 +838,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
         }
     }
     for (int j = tid; j < NK; j += nthr)
-        addm[j] = (kb0 + j < L && (!mask || mask[(size_t)bi * L + kb0 + j] != 0)) ? 0.f : -INFINITY;
+        addm[j] = (kb0 + j < L && (!mask || mask[row0 + kb0 + j] != 0)) ? 0.f : -INFINITY;
     __syncthreads();
 
     f32x16 sacc[NKT];
@@ -922,7 +942,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
     for (int e = lane; e < 32 * 64; e += 64) {
         const int r = e >> 6, c = e & 63;
         const int qr = blockIdx.y * 128 + 32 * w + r;
-        const size_t at = ((size_t)bi * L + qr) * H + h * DH;
+        const size_t at = (row0 + qr) * H + h * DH;
         const float val = Ot[r * 65 + c];
         if (out && qr < L) out[at + c] = val;
         if (out_h) store_split_pair(val, qr < L, out_h, out_l, at + (c & ~1), lane);
@@ -1133,6 +1153,24 @@ int mq_bert_embed_ln_split_f32(const int64_t* input_ids_dev, const int64_t* toke
     return MQ_OK;
 }
 
+int mq_bert_embed_ln_packed_f32(const int64_t* input_ids_dev, const int64_t* token_type_ids_dev, const int32_t* position_ids_dev,
+                                const float* word_dev, const float* pos_dev, const float* type_dev, const float* gamma_dev,
+                                const float* beta_dev, float* out_dev, uint16_t* out_h_dev, uint16_t* out_l_dev, int T, int H,
+                                float eps, void* stream) {
+    if (T == 0) return MQ_OK;
+    if (!input_ids_dev || !position_ids_dev || !word_dev || !pos_dev || !type_dev || !gamma_dev || !beta_dev || !out_dev || T < 0 ||
+        H <= 0)
+        return MQ_EINVAL;
+    if (!out_h_dev != !out_l_dev) return MQ_EINVAL;
+    if (H > 64 * LN_MAXPER || (out_h_dev && (H & 1))) return MQ_EUNSUPPORTED;
+    hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)input_ids_dev, (const long long*)token_type_ids_dev, word_dev, pos_dev, type_dev,
+                       gamma_dev, beta_dev, out_dev, (unsigned short*)out_h_dev, (unsigned short*)out_l_dev, T, 1, H, eps,
+                       (const int*)position_ids_dev);
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
 int mq_attention_f32(const float* qkv_dev, const int64_t* attention_mask_dev, float* out_dev, int B, int L, int heads,
                      int head_dim, float scale, void* stream) {
     return mq_attention_causal_f32(qkv_dev, attention_mask_dev, out_dev, B, L, heads, head_dim, scale, 0, stream);
@@ -1183,6 +1221,53 @@ int mq_attention_split_f32(const float* qkv_dev, const int64_t* attention_mask_d
     }
 #undef MQ_ATT
 #undef MQ_ATT3
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_attention_packed_f32(const float* qkv_dev, const int32_t* cu_seqlens_dev, const int32_t* seq_ids_dev, int n_seqs,
+                            int max_len, float* out_dev, uint16_t* out_h_dev, uint16_t* out_l_dev, int heads, int head_dim,
+                            float scale, int causal, int bf16x3, void* stream) {
+    if (n_seqs == 0 || max_len == 0) return MQ_OK;
+    if (!qkv_dev || !cu_seqlens_dev || !seq_ids_dev || (!out_dev && !out_h_dev) || (!out_h_dev != !out_l_dev) || n_seqs < 0 ||
+        max_len < 0 || heads <= 0)
+        return MQ_EINVAL;
+    if (head_dim != DH) return MQ_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int L = max_len;
+    const dim3 grid((unsigned)(n_seqs * heads), (unsigned)((L + 127) / 128));
+    const unsigned nthr = 64u * (unsigned)(L >= 97 ? 4 : (L + 31) / 32);
+#define MQ_ATTP(NKT, MULTI)                                                                                                  \
+    {                                                                                                                 \
+        const size_t lds = (size_t)(32 * NKT) * (65 + 64 + 1) * 4 > (size_t)4 * 32 * 65 * 4 ? (size_t)(32 * NKT) * (65 + 64 + 1) * 4 : (size_t)4 * 32 * 65 * 4; \
+        MQ_DYNAMIC_LDS_WITH(ENC_HIP, mq_detail::LDS_PER_CU, attention_mfma_kernel<NKT, MULTI>); \
+        hipLaunchKernelGGL((attention_mfma_kernel<NKT, MULTI>), grid, dim3(nthr), lds, st, qkv_dev, (const long long*)nullptr,    \
+                           out_dev, (unsigned short*)out_h_dev, (unsigned short*)out_l_dev, L, heads, scale, causal ? 1 : 0, \
+                           (const int*)cu_seqlens_dev, (const int*)seq_ids_dev); \
+    }
+#define MQ_ATTP3(NKT, MULTI)                                                                                                  \
+    {                                                                                                                 \
+        const size_t need = (size_t)(32 * NKT) * 128 * 2 + (size_t)64 * (32 * NKT) * 2 * 2 + (size_t)(32 * NKT) * 4;    \
+        const size_t lds = need > (size_t)4 * 32 * 65 * 4 ? need : (size_t)4 * 32 * 65 * 4;                           \
+        MQ_DYNAMIC_LDS_WITH(ENC_HIP, mq_detail::LDS_PER_CU, attention_x3_kernel<NKT, MULTI>); \
+        hipLaunchKernelGGL((attention_x3_kernel<NKT, MULTI>), grid, dim3(nthr), lds, st, qkv_dev, (const long long*)nullptr,    \
+                           out_dev, (unsigned short*)out_h_dev, (unsigned short*)out_l_dev, L, heads, scale, causal ? 1 : 0, \
+                           (const int*)cu_seqlens_dev, (const int*)seq_ids_dev); \
+    }
+    if (bf16x3) {
+        if (((uintptr_t)qkv_dev & 15) || (heads * DH) % 4) return MQ_EINVAL;
+        if (L <= 64) MQ_ATTP3(2, false)
+        else if (L <= 128) MQ_ATTP3(4, false)
+        else if (L <= 256) MQ_ATTP3(8, false)
+        else MQ_ATTP3(8, true)
+    } else {
+        if (L <= 64) MQ_ATTP(2, false)
+        else if (L <= 128) MQ_ATTP(4, false)
+        else if (L <= 256) MQ_ATTP(8, false)
+        else MQ_ATTP(8, true)
+    }
+#undef MQ_ATTP
+#undef MQ_ATTP3
     ENC_HIP(hipGetLastError());
     return MQ_OK;
 }

@@ -192,6 +192,26 @@ def attention(qkv, mask, B, L, heads, scale, causal=False, split=False, bf16x3=N
     return sp if split else out
 
 
+def attention_packed(qkv, cu_seqlens, classes, heads, scale, causal=False, split=False, bf16x3=None):
+    """Attention over a PACKED token matrix (sequence b = rows [cu[b], cu[b+1]), every key real).  ``classes`` =
+    [(int32 sequence ids on the device, longest length among them)]: one launch per length class."""
+    _check_cuda(qkv)
+    lib = _lib.load()
+    T, H = qkv.shape[0], qkv.shape[1] // 3
+    if bf16x3 is None:
+        bf16x3 = _gemm_mode() == "split_bf16"
+    sp = SplitAct.empty(T, H, qkv.device) if split else None
+    out = None if split else torch.empty((T, H), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        for seq_ids, max_len in classes:
+            _lib.check(lib.mq_attention_packed_f32(qkv.data_ptr(), cu_seqlens.data_ptr(), seq_ids.data_ptr(), seq_ids.numel(),
+                                                   int(max_len), out.data_ptr() if out is not None else None,
+                                                   sp.hi.data_ptr() if split else None, sp.lo.data_ptr() if split else None,
+                                                   heads, H // heads, float(scale), int(bool(causal)), int(bool(bf16x3)),
+                                                   _stream(qkv)), "mq_attention_packed_f32")
+    return sp if split else out
+
+
 # --------------------------------------------------------------------------------------------------
 # checkpoint reading
 # --------------------------------------------------------------------------------------------------
@@ -301,6 +321,54 @@ class BertEncoderHIP(_HipEncoder):
         return _use_split(self.hidden, self.l0_wi.shape[0])
 
     @torch.no_grad()
+    def forward_packed(self, input_ids, token_type_ids, pack):
+        """[CLS] vectors [B, H] of a right-padded batch through the PACKED forward: only the real tokens of all sequences
+        (``pack`` from :func:`_pack_plan`) go through the embedding, the GEMMs and the LayerNorms; attention runs per
+        sequence over exactly its own keys.  Bit-identical to the dense forward's [CLS] rows (see _pack_plan)."""
+        _check_cuda(input_ids, self.w_word)
+        lib = _lib.load()
+        dev = input_ids.device
+        keep, pos, cu, classes, cls_rows = pack
+        T, H = int(keep.numel()), self.hidden
+        ids = input_ids.to(torch.int64).reshape(-1).index_select(0, keep)
+        tt = token_type_ids.to(torch.int64).reshape(-1).index_select(0, keep) if token_type_ids is not None else None
+        split = self.uses_split()
+        h = torch.empty((T, H), dtype=torch.float32, device=dev)
+        hs = SplitAct.empty(T, H, dev) if split else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.mq_bert_embed_ln_packed_f32(
+                ids.data_ptr(), tt.data_ptr() if tt is not None else None, pos.data_ptr(), self.w_word.data_ptr(),
+                self.w_pos.data_ptr(), self.w_type.data_ptr(), self.emb_g.data_ptr(), self.emb_b.data_ptr(), h.data_ptr(),
+                hs.hi.data_ptr() if split else None, hs.lo.data_ptr() if split else None, T, H, self.eps, _stream(h)),
+                "mq_bert_embed_ln_packed_f32")
+        scale = 1.0 / math.sqrt(H // self.heads)
+        for i in range(self.layers):
+            w = lambda n: getattr(self, f"l{i}_{n}")  # noqa: E731
+            sp = lambda n: self._ws(f"l{i}_{n}")  # noqa: E731
+            last = i == self.layers - 1
+            if split:
+                qkv = gemm_nt(hs, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
+                ctx = attention_packed(qkv, cu, classes, self.heads, scale, split=True)
+                if last:  # everything after the last attention is row-wise: only the [CLS] rows go on
+                    ctx, h = ctx.rows(cls_rows), h.index_select(0, cls_rows).contiguous()
+                a = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, wsplit=sp("wo"))
+                h1, h1s = layernorm_split(a, w("g1"), w("b1"), self.eps, f32_out=a)
+                f = gemm_nt(h1s, w("wi"), w("bi"), None, EPI_BIAS_GELU, wsplit=sp("wi"), out_split=True)
+                o = gemm_nt(f, w("w2"), w("b2"), h1, EPI_BIAS_RESIDUAL, wsplit=sp("w2"))
+                h, hs = layernorm_split(o, w("g2"), w("b2n"), self.eps, f32_out=o)
+            else:
+                qkv = gemm_nt(h, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
+                ctx = attention_packed(qkv, cu, classes, self.heads, scale)
+                if last:
+                    ctx, h = ctx.index_select(0, cls_rows).contiguous(), h.index_select(0, cls_rows).contiguous()
+                a = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, wsplit=sp("wo"))
+                h1 = layernorm(a, w("g1"), w("b1"), self.eps, out=a)
+                f = gemm_nt(h1, w("wi"), w("bi"), None, EPI_BIAS_GELU, wsplit=sp("wi"))
+                o = gemm_nt(f, w("w2"), w("b2"), h1, EPI_BIAS_RESIDUAL, wsplit=sp("w2"))
+                h = layernorm(o, w("g2"), w("b2n"), self.eps, out=o)
+        return h
+
+    @torch.no_grad()
     def _layers(self, h, hs, mask, B, L, output_hidden_states=False, cls_only=False):
         """The encoder stack over embeddings h [B*L, H] (hs = their split pair in split mode, or None to make it here)
         with an int64 0/1 mask [B, L] -> (last hidden [B, L or 1, H], hidden states or None)."""
@@ -384,6 +452,42 @@ def _length_buckets(attention_mask, max_buckets=8):
     return plan
 
 
+def _pack_plan(attention_mask):
+    """(kept flat token indices, position id per kept token, cu_seqlens, attention launch classes, [CLS] rows) for a
+    right-padded 0/1 mask with padding worth skipping -- else None (no mask, other mask shapes, empty sequences,
+    < 10 % padding, or MQ_ENC_PACKED=0).  One small D2H copy (the lengths).
+
+    Packed forward: the reference pads every passage to max_length (256, experiments/ir/viquae/dpr/passages/config.json:11-14)
+    although a 100-word passage has ~130 tokens.  Every operation of the encoder is row-wise except attention, and in
+    attention a padded key contributes exactly 0 to every sum and never sets a row maximum: dropping the padded ROWS
+    everywhere and the padded KEYS in attention leaves the [CLS] vectors bit-identical to the dense forward."""
+    if attention_mask is None or os.environ.get("MQ_ENC_PACKED", "1") == "0" or os.environ.get("MQ_ENC_PAD_SKIP", "1") == "0":
+        return None
+    B, L = attention_mask.shape
+    if B == 0 or L < 2:
+        return None
+    m = attention_mask != 0
+    right_padded = bool((m[:, 1:] <= m[:, :-1]).all()) and bool(((attention_mask == 0) | (attention_mask == 1)).all())
+    if not right_padded:
+        return None
+    lens_dev = m.sum(dim=1)
+    lens = lens_dev.cpu().numpy()
+    if lens.min() < 1 or int(lens.sum()) > 0.9 * B * L:
+        return None
+    dev = attention_mask.device
+    keep = m.reshape(-1).nonzero(as_tuple=False).reshape(-1)                      # flat indices b * L + t of the real tokens
+    pos = (keep % L).to(torch.int32)
+    cu_host = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cu = torch.from_numpy(cu_host).to(dev)
+    classes = []
+    for lo, hi in ((0, 64), (64, 128), (128, 256), (256, 1 << 30)):               # the attention kernel's key-tile counts
+        sel = np.nonzero((lens > lo) & (lens <= hi))[0].astype(np.int32)
+        if sel.size:
+            classes.append((torch.from_numpy(sel).to(dev), int(lens[sel].max())))
+    cls_rows = torch.from_numpy(cu_host[:-1].astype(np.int64)).to(dev)
+    return keep, pos, cu, classes, cls_rows
+
+
 def _partition_by_length(sorted_lens, nb):
     """Cuts ascending lengths into <= nb contiguous groups minimising sum(group size x group's longest length), the
     tokens a dense forward of each group processes (dynamic programme over the distinct lengths) -> list of slices."""
@@ -430,6 +534,9 @@ class _DPREncoder(_HipEncoder):
 
     @torch.no_grad()
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, output_hidden_states=False, **unused):
+        pack = None if output_hidden_states else _pack_plan(attention_mask)
+        if pack is not None:
+            return ModelOutput(pooler_output=self.bert_model.forward_packed(input_ids, token_type_ids, pack))
         plan = None if output_hidden_states else _length_buckets(attention_mask)
         if plan is not None:
             return ModelOutput(pooler_output=self._forward_buckets(plan, input_ids, attention_mask, token_type_ids))
