@@ -168,7 +168,7 @@ def spawn_ranks(args):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and os.environ.get("MQ_BENCH_SHARE_GPU") != "1":
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -199,6 +199,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: viquae_amd has no CPU path")
+    # Developer switches for exercising the N > 1 code path on a ONE-GPU box (never set by the driver): every rank on GPU 0
+    # (RCCL refuses two ranks on one device, hence the gloo backend, which stages through host memory)
+    if os.environ.get("MQ_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("MQ_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # MQ_BENCH_FORCE_DIST=1: go through the RCCL all-gather + shard merge even with one rank (exercises the
@@ -209,7 +214,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     lib = _lib.load()
 
     multi = world > 1 or force_dist
