@@ -906,11 +906,12 @@ static int knn_search_l2_direct(const float* packed_dev, int64_t N, int d, const
                            g.dpad, nq, (long long)g.npad, dist);
         MQ_HIP(hipGetLastError());
     }
+    // segment winners live in the (much larger) pool region of the other paths: nq * S * 128 keys
     hipLaunchKernelGGL(l2_direct_select_kernel, dim3((unsigned)g.S, (unsigned)nq), dim3(256), 0, st, dist, (long long)N,
                        (long long)g.npad, seg, k, lists);
     MQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(128), 0, st, lists, nq, g.S, k, (long long)id_offset,
-                       D_dev, (long long*)I_dev, (const int*)nullptr);
+    hipLaunchKernelGGL(l2_direct_final_kernel, dim3((unsigned)nq), dim3(256), 0, st, lists, g.S, k, (long long)id_offset, D_dev,
+                       (long long*)I_dev);
     MQ_HIP(hipGetLastError());
     return MQ_OK;
 }

@@ -254,6 +254,9 @@ def dataset_search(dataset, k=100, metric_save_path=None, map_kwargs={}, **kwarg
         searcher.arrow_queries = None
     else:
         dataset = dataset.map(searcher, batched=True, **map_kwargs)
+    from .embedding import process_rank_and_world
+    if process_rank_and_world()[0] != 0:
+        metric_save_path = None  # sharded search: every rank holds the same runs, rank 0 writes them
     if metric_save_path is not None:
         metric_save_path = Path(metric_save_path)
         metric_save_path.mkdir(exist_ok=True)
@@ -291,8 +294,13 @@ def main(dataset_path, config_path, k=100, metrics=None, disable_caching=False):
     (meerqat/ir/search.py:527-543): load the dataset and the JSON config, apply its ``format`` entry, search, save."""
     import datasets
     from datasets import load_from_disk
+    from .embedding import init_process_group_from_env
     if disable_caching:
         datasets.disable_caching()
+    # under `python -m torch.distributed.run --nproc-per-node N -m viquae_amd.ir.searcher ...`: one process per GPU, every
+    # KB index row-sharded over the ranks (viquae_amd.sharded.make_flat_index); every rank runs the same questions and ends
+    # with the same runs, rank 0 writes them
+    init_process_group_from_env()
     dataset = load_from_disk(dataset_path)
     with open(config_path, "rt") as file:
         config = json.load(file)
