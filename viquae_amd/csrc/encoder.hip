@@ -767,8 +767,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 // LDS: Kh, Kl [NK][64] bf16 (16-byte chunks swizzled by (key >> 1) & 7), Vth, Vtl [64][NK] bf16 (chunks swizzled by
 // d & (NK/8 - 1)), mask row.
 // ------------------------------------------------------------------------------------------------
-template <int NKT, bool MULTI>
-__global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ qkv, const long long* __restrict__ mask,
+// WIDE: up to 8 waves (256 queries) per workgroup -- a whole packed sequence of 129..256 tokens stages its K / V once
+// instead of once per 128-query block (224 VGPRs: two waves per SIMD fit).
+template <int NKT, bool MULTI, bool WIDE = false>
+__global__ __launch_bounds__(WIDE ? 512 : 256) void attention_x3_kernel(const float* __restrict__ qkv, const long long* __restrict__ mask,
                                                            float* __restrict__ out, unsigned short* __restrict__ out_h,
                                                            unsigned short* __restrict__ out_l, int L, int heads, float scale,
                                                            int causal, const int* __restrict__ cu = nullptr,
@@ -789,14 +791,20 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
     const size_t row0 = cu ? (size_t)cu[bi] : (size_t)bi * L;
     if (cu) {
         L = cu[bi + 1] - cu[bi];
-        if ((int)blockIdx.y * 128 >= L) return;  // block-uniform: no query of this sequence in the block
+        if ((int)blockIdx.y * (int)(blockDim.x >> 1) >= L) return;  // block-uniform: no query of this sequence in the block
     }
     const int H = heads * DH, ld = 3 * H;
     const float* base = qkv + row0 * ld + h * DH;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nthr = blockDim.x;
     const int i = lane & 31, kg = lane >> 5;
-    const int qrow = blockIdx.y * 128 + 32 * w + i;   // this lane's query
+    const int qpb = nthr >> 1;                         // queries per workgroup: 32 per wave
+    const bool wave_active = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * qpb + 32 * w)) < L;
+    // key tiles that hold at least one key of this sequence (block-uniform).  A packed sequence of 150 tokens in the
+    // 256-key instantiation has 5 live tiles of 8: the dead ones would only multiply zeros (their probabilities are exactly
+    // 0 and their V rows are staged as zeros), so skipping their staging, MFMAs and exponentials changes no bit.
+    const int nt_live = MULTI ? NKT : ((L + 31) / 32 < NKT ? (L + 31) / 32 : NKT);
+    const int qrow = blockIdx.y * qpb + 32 * w + i;   // this lane's query
     bf16x8_t qh[4], ql[4];                            // d in [16 m + 8 kg, + 8)
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -814,7 +822,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
     f32x16 oacc0 = {0}, oacc1 = {0};
     for (int kb0 = 0; kb0 < (MULTI ? L : 1); kb0 += NK) {  // !MULTI: exactly one pass, known at compile time
     if (kb0) __syncthreads();  // the previous block's K / V are dead
-    for (int e = tid; e < NK * (DH / 4); e += nthr) {
+    for (int e = tid; e < nt_live * 32 * (DH / 4); e += nthr) {
         const int j = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
         float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
         if (kb0 + j < L) {
@@ -841,12 +849,14 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
         addm[j] = (kb0 + j < L && (!mask || mask[row0 + kb0 + j] != 0)) ? 0.f : -INFINITY;
     __syncthreads();
 
+    if (wave_active) {  // wave-uniform: a wave without queries (short sequence in a wide workgroup) only helps staging
     f32x16 sacc[NKT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) sacc[t] = (f32x16){0};
     const int ksw = (i >> 1) & 7;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
+        if (t >= nt_live) break;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int ko = (32 * t + i) * 128 + (((2 * m + kg) ^ ksw) * 16);
@@ -861,6 +871,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
+        if (t >= nt_live) break;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int key = 32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
@@ -874,6 +885,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
     float bsum = 0.f;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
+        if (t >= nt_live) break;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const float p = (sacc[t][reg] == -INFINITY) ? 0.f : expf(sacc[t][reg] - mx);
@@ -894,6 +906,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
     const int vsw0 = i & (NCH - 1);  // d = i and d = 32 + i swizzle alike when NCH <= 32
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
+        if (t >= nt_live) break;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             // keys 32 t + 16 g + 8 kg + (0..7): k 0..3 sit in the lower lane's registers 8g+4kg+r, k 4..7 in the upper's
@@ -926,6 +939,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
             }
         }
     }
+    }  // wave_active
     }  // key blocks
     // oacc{0,1}[reg] = sum_key p V[key][d], d = 32 dt + (reg&3) + 8 (reg>>2) + 4 kg, for this lane's query.
     // Transpose through LDS (K/V are dead) so that every query row is stored as 256 contiguous bytes.
@@ -941,7 +955,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
     __syncthreads();
     for (int e = lane; e < 32 * 64; e += 64) {
         const int r = e >> 6, c = e & 63;
-        const int qr = blockIdx.y * 128 + 32 * w + r;
+        const int qr = blockIdx.y * qpb + 32 * w + r;
         const size_t at = (row0 + qr) * H + h * DH;
         const float val = Ot[r * 65 + c];
         if (out && qr < L) out[at + c] = val;
@@ -1258,7 +1272,17 @@ int mq_attention_packed_f32(const float* qkv_dev, const int32_t* cu_seqlens_dev,
         if (((uintptr_t)qkv_dev & 15) || (heads * DH) % 4) return MQ_EINVAL;
         if (L <= 64) MQ_ATTP3(2, false)
         else if (L <= 128) MQ_ATTP3(4, false)
-        else if (L <= 256) MQ_ATTP3(8, false)
+        else if (L <= 256) {
+            // one workgroup of ceil(L / 32) <= 8 waves per (sequence, head): K / V staged once for all its queries
+            const size_t need = (size_t)256 * 128 * 2 + (size_t)64 * 256 * 2 * 2 + (size_t)256 * 4;
+            const size_t ot = (size_t)8 * 32 * 65 * 4;
+            const size_t lds = need > ot ? need : ot;
+            MQ_DYNAMIC_LDS_WITH(ENC_HIP, mq_detail::LDS_PER_CU, attention_x3_kernel<8, false, true>);
+            hipLaunchKernelGGL((attention_x3_kernel<8, false, true>), dim3((unsigned)(n_seqs * heads), 1u), dim3(64u * (unsigned)((L + 31) / 32)),
+                               lds, st, qkv_dev, (const long long*)nullptr, out_dev, (unsigned short*)out_h_dev,
+                               (unsigned short*)out_l_dev, L, heads, scale, causal ? 1 : 0, (const int*)cu_seqlens_dev,
+                               (const int*)seq_ids_dev);
+        }
         else MQ_ATTP3(8, true)
     } else {
         if (L <= 64) MQ_ATTP(2, false)
