@@ -1,6 +1,7 @@
 """CPU suite: host-side mirror of meerqat.ir.search (no GPU: a test-only index object backed by the
 oracle is registered in place of the HIP index, exactly where MI355XFlatIndex would sit)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -274,3 +275,32 @@ def test_padding_plan_host_logic_on_cpu_tensors():
         assert _length_buckets(mask) is None
     finally:
         del os.environ["MQ_ENC_PAD_SKIP"]
+
+
+def test_bench_gpus_n_starts_its_own_ranks_before_touching_a_gpu(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment must launch N ranks itself (a
+    torch.distributed.run child), and must do so before anything initialises HIP in the parent."""
+    import importlib
+    import subprocess
+    import torch
+    bench = importlib.import_module("bench")
+    seen = {}
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("parent touched the GPU")))
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # more ranks than GPUs: refused before anything is launched
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    seen.clear()
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "only 2 GPU" in str(e.value.code) and not seen
