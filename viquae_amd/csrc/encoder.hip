@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/meerqat_hip.h"
 #include "launch_attr.h"
@@ -255,14 +256,27 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
                                                            const float* __restrict__ bias, const float* __restrict__ R,
                                                            float* __restrict__ C, unsigned short* __restrict__ Ch,
                                                            unsigned short* __restrict__ Cl, int M, int N, int K, int ntm, int ntn) {
+    // Each workgroup walks the output tiles blockIdx.x, + gridDim.x, ... (one tile per workgroup by default; a persistent
+    // launch of ~#CU workgroups under MQ_GEMM_WGS).  The first K stage of the NEXT tile is requested during the last K step
+    // of the current one, so its DMA round trip overlaps the C-store epilogue.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 2, wc = w & 3;
-    int mt, nt;
-    {
-        const int b = blockIdx.x;
+    const int ntiles = ntm * ntn;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem + 16 * w * 64));
+    const int i = lane & 31, kg = lane >> 5;
+    const int sww = (i >> 2) & 3;
+    const char* ard = smem + (64 * wr + i) * 64;                    // Ah rows of this wave; Al at + X_W_BYTES
+    const char* wrd = smem + 2 * X_W_BYTES + (64 * wc + i) * 64;    // Wh rows of this wave; Wl at + X_W_BYTES
+    const int nk = K / XBK;
+
+    // operand addressing of one tile.  DMA: wave w moves rows [16w, 16w+16) of Ah, Al, Wh, Wl: one instruction of 16 rows
+    // x 64 B each.  gridDim.x is a multiple of 8 whenever it is smaller than the tile count, so tile & 7 is this workgroup's XCD.
+    struct Tile { const char *ah, *al, *wh, *wl; unsigned a_voff, w_voff; int m0, n0; };
+    auto make_tile = [&](int b) __attribute__((always_inline)) {
+        int mt, nt;
         if ((ntm & 7) == 0) {
             const int xcd = b & 7, j = b >> 3;
             mt = (j / ntn) * 8 + xcd;
@@ -271,49 +285,50 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
             mt = b / ntn;
             nt = b % ntn;
         }
-    }
-    mt = __builtin_amdgcn_readfirstlane(mt);
-    nt = __builtin_amdgcn_readfirstlane(nt);
-    const int m0 = mt * GT, n0 = nt * GT;
-
-    // DMA: wave w moves rows [16w, 16w+16) of Ah, Al, Wh, Wl: one instruction of 16 rows x 64 B each
-    unsigned a_voff, w_voff;
-    {
+        mt = __builtin_amdgcn_readfirstlane(mt);
+        nt = __builtin_amdgcn_readfirstlane(nt);
+        Tile t;
+        t.m0 = mt * GT;
+        t.n0 = nt * GT;
         const int r = 16 * w + (lane >> 2);
-        int am = m0 + r; if (am > M - 1) am = M - 1;
-        int wn = n0 + r; if (wn > N - 1) wn = N - 1;
+        int am = t.m0 + r; if (am > M - 1) am = M - 1;
+        int wn = t.n0 + r; if (wn > N - 1) wn = N - 1;
         const size_t chunk = (size_t)(((lane & 3) ^ ((r >> 2) & 3)) * 8);
-        a_voff = (unsigned)(((size_t)(am - m0) * K + chunk) * 2);
-        w_voff = (unsigned)(((size_t)(wn - n0) * K + chunk) * 2);
-    }
-    const char* const ahbase = reinterpret_cast<const char*>(Ah + (size_t)m0 * K);
-    const char* const albase = reinterpret_cast<const char*>(Al + (size_t)m0 * K);
-    const char* const whbase = reinterpret_cast<const char*>(Wh + (size_t)n0 * K);
-    const char* const wlbase = reinterpret_cast<const char*>(Wl + (size_t)n0 * K);
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem + 16 * w * 64));
-    auto issue = [&](int kb, int stg) __attribute__((always_inline)) {
+        t.a_voff = (unsigned)(((size_t)(am - t.m0) * K + chunk) * 2);
+        t.w_voff = (unsigned)(((size_t)(wn - t.n0) * K + chunk) * 2);
+        t.ah = reinterpret_cast<const char*>(Ah + (size_t)t.m0 * K);
+        t.al = reinterpret_cast<const char*>(Al + (size_t)t.m0 * K);
+        t.wh = reinterpret_cast<const char*>(Wh + (size_t)t.n0 * K);
+        t.wl = reinterpret_cast<const char*>(Wl + (size_t)t.n0 * K);
+        return t;
+    };
+    auto issue = [&](const Tile& t, int kb, int stg) __attribute__((always_inline)) {
         const unsigned so = lds0 + stg * XS_STAGE;
         const size_t ko = (size_t)kb * (XBK * 2);
-        dma16s(ahbase + ko, a_voff, so);
-        dma16s(albase + ko, a_voff, so + X_W_BYTES);
-        dma16s(whbase + ko, w_voff, so + 2 * X_W_BYTES);
-        dma16s(wlbase + ko, w_voff, so + 3 * X_W_BYTES);
+        dma16s(t.ah + ko, t.a_voff, so);
+        dma16s(t.al + ko, t.a_voff, so + X_W_BYTES);
+        dma16s(t.wh + ko, t.w_voff, so + 2 * X_W_BYTES);
+        dma16s(t.wl + ko, t.w_voff, so + 3 * X_W_BYTES);
     };
 
-    const int i = lane & 31, kg = lane >> 5;
-    const int sww = (i >> 2) & 3;
-    const char* ard = smem + (64 * wr + i) * 64;                    // Ah rows of this wave; Al at + X_W_BYTES
-    const char* wrd = smem + 2 * X_W_BYTES + (64 * wc + i) * 64;    // Wh rows of this wave; Wl at + X_W_BYTES
-
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    const int nk = K / XBK;
-    issue(0, 0);
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    Tile cur = make_tile(tile);
+    issue(cur, 0, 0);
     int stage = 0;
+    for (;;) {
+    const int next = tile + (int)gridDim.x;
+    Tile nxt = cur;
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
     for (int kb = 0; kb < nk; ++kb) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kb + 1 < nk) issue(kb + 1, stage ^ 1);
+        if (kb + 1 < nk) issue(cur, kb + 1, stage ^ 1);
+        else if (next < ntiles) {  // last step: the other stage is free -> the next tile's first K stage
+            nxt = make_tile(next);
+            issue(nxt, 0, stage ^ 1);
+        }
         const char* as = ard + stage * XS_STAGE;
         const char* ws = wrd + stage * XS_STAGE;
 #pragma unroll
@@ -344,6 +359,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
         stage ^= 1;
     }
 
+    const int m0 = cur.m0, n0 = cur.n0;
     const int nb0 = n0 + 64 * wc + i, nb1 = nb0 + 32;
     float bias0 = 0.f, bias1 = 0.f;
     if (EPI != EPI_NONE) {
@@ -375,6 +391,10 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
             if (mr1 < M && nb1 < N) C[(size_t)mr1 * N + nb1] = v11;
         }
     }
+    if (next >= ntiles) break;
+    tile = next;
+    cur = nxt;
+    }  // tiles
 }
 
 template <int EPI>
@@ -1017,6 +1037,19 @@ __global__ __launch_bounds__(256) void clip_eos_pool_ln_kernel(const float* __re
     ln_store(v, H, lane, g, b, eps, out + (size_t)seq * H);
 }
 
+// Workgroups of a split-bf16 GEMM launch.  Default 0 = one workgroup per output tile.  MQ_GEMM_WGS=n (a multiple of 8, e.g.
+// the CU count) makes the launch persistent: n workgroups walk the tiles and request the next tile's first K stage during the
+// current tile's last step.  Measured on every encoder shape (tools/bench_gemm_shapes.py, round 2): 976 vs 975, 740 vs 731,
+// 949 vs 941, 1093 vs 1092 executed TFLOP/s -- the dispatcher already starts the next workgroup as fast as the overlap does,
+// so the plain launch stays the default (it also leaves CUs to the side streams of the grouped forward).
+int gemm_persistent_wgs() {
+    static const int wgs = [] {
+        const char* e = getenv("MQ_GEMM_WGS");
+        return e ? atoi(e) / 8 * 8 : 0;
+    }();
+    return wgs;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1099,7 +1132,10 @@ int mq_gemm_nt_bf16x3s_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const
     if (((uintptr_t)Ah_dev | (uintptr_t)Al_dev | (uintptr_t)Wh_dev | (uintptr_t)Wl_dev) & 15) return MQ_EINVAL;
     if (Ch_dev && (N & 1)) return MQ_EUNSUPPORTED;
     const int ntm = (M + GT - 1) / GT, ntn = (N + GT - 1) / GT;
-    const dim3 grid((unsigned)(ntm * ntn)), block(1024);
+    // MQ_GEMM_WGS=n: persistent launch, n workgroups walk the tiles (default: one workgroup per tile)
+    const int persist = gemm_persistent_wgs();
+    const int ntiles = ntm * ntn;
+    const dim3 grid((unsigned)(persist > 0 && ntiles > persist ? persist : ntiles)), block(1024);
     hipStream_t st = (hipStream_t)stream;
 #define MQ_LAUNCH2(E, S)                                                                                              \
     {                                                                                                                 \
