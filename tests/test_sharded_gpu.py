@@ -133,3 +133,51 @@ def test_faiss_file_written_by_the_reference_loads(tmp_path):
     D, I = idx.search_batch(Q, 20)
     Do, Io = ok.knn(X, ok.l2norm_rows(Q), 20, metric=0)
     assert np.array_equal(I, Io) and np.array_equal(D, Do)
+
+
+def test_config4_full_size_12M_rows_in_eight_shards_16k_queries():
+    """BASELINE configs[4] at full size on ONE MI355X (288 GB of HBM hold it): 12M x 768 fp32 rows in eight 1.5M-row shards
+    (screened search per shard, shard records, merge) against ONE unsharded 12M-row index searched by the exact fp32 scan --
+    16,384 queries, top-100, scores and ids bit for bit.  Only the transport differs from the 8-GPU job (device-to-device
+    copies instead of the RCCL all-gather, which tests/test_sharded_gpu.py runs at world size 1)."""
+    import torch
+    from viquae_amd.index import MI355XFlatIndex
+    from viquae_amd.sharded import LocalShardsFlatIndex
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    if free < 150 * (1 << 30):
+        pytest.skip(f"needs ~135 GB of free HBM, {free >> 30} GB available")
+    from viquae_amd.sharded import shard_bounds
+    n_total, shards, d, nq, k = 12_000_000, 8, 768, 16384, 100
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    sharded = LocalShardsFlatIndex([0] * shards, string_factory="Flat", metric_type=0, allow_repeated_devices=True, screen=True)
+    whole = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=False)
+    bounds = [shard_bounds(n_total, shards, r) for r in range(shards)]     # 1,500,032 rows per shard (whole panels), the last 1,499,776
+    for sh, (lo, _) in zip(sharded.shards, bounds):
+        sh.id_offset = lo
+    planted = {}
+    for b0 in range(0, n_total, 1 << 16):
+        x = torch.randn((min(1 << 16, n_total - b0), d), generator=g, device=dev)
+        whole.add(x, total_hint=n_total)
+        for r, (lo, hi) in enumerate(bounds):
+            s0, e0 = max(lo, b0), min(hi, b0 + x.shape[0])
+            if s0 < e0:
+                sharded.shards[r].add(x[s0 - b0:e0 - b0], total_hint=hi - lo)
+                if s0 == lo:
+                    planted[lo + 5] = x[lo + 5 - b0].clone()   # one known row per shard
+    sharded.ntotal, sharded.d = n_total, d
+    assert whole.ntotal == n_total and [sh.ntotal for sh in sharded.shards] == [hi - lo for lo, hi in bounds]
+    Q = torch.randn((nq, d), generator=g, device=dev)
+    for i, (gid, x) in enumerate(planted.items()):
+        Q[i * 1000] = 2.0 * x                              # its own row must be its top-1, whatever shard holds it
+    D, I = sharded.search_device(Q, k)
+    D0, I0 = whole.search_device(Q, k)
+    torch.cuda.synchronize()
+    assert torch.equal(I, I0) and torch.equal(D, D0)
+    for i, gid in enumerate(planted):
+        assert int(I[i * 1000, 0]) == gid
+    assert int(I.max()) >= bounds[7][0] and int(I.min()) >= 0   # neighbours come from every part of the id range
+    del sharded, whole
+    torch.cuda.empty_cache()
