@@ -689,6 +689,9 @@ __global__ __launch_bounds__(128) void shard_merge_kernel(const float* __restric
 
 #include "knn_screen.inc"
 #include "knn_direct.inc"
+#ifdef MQ_PROBE8
+#include "knn_probe8.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1089,8 +1092,13 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         a.dbg = dbg_ptr();
         a.N = N; a.dp = dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx_screen; a.nchunks = g.nchunks;
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
+#ifdef MQ_PROBE8
+        MQ_DYNAMIC_LDS(S_LDS_TOTAL, screen_probe8_kernel);
+        hipLaunchKernelGGL(screen_probe8_kernel, dim3((unsigned)(g.nqt * g.S)), dim3(512), S_LDS_TOTAL, st, a);
+#else
         MQ_DYNAMIC_LDS(S_LDS_TOTAL, screen_scan_kernel);
         hipLaunchKernelGGL(screen_scan_kernel, dim3((unsigned)(g.nqt * g.S)), dim3(1024), S_LDS_TOTAL, st, a);
+#endif
         MQ_HIP(hipGetLastError());
         if (ev_scan_end) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_end, st));
     }
