@@ -17,8 +17,8 @@ src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 
 
 def first(pattern):
-    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
-    return hits[0] if hits else None
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
+    return hits[-1] if hits else None  # gpurun merges runs into the same directories: take the newest
 
 
 for sub, name in (("kt", f"{tag}_kernel_stats.csv"), ("enc", f"{tag}_encoders_kernel_stats.csv")):
