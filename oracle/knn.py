@@ -113,9 +113,12 @@ def topk_merge(Ds, Is, metric=0):
 def knn_blas(X, Q, k, metric=0, block=1 << 16, threads=None):
     """The same search organised the way FAISS's IndexFlat runs it for 20 or more queries
     (faiss/utils/distances.cpp, exhaustive_inner_product_blas / exhaustive_L2sqr_blas): database blocks
-    through sgemm, then the k best per query.  Scores carry the BLAS library's summation order, not the
-    fmaf chain of knn(): this is bench.py's fast CPU leg (all cores through torch's BLAS), and it is
-    compared with knn() only up to float64 near-ties (tests/test_oracle_cpu.py)."""
+    through sgemm, then FAISS's heap rule -- a score enters a query's result only if it beats the query's
+    current k-th best.  Vectorised: after the first block (a plain top-k), a block's scores are compared with
+    the per-query thresholds and only the few survivors are merged (a full top-k of every 4096 x 65536 score
+    block cost 2.5x the sgemm).  Scores carry the BLAS library's summation order, not the fmaf chain of
+    knn(): this is bench.py's fast CPU leg (all cores through torch's BLAS), compared with knn() only up to
+    float64 near-ties (tests/test_oracle_cpu.py)."""
     import torch
     if threads:
         torch.set_num_threads(int(threads))
@@ -123,25 +126,35 @@ def knn_blas(X, Q, k, metric=0, block=1 << 16, threads=None):
     Xt, Qt = torch.from_numpy(X), torch.from_numpy(Q)
     nq, N = Qt.shape[0], Xt.shape[0]
     qn = (Qt * Qt).sum(1) if metric == 1 else None
-    best_v = torch.full((nq, 0), 0.0)
-    best_i = torch.zeros((nq, 0), dtype=torch.int64)
+    best_v = torch.full((nq, k), -FLT_MAX)            # goodness (ip, or -distance), best first; unfilled = neutral value
+    best_i = torch.full((nq, k), -1, dtype=torch.int64)
     for s in range(0, N, block):
         xb = Xt[s:s + block]
         S = Qt @ xb.T
         if metric == 1:
             S = -(qn[:, None] + (xb * xb).sum(1)[None, :] - 2.0 * S).clamp_min_(0.0)
-        v, i = torch.topk(S, min(k, S.shape[1]), dim=1)
-        best_v = torch.cat([best_v, v], 1)
-        best_i = torch.cat([best_i, i + s], 1)
-        if best_v.shape[1] > k:
-            best_v, sel = torch.topk(best_v, k, dim=1)
-            best_i = torch.gather(best_i, 1, sel)
+        if s == 0:
+            kk = min(k, S.shape[1])
+            v, i = torch.topk(S, kk, dim=1)
+            best_v[:, :kk], best_i[:, :kk] = v, i
+            continue
+        rows, cols = (S > best_v[:, -1:]).nonzero(as_tuple=True)   # strict, like FAISS's heap
+        if rows.numel() == 0:
+            continue
+        counts = torch.bincount(rows, minlength=nq)
+        width = int(counts.max())
+        first = torch.cumsum(counts, 0) - counts
+        pos = torch.arange(rows.numel()) - first[rows]
+        cand_v = torch.full((nq, width), -FLT_MAX)
+        cand_i = torch.full((nq, width), -1, dtype=torch.int64)
+        cand_v[rows, pos] = S[rows, cols]
+        cand_i[rows, pos] = cols + s
+        allv, alli = torch.cat([best_v, cand_v], 1), torch.cat([best_i, cand_i], 1)
+        best_v, sel = torch.topk(allv, k, dim=1)
+        best_i = torch.gather(alli, 1, sel)
     order = torch.argsort(best_v, dim=1, descending=True, stable=True)
     D, I = torch.gather(best_v, 1, order), torch.gather(best_i, 1, order)
-    if D.shape[1] < k:
-        pad = k - D.shape[1]
-        D = torch.cat([D, torch.full((nq, pad), -FLT_MAX)], 1)
-        I = torch.cat([I, torch.full((nq, pad), -1, dtype=torch.int64)], 1)
+    I = torch.where(D > -FLT_MAX, I, torch.full_like(I, -1))
     D = D.numpy()
     return (-D if metric == 1 else D).astype(np.float32), I.numpy()
 
