@@ -149,3 +149,25 @@ def test_shard_merge_kernel():
                                          torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         assert np.array_equal(I.cpu().numpy(), Iref) and np.array_equal(D.cpu().numpy(), Dref)
+
+
+@pytest.mark.parametrize("screen", [True, False])
+@pytest.mark.parametrize("metric,factory", [(0, "Flat"), (1, "Flat"), (0, "L2norm,Flat")])
+def test_add_accepts_any_number_of_rows_at_a_time(metric, factory, screen):
+    """faiss.Index.add takes any number of rows per call; the panel layout must not leak into the API: ragged appends give
+    the index (stored rows, norms, screening copies) one add of everything gives, bit for bit."""
+    from viquae_amd.index import MI355XFlatIndex
+    rng = np.random.default_rng(17)
+    X = rng.standard_normal((1000, 96), dtype=np.float32) * 3
+    Q = rng.standard_normal((40, 96), dtype=np.float32)
+    one = MI355XFlatIndex(string_factory=factory, metric_type=metric, screen=screen)
+    one.add(X)
+    many = MI355XFlatIndex(string_factory=factory, metric_type=metric, screen=screen)
+    at = 0
+    for n in (1, 62, 1, 100, 7, 64, 129, 300, 5, 331):
+        many.add(X[at:at + n])
+        at += n
+    assert at == 1000 and many.ntotal == 1000
+    assert np.array_equal(many.reconstruct_n(), one.reconstruct_n())
+    a, b = many.search_batch(Q, 50), one.search_batch(Q, 50)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])

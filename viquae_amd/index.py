@@ -176,8 +176,10 @@ class MI355XFlatIndex(BaseIndex):
         self._packed, self._sqnorm, self._capacity = new_packed, new_sqnorm, cap
 
     def add(self, vecs, total_hint: Optional[int] = None):
-        """Append rows (numpy [n,d] or a CUDA torch tensor). Rows already appended must be a
-        multiple of 64 unless this is the first call after them (the C ABI packs whole panels)."""
+        """Append rows (numpy [n,d] or a CUDA torch tensor), any number at a time like ``faiss.Index.add``.  The C ABI
+        packs whole 64-row panels: when the rows already stored end inside a panel, that panel's stored rows are read
+        back and re-packed together with the first new rows (bit-identical: they are stored after the "L2norm,"
+        transform and are not transformed twice)."""
         import torch
         lib = _lib.load()
         if isinstance(vecs, torch.Tensor):
@@ -191,13 +193,35 @@ class MI355XFlatIndex(BaseIndex):
             n, d = vecs.shape
         if n == 0:
             return
-        if self.ntotal % 64 != 0:
-            raise ValueError("MI355XFlatIndex.add: previous adds must total a multiple of 64 rows "
-                             "(add_vectors batches accordingly)")
         self._ensure_capacity(max(self.ntotal + n, total_hint or 0), d, exact=bool(total_hint))
         stream = torch.cuda.current_stream(self._torch_device).cuda_stream
+        first = 0
+        if self.ntotal % 64 != 0:
+            # finish the open panel: stored tail rows (already transformed) + the first new rows (transformed here)
+            floor = self.ntotal // 64 * 64
+            first = min(n, 64 - (self.ntotal - floor))
+            with torch.cuda.device(self._torch_device):
+                tail = torch.empty((self.ntotal - floor, self.d), dtype=torch.float32, device=self._torch_device)
+                _lib.check(lib.mq_unpack_rows_f32(self._packed.data_ptr(), self._capacity, self.d, floor, tail.shape[0],
+                                                  tail.data_ptr(), stream), "mq_unpack_rows_f32")
+                head = vecs[:first]
+                head = (head if isinstance(head, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(head)))
+                head = head.to(device=self._torch_device, dtype=torch.float32).contiguous().clone()
+                if self.do_l2norm:
+                    _lib.check(lib.mq_l2norm_rows_f32(head.data_ptr(), head.shape[0], self.d, stream), "mq_l2norm_rows_f32")
+                blk = torch.cat([tail, head]).contiguous()
+                _lib.check(lib.mq_pack_rows_f32(blk.data_ptr(), blk.shape[0], self.d, floor, 0, self._packed.data_ptr(),
+                                                self._capacity, self._sqnorm.data_ptr(), stream), "mq_pack_rows_f32")
+                if self.screen:
+                    _lib.check(lib.mq_knn_screen_prepare(self._packed.data_ptr(), self._sqnorm.data_ptr(), self._capacity, self.d,
+                                                         self.metric_type, floor, blk.shape[0], self._rowmajor.data_ptr(),
+                                                         self._bf16.data_ptr(), self._xmax2.data_ptr(),
+                                                         self._center.data_ptr() if self._center is not None else None, stream),
+                               "mq_knn_screen_prepare")
+                self.ntotal = floor + blk.shape[0]
+                torch.cuda.current_stream(self._torch_device).synchronize()
         with torch.cuda.device(self._torch_device):
-            for i in range(0, n, _UPLOAD_ROWS):
+            for i in range(first, n, _UPLOAD_ROWS):
                 part = vecs[i:i + _UPLOAD_ROWS]
                 if isinstance(part, torch.Tensor):
                     dev = part.to(device=self._torch_device, dtype=torch.float32).contiguous()
