@@ -84,11 +84,12 @@ def _worker(rank, world, port, metric, n, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("metric,n", [(0, 1000), (1, 1000), (0, 70), (1, 40), (0, 5)])  # 40, 5: rank 1 holds NO rows
-def test_world2_sharded_equals_unsharded(tmp_path, metric, n):
+@pytest.mark.parametrize("metric,n,world", [(0, 1000, 2), (1, 1000, 2), (0, 70, 2), (1, 40, 2), (0, 5, 2),   # 40, 5: rank 1 holds NO rows
+                                            (0, 333, 3), (1, 130, 4)])                                    # odd world; 4 ranks, the last one empty
+def test_world2_sharded_equals_unsharded(tmp_path, metric, n, world):
     from oracle import knn as ok
     out = str(tmp_path / "res.npz")
-    mp.spawn(_worker, args=(2, _free_port(), metric, n, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), metric, n, out), nprocs=world, join=True)
     z = np.load(out)
     D, I = ok.knn(z["X"], z["Q"], 20, metric=metric)
     assert np.array_equal(z["I"], I) and np.array_equal(z["D"], D)
