@@ -218,6 +218,10 @@ int mq_clip_text_embed_f32(const int64_t *input_ids_dev, const float *token_emb_
                            int B, int L, int H, void *stream);
 int mq_clip_eos_pool_ln_f32(const float *hidden_dev, const int64_t *input_ids_dev, int64_t eos_token_id, const float *gamma_dev,
                             const float *beta_dev, float *out_dev, int B, int L, int H, float eps, void *stream);
+/* mq_clip_text_embed_f32 over a PACKED token matrix (the real tokens of right-padded titles, see mq_attention_packed_f32):
+ * out[t] = token_emb[input_ids[t]] + pos_emb[position_ids[t]], t < T. */
+int mq_clip_text_embed_packed_f32(const int64_t *input_ids_dev, const int32_t *position_ids_dev, const float *token_emb_dev,
+                                  const float *pos_emb_dev, float *out_dev, int T, int H, void *stream);
 
 /* Split activations: a tensor that only feeds GEMMs is kept as its (hi, lo) bf16 pair (hi = bf16(x), lo = bf16(x - hi),
  * two uint16 arrays of the tensor's shape), written by the kernel that produces it, so that the consuming GEMM streams

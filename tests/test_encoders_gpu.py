@@ -624,13 +624,53 @@ def test_clip_text_padding_aware_forward_is_bit_identical_to_dense(monkeypatch):
         ids[b, n - 1:] = eot          # end of text, then padding with the same id (CLIPTokenizer's pad token)
     mask = (np.arange(L)[None] < lens[:, None]).astype(np.int64)
     model = encoders.CLIPModel.from_state_dict({"text_config": cfg}, state).to("cuda").eval()
+    packed = model.get_text_features(input_ids=_cuda(ids), attention_mask=_cuda(mask))   # default: packed forward
+    monkeypatch.setenv("MQ_ENC_PACKED", "0")
     monkeypatch.setattr(encoders, "_length_buckets", lambda m, max_buckets=8: _forced_plan(m))
     fast = model.get_text_features(input_ids=_cuda(ids), attention_mask=_cuda(mask))
     monkeypatch.setattr(encoders, "_length_buckets", lambda m, max_buckets=8: None)
     dense = model.get_text_features(input_ids=_cuda(ids), attention_mask=_cuda(mask))
-    assert torch.equal(fast, dense)
+    assert torch.equal(fast, dense) and torch.equal(packed, dense)
     want = oe.clip_text_forward(state, cfg, ids[:32], mask[:32])
     assert np.abs(fast[:32].cpu().numpy() - want).max() < TOL
+
+
+@pytest.mark.parametrize("gemm", ["split_bf16", "f32"])
+def test_clip_text_packed_forward_vitb32_text_size(gemm, monkeypatch):
+    """CLIP ViT-B/32's text tower (512 wide, 12 layers, 77 positions), titles of 3 .. 77 tokens padded to 77 (lengths on both
+    sides of the attention kernel's 64-key tile): packed == dense bit for bit in both GEMM arithmetics; a batch whose
+    end-of-text token lies outside the mask is not packed (and still equals the dense forward)."""
+    from oracle import encoders as oe
+    from viquae_amd import encoders
+    monkeypatch.setenv("MQ_ENC_GEMM", gemm)
+    cfg = oe.CLIP_TEXT_VITB32
+    state = oe.seeded_state(oe.clip_text_param_shapes(cfg), 4)
+    rng = np.random.default_rng(8)
+    B, L = 40, 77
+    bos, eot = cfg["vocab_size"] - 2, cfg["vocab_size"] - 1
+    lens = np.array([77, 3, 64, 65, 63, 8, 9, 12] + list(rng.integers(3, 30, B - 8)))
+    ids = rng.integers(3, cfg["vocab_size"] - 2, (B, L)).astype(np.int64)
+    ids[:, 0] = bos
+    for b, n in enumerate(lens):
+        ids[b, n - 1:] = eot
+    mask = (np.arange(L)[None] < lens[:, None]).astype(np.int64)
+    model = encoders.CLIPModel.from_state_dict({"text_config": cfg}, state).to("cuda").eval()
+    calls = []
+    real = model._text_features_packed
+    monkeypatch.setattr(model, "_text_features_packed", lambda *a: calls.append(1) or real(*a))
+    packed = model.get_text_features(input_ids=_cuda(ids), attention_mask=_cuda(mask))
+    assert calls == [1]
+    short = mask.copy()
+    short[5, lens[5] - 1] = 0                 # the mask stops before the end-of-text token of title 5
+    cut = model.get_text_features(input_ids=_cuda(ids), attention_mask=_cuda(short))
+    assert calls == [1]                       # declined
+    monkeypatch.setenv("MQ_ENC_PACKED", "0")
+    monkeypatch.setattr(encoders, "_length_buckets", lambda m, max_buckets=8: None)
+    dense = model.get_text_features(input_ids=_cuda(ids), attention_mask=_cuda(mask))
+    assert torch.equal(packed, dense)
+    assert torch.equal(cut, model.get_text_features(input_ids=_cuda(ids), attention_mask=_cuda(short)))
+    want = oe.clip_text_forward(state, cfg, ids[:3], mask[:3])
+    assert np.abs(packed[:3].cpu().numpy() - want).max() < TOL
 
 
 def test_dpr_beyond_256_tokens_matches_the_oracle():

@@ -172,19 +172,25 @@ def clip_text_padded_throughput(B=2048, mean_len=8, std_len=3, longest=32, steps
     ids = torch.from_numpy(ids).to(device)
     mask = torch.from_numpy((np.arange(L)[None] < lens[:, None]).astype(np.int64)).to(device)
     run = lambda: model.get_text_features(input_ids=ids, attention_mask=mask)  # noqa: E731
-    t_skip = time_it(run, steps)   # small batches stay dense (size heuristic of _length_buckets)
+    t_skip = time_it(run, steps)   # default: the packed forward (real tokens only)
     a = run()
+    os.environ["MQ_ENC_PACKED"] = "0"
+    try:
+        t_groups = time_it(run, steps)   # groups of similar length, each dense at its own length
+        g = run()
+    finally:
+        del os.environ["MQ_ENC_PACKED"]
     os.environ["MQ_ENC_PAD_SKIP"] = "0"
     try:
         t_dense = time_it(run, steps)
         b = run()
     finally:
         del os.environ["MQ_ENC_PAD_SKIP"]
-    return {"titles_per_s": B / t_skip, "ms_per_batch": t_skip * 1e3, "dense_titles_per_s": B / t_dense,
-            "dense_ms_per_batch": t_dense * 1e3, "batch": B, "padded_to": L, "mean_tokens": float(lens.mean()),
-            "identical_to_dense": bool(torch.equal(a, b))}
+    return {"titles_per_s": B / t_skip, "ms_per_batch": t_skip * 1e3, "length_groups_titles_per_s": B / t_groups,
+            "dense_titles_per_s": B / t_dense, "dense_ms_per_batch": t_dense * 1e3, "batch": B, "padded_to": L,
+            "mean_tokens": float(lens.mean()), "identical_to_dense": bool(torch.equal(a, b) and torch.equal(g, b))}
 
 
 if __name__ == "__main__":
     print(json.dumps({"dpr": dpr_throughput(), "dpr_padded": dpr_padded_throughput(), "clip": clip_throughput(),
-                      "clip_text": clip_text_throughput()}))
+                      "clip_text": clip_text_throughput(), "clip_text_padded": clip_text_padded_throughput()}))

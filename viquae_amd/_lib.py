@@ -49,6 +49,7 @@ SIGNATURES = {
                                         c_ptr]),
     "mq_attention_causal_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, ctypes.c_float, c_int, c_ptr]),
     "mq_clip_text_embed_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
+    "mq_clip_text_embed_packed_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "mq_clip_eos_pool_ln_f32": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, ctypes.c_float, c_ptr]),
     "mq_gemm_nt_bf16x3s_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int,
                                        c_ptr]),

@@ -998,12 +998,12 @@ __global__ __launch_bounds__(256) void sum_groups_kernel(const float* __restrict
 // CLIP text tower input: token embedding + position embedding (no LayerNorm, no token types)
 __global__ __launch_bounds__(256) void clip_text_embed_kernel(const long long* __restrict__ ids, const float* __restrict__ tok,
                                                               const float* __restrict__ pos, float* __restrict__ out, int M,
-                                                              int L, int H) {
+                                                              int L, int H, const int* __restrict__ pos_ids) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
     const long long id = ids[row];
-    const int t_pos = row % L;
+    const int t_pos = pos_ids ? pos_ids[row] : row % L;  // packed token matrix: the position travels with the token
     for (int c = lane; c < H; c += 64) out[(size_t)row * H + c] = tok[(size_t)id * H + c] + pos[(size_t)t_pos * H + c];
 }
 
@@ -1348,7 +1348,18 @@ int mq_clip_text_embed_f32(const int64_t* input_ids_dev, const float* token_emb_
     if (!input_ids_dev || !token_emb_dev || !pos_emb_dev || !out_dev || B < 0 || L < 0 || H <= 0) return MQ_EINVAL;
     const int M = B * L;
     hipLaunchKernelGGL(clip_text_embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const long long*)input_ids_dev, token_emb_dev, pos_emb_dev, out_dev, M, L, H);
+                       (const long long*)input_ids_dev, token_emb_dev, pos_emb_dev, out_dev, M, L, H, (const int*)nullptr);
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_clip_text_embed_packed_f32(const int64_t* input_ids_dev, const int32_t* position_ids_dev, const float* token_emb_dev,
+                                  const float* pos_emb_dev, float* out_dev, int T, int H, void* stream) {
+    if (T == 0) return MQ_OK;
+    if (!input_ids_dev || !position_ids_dev || !token_emb_dev || !pos_emb_dev || !out_dev || T < 0 || H <= 0) return MQ_EINVAL;
+    hipLaunchKernelGGL(clip_text_embed_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)input_ids_dev, token_emb_dev, pos_emb_dev, out_dev, T, 1, H,
+                       (const int*)position_ids_dev);
     ENC_HIP(hipGetLastError());
     return MQ_OK;
 }

@@ -610,14 +610,20 @@ class DPRQuestionEncoder(_DPREncoder):
 # --------------------------------------------------------------------------------------------------
 # CLIP vision tower
 # --------------------------------------------------------------------------------------------------
-def _clip_block(h, w, sp, mask, B, T, heads, scale, eps, act, causal, keep_rows=None):
+def _clip_block(h, w, sp, mask, B, T, heads, scale, eps, act, causal, keep_rows=None, pack=None):
     """One pre-LN CLIP transformer block on the residual stream h [B*T, H] (updated in place).  ``keep_rows`` (int64 row
     indices, one per sequence) is given for the LAST block: only the pooled token's row leaves the tower, and everything
-    after the attention is row-wise, so the output projection and the MLP run on those B rows alone (same numbers)."""
+    after the attention is row-wise, so the output projection and the MLP run on those B rows alone (same numbers).
+    ``pack`` = (cu_seqlens, attention launch classes) when h is a PACKED token matrix (see _pack_plan)."""
+    def attend(qkv, split):
+        if pack is not None:
+            return attention_packed(qkv, pack[0], pack[1], heads, scale, causal=causal, split=split)
+        return attention(qkv, mask, B, T, heads, scale, causal=causal, split=split)
+
     if _use_split(h.shape[1], w("w1").shape[0]):
         _, y = layernorm_split(h, w("g1"), w("b1"), eps, want_f32=False)
         qkv = gemm_nt(y, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
-        ctx = attention(qkv, mask, B, T, heads, scale, causal=causal, split=True)
+        ctx = attend(qkv, True)
         if keep_rows is not None:
             ctx, h = ctx.rows(keep_rows), h.index_select(0, keep_rows).contiguous()
         h = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("wo"))
@@ -626,7 +632,7 @@ def _clip_block(h, w, sp, mask, B, T, heads, scale, eps, act, causal, keep_rows=
         return gemm_nt(f, w("w2"), w("bb2"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("w2"))
     y = layernorm(h, w("g1"), w("b1"), eps)
     qkv = gemm_nt(y, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
-    ctx = attention(qkv, mask, B, T, heads, scale, causal=causal)
+    ctx = attend(qkv, False)
     if keep_rows is not None:
         ctx, h = ctx.index_select(0, keep_rows).contiguous(), h.index_select(0, keep_rows).contiguous()
     h = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, out=h, wsplit=sp("wo"))
@@ -757,6 +763,10 @@ class CLIPModel(_HipEncoder):
                              f"and max_position_embeddings: {self.t_max_pos}")
         if B and (int(ids.min()) < 0 or int(ids.max()) >= self.t_tok.shape[0]):
             raise IndexError("input_ids outside the vocabulary")
+        eot = ids.to(torch.int32).argmax(dim=1) if self.t_eos == 2 else (ids == self.t_eos).to(torch.int32).argmax(dim=1)
+        pack = _pack_plan(attention_mask)
+        if pack is not None and bool((eot.to(torch.int64) < attention_mask.to(torch.int64).sum(dim=1)).all()):
+            return self._text_features_packed(ids, eot, pack)
         plan = _length_buckets(attention_mask)
         if plan is not None:
             # titles padded to the longest of 2048 (experiments/ir/viquae/clip/config.json:10-13) are mostly padding: run
@@ -768,6 +778,29 @@ class CLIPModel(_HipEncoder):
                                                                   attention_mask.index_select(0, idx)[:, :Li]))
             return out
         return self._text_features_dense(ids, attention_mask)
+
+    def _text_features_packed(self, ids, eot, pack):
+        """Packed forward of right-padded titles (``pack`` from :func:`_pack_plan`): only the real tokens go through the
+        tower and causal attention runs per title over its own keys.  The pooled end-of-text row ``eot[b]`` (a real token)
+        attends to real tokens only, and so does every row it depends on: bit-identical to the dense forward."""
+        lib = _lib.load()
+        keep, pos, cu, classes, first_rows = pack
+        dev, H, T = ids.device, self.t_hidden, int(keep.numel())
+        ids_p = ids.reshape(-1).index_select(0, keep)
+        h = torch.empty((T, H), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mq_clip_text_embed_packed_f32(ids_p.data_ptr(), pos.data_ptr(), self.t_tok.data_ptr(),
+                                                         self.t_pos.data_ptr(), h.data_ptr(), T, H, _stream(h)),
+                       "mq_clip_text_embed_packed_f32")
+        scale = (H // self.t_heads) ** -0.5
+        eot_rows = first_rows + eot.to(torch.int64)
+        for i in range(self.t_layers):
+            w = lambda n: getattr(self, f"t{i}_{n}")  # noqa: E731
+            sp = lambda n: self._ws(f"t{i}_{n}")  # noqa: E731
+            h = _clip_block(h, w, sp, None, 0, 0, self.t_heads, scale, self.t_eps, self.t_act, causal=True,
+                            keep_rows=eot_rows if i == self.t_layers - 1 else None, pack=(cu, classes))
+        pooled = layernorm(h, self.t_fin_g, self.t_fin_b, self.t_eps)
+        return gemm_nt(pooled, self.t_wproj, None, None, EPI_NONE, wsplit=self._ws("t_wproj"))
 
     def _text_features_dense(self, ids, attention_mask):
         lib = _lib.load()
