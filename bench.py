@@ -223,7 +223,10 @@ def main():
     multi = world > 1 or force_dist
     rows, k = args.rows, TOPK
     nq = args.nq or (4 * NQ if multi else NQ)
-    local = MI355XFlatIndex(device=local_rank, string_factory="Flat", metric_type=0, id_offset=rank * rows, screen=True)
+    # keep_panel: the exact fp32 scan is timed beside the screened search on the same shard (a screened index alone keeps no
+    # panel copy; its fallback launch is the same no-op either way)
+    local = MI355XFlatIndex(device=local_rank, string_factory="Flat", metric_type=0, id_offset=rank * rows, screen=True,
+                            keep_panel=True)
     build_shard(local, rows, seed=rank, device=device)
     index = ShardedFlatIndex(string_factory="Flat", metric_type=0, local_index=local, always_gather=force_dist) if multi else None
     if index is not None:
@@ -248,7 +251,7 @@ def main():
         Dq, Iq = (D, I) if out is None else out
         if (which or mode) == "screened":
             _lib.check(lib.mq_knn_search_screened_f32(
-                local._packed.data_ptr(), local._sqnorm.data_ptr(), local._rowmajor.data_ptr(), local._bf16.data_ptr(),
+                local._packed.data_ptr() if local._packed is not None else None, local._sqnorm.data_ptr(), local._rowmajor.data_ptr(), local._bf16.data_ptr(),
                 local._xmax2.data_ptr(), rows, DIM, q.data_ptr(), q.shape[0], k, 0, 0, local.id_offset, Dq.data_ptr(), Iq.data_ptr(),
                 ws.data_ptr(), ws_bytes, stream.cuda_stream, e0, e1), "mq_knn_search_screened_f32")
         else:

@@ -117,13 +117,21 @@ int mq_knn_search_f32_ev(const float *packed_dev, const float *sqnorm_dev, int64
  *                               embeddings with a large shared component the screen's margin then follows ||x - c||);
  *                               the same vector must be passed for every row range of a shard
  * mq_knn_screen_prepare fills rowmajor/bf16 for rows [row_offset, row_offset+n) from the panel buffer.
+ * mq_knn_screen_add_rows_f32 does the same straight from incoming rows (row-major [n, d], any row_offset), applying the
+ * optional "L2norm," transform and writing ||x||^2 with mq_pack_rows_f32's arithmetic -- for a shard that keeps NO panel copy
+ * (1.5x the matrix in HBM instead of 2.5x): mq_knn_search_screened_f32 then takes packed_dev = NULL.
  * Query tiles whose bounded candidate buffers overflow are recomputed by the exact scan inside the
- * same call.  Workspace: mq_knn_workspace_bytes (covers both paths).
+ * same call (from the panel copy, or from the row-major copy when packed_dev is NULL: same MFMA sequence, same bits, a
+ * slower operand path); FAISS's small-batch L2 form (MQ_KNN_L2_DIRECT_BELOW) likewise reads whichever copy exists.
+ * Workspace: mq_knn_workspace_bytes (covers both paths).
  * ------------------------------------------------------------------------------------------- */
 size_t mq_knn_screen_bytes(int64_t n_rows, int d, int metric);
 int mq_knn_screen_prepare(const float *packed_dev, const float *sqnorm_dev, int64_t capacity_rows, int d, int metric,
                           int64_t row_offset, int64_t n, float *rowmajor_dev, uint16_t *bf16_dev, float *xstats_dev,
                           const float *center_dev, void *stream);
+int mq_knn_screen_add_rows_f32(const float *rows_dev, int64_t n, int d, int64_t row_offset, int l2norm, int metric,
+                               int64_t capacity_rows, float *sqnorm_dev, float *rowmajor_dev, uint16_t *bf16_dev,
+                               float *xstats_dev, const float *center_dev, void *stream);
 int mq_knn_search_screened_f32(const float *packed_dev, const float *sqnorm_dev, const float *rowmajor_dev,
                                const uint16_t *bf16_dev, const float *xstats_dev, int64_t N, int d,
                                const float *queries_dev, int nq, int k, int metric, int l2norm_queries, int64_t id_offset,

@@ -9,7 +9,7 @@ N, d, nq, k = int(os.environ.get("N", 1500000)), 768, int(os.environ.get("NQ", 4
 dev = torch.device("cuda")
 g = torch.Generator(device=dev); g.manual_seed(0)
 mu = torch.randn((1, d), generator=g, device=dev); mu = 9.0 * mu / mu.norm()
-idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
+idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True, keep_panel=True)
 for s in range(0, N, 1 << 16):
     n = min(1 << 16, N - s)
     idx.add(mu + 0.25 * torch.randn((n, d), generator=g, device=dev), total_hint=N)

@@ -18,7 +18,7 @@ evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tru
 for a, b in evs: a.record(st); b.record(st)
 torch.cuda.synchronize()
 for a, b in evs:
-    _lib.check(lib.mq_knn_search_screened_f32(idx._packed.data_ptr(), idx._sqnorm.data_ptr(), idx._rowmajor.data_ptr(), idx._bf16.data_ptr(),
+    _lib.check(lib.mq_knn_search_screened_f32(idx._packed.data_ptr() if idx._packed is not None else None, idx._sqnorm.data_ptr(), idx._rowmajor.data_ptr(), idx._bf16.data_ptr(),
         idx._xmax2.data_ptr(), N, d, Q.data_ptr(), nq, k, 0, 0, 0, D.data_ptr(), I.data_ptr(), ws.data_ptr(), ws.numel(), st.cuda_stream, a.cuda_event, b.cuda_event))
 torch.cuda.synchronize()
 print(os.environ.get("MEERQAT_HIP_LIB", "default").split("/")[-1], "scan ms:", sum(a.elapsed_time(b) for a, b in evs[1:]) / 5)

@@ -186,6 +186,53 @@ __global__ void unpack_rows_kernel(const float* __restrict__ packed, int d, int 
     dst[e] = packed[((row / PANEL) * dpad + k) * PANEL + (row % PANEL)];
 }
 
+// pack_rows_kernel's arithmetic (the "L2norm," transform, the ||x||^2 chain over the padded dimension) with a ROW-MAJOR
+// destination dst[row_offset + r][k] -- the stored rows of a screened index that keeps no panel copy; any row_offset.
+__global__ __launch_bounds__(256) void store_rows_kernel(const float* __restrict__ src, int64_t n, int d, int dpad,
+                                                         int64_t row_offset, int l2norm, float* __restrict__ dst,
+                                                         float* __restrict__ sqnorm) {
+    __shared__ float tile[64][65];
+    __shared__ float nrm[64];
+    const int t = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    if (l2norm) {
+        float acc = 0.f;
+        for (int kc = 0; kc < d; kc += 64) {
+            load_tile64(src, n, d, row0, kc, tile);
+            __syncthreads();
+            if (t < 64) {
+#pragma unroll 8
+                for (int k = 0; k < 64; ++k) acc = fmaf(tile[t][k], tile[t][k], acc);
+            }
+            __syncthreads();
+        }
+        if (t < 64) nrm[t] = sqrtf(acc);
+        __syncthreads();
+    }
+    float acc2 = 0.f;
+    for (int kc = 0; kc < dpad; kc += 64) {
+        load_tile64(src, n, d, row0, kc, tile);
+        __syncthreads();
+        if (l2norm) {
+            for (int e = t; e < 64 * 64; e += 256) {
+                const int r = e >> 6, k = e & 63;
+                if (row0 + r < n && kc + k < d) tile[r][k] = tile[r][k] / nrm[r];
+            }
+            __syncthreads();
+        }
+        if (t < 64) {
+#pragma unroll 8
+            for (int k = 0; k < 64; ++k) acc2 = fmaf(tile[t][k], tile[t][k], acc2);
+        }
+        for (int e = t; e < 64 * 64; e += 256) {
+            const int r = e >> 6, k = e & 63;
+            if (row0 + r < n && kc + k < d) dst[(row_offset + row0 + r) * (int64_t)d + kc + k] = tile[r][k];
+        }
+        __syncthreads();
+    }
+    if (t < 64 && row0 + t < n) sqnorm[row_offset + row0 + t] = acc2;
+}
+
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ rows, int64_t n, int d) {
     __shared__ float tile[64][65];
     __shared__ float nrm[64];
@@ -217,7 +264,7 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ ro
 // the scan kernel
 // ------------------------------------------------------------------------------------------------
 struct ScanArgs {
-    const float* Xp;   // KB, panel layout
+    const float* Xp;   // KB, panel layout (knn_scan_kernel<*, true>: the row-major [N][d] copy)
     const float* Qp;   // queries, panel layout (nqt * 4 panels)
     const float* xn;   // ||x||^2 per KB row (L2 only)
     const float* qn;   // ||q||^2 per query   (L2 only)
@@ -226,6 +273,7 @@ struct ScanArgs {
     int dpad, nqt, S, k, qpx;
     long long nchunks;
     unsigned long long* dbg;  // MQ_TIMING builds only
+    int d;                    // row stride of the row-major operand (XROW instantiations)
     const int* only;          // optional [nqt] flags: scan only the flagged query tiles (fallback of the screened path)
 };
 
@@ -354,7 +402,13 @@ __device__ __forceinline__ int compact_pool(u64* __restrict__ P, int g, int k, f
 #define MQ_T_DUMP
 #endif
 
-template <int METRIC>
+// XROW: the KB operand is read from a ROW-MAJOR fp32 matrix (a.Xp = [N][a.d]) instead of the panel layout -- the exact-scan
+// fallback of a screened index that keeps no panel copy (mq_knn_search_screened_f32 with packed_dev = NULL).  Each thread
+// loads four consecutive k of one row to registers one K-step ahead and lays them out in the LDS stage exactly as the
+// LDS-DMA of the panel layout would, so the MFMA sequence -- hence every score bit -- is the same; rows >= N and k >= d read
+// as zero like the panel padding.  Slower than the DMA path (64-byte row pieces, a 4-way bank conflict on the transposing
+// ds_write): it only runs for query tiles whose screening buffers overflowed.
+template <int METRIC, bool XROW = false>
 __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Xs = reinterpret_cast<float*>(smem + LDS_XS);
@@ -417,8 +471,35 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
     auto issue = [&](int c, int kb, int stage) __attribute__((always_inline)) {
         const char* xb = xbase0 + (size_t)c * chunk_bytes + (size_t)kb * (BK * PANEL * 4);
         const char* qb = qbase0 + (size_t)kb * (BK * PANEL * 4);
-        dma16s(xb, dma_voff, lds_x + stage * (4096 * 4));
+        if (!XROW) dma16s(xb, dma_voff, lds_x + stage * (4096 * 4));
         dma16s(qb, dma_voff, lds_q + stage * (4096 * 4));
+    };
+    // XROW operand path: thread -> (row = tid / 4 of the chunk, k = 4 (tid % 4) .. + 3 of the K-step)
+    float xr0 = 0.f, xr1 = 0.f, xr2 = 0.f, xr3 = 0.f;
+    int xci = c0, xkbi = 0;
+    auto xrow_load = [&]() __attribute__((always_inline)) {
+        xr0 = xr1 = xr2 = xr3 = 0.f;
+        if (xci < c1) {
+            const long long row = (long long)xci * TN + (tid >> 2);
+            const int kk = xkbi * BK + (tid & 3) * 4;
+            if (row < a.N) {
+                const float* p = a.Xp + (size_t)row * a.d + kk;
+                if (kk + 3 < a.d && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                    const float4 f = *reinterpret_cast<const float4*>(p);
+                    xr0 = f.x; xr1 = f.y; xr2 = f.z; xr3 = f.w;
+                } else {
+                    if (kk < a.d) xr0 = p[0];
+                    if (kk + 1 < a.d) xr1 = p[1];
+                    if (kk + 2 < a.d) xr2 = p[2];
+                    if (kk + 3 < a.d) xr3 = p[3];
+                }
+            }
+            if (++xkbi == nkb) { xkbi = 0; ++xci; }
+        }
+    };
+    auto xrow_store = [&](int stage) __attribute__((always_inline)) {
+        float* dst = Xs + stage * 4096 + (tid >> 8) * (BK * 64) + (tid & 3) * (4 * 64) + ((tid >> 2) & 63);
+        dst[0] = xr0; dst[64] = xr1; dst[128] = xr2; dst[192] = xr3;
     };
 
     const int i2 = (lane & 31) * 2;
@@ -451,6 +532,13 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
     };
     issue_next(0);
     issue_next(1);
+    if (XROW) {  // stages 0 and 1 by hand; the rows of step 2 wait in registers
+        xrow_load();
+        xrow_store(0);
+        xrow_load();
+        xrow_store(1);
+        xrow_load();
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
@@ -489,9 +577,14 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
             // LDS burst during which the matrix pipe starves.  The only cross-wave facts needed here are
             // the DMA landing (vmcnt) and program order; the empty asm statements keep hipcc from moving
             // LDS accesses across the barrier.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (XROW) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // + the previous step's ds_write of the X rows
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (XROW) {
+                xrow_store(cur >= 1 ? cur - 1 : 2);  // the rows of step t + 2, loaded during step t - 1
+                xrow_load();                         // step t + 3
+            }
             issue_next(cur >= 1 ? cur - 1 : 2);  // stage (cur + 2) % 3
             const float2 fx6 = MQ_LD2(xs + 6 * 128), fq6 = MQ_LD2(qs + 6 * 128);
             MQ_M4(fx4, fq4)
@@ -891,7 +984,7 @@ int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[8]) {
 }
 
 // metric L2 with fewer than 20 queries: FAISS's sequential path, d = sum_k (q[k] - x[k])^2 (knn_direct.inc)
-static int knn_search_l2_direct(const float* packed_dev, int64_t N, int d, const float* queries_dev, int nq, int k,
+static int knn_search_l2_direct(const float* packed_dev, const float* rowmajor_dev, int64_t N, int d, const float* queries_dev, int nq, int k,
                                 int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev, void* ws_dev,
                                 const Geometry& g, hipStream_t st) {
     char* ws = (char*)ws_dev;
@@ -911,8 +1004,12 @@ static int knn_search_l2_direct(const float* packed_dev, int64_t N, int d, const
     MQ_HIP(hipGetLastError());
     const long long seg = (long long)((g.nchunks + g.S - 1) / g.S) * TN;  // rows per selection segment
     if (N > 0) {
-        hipLaunchKernelGGL(l2_direct_dist_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, packed_dev, Qt, (long long)N, d,
-                           g.dpad, nq, (long long)g.npad, dist);
+        if (packed_dev)
+            hipLaunchKernelGGL(l2_direct_dist_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, packed_dev, Qt, (long long)N,
+                               d, g.dpad, nq, (long long)g.npad, dist);
+        else
+            hipLaunchKernelGGL(l2_direct_dist_rows_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, rowmajor_dev, Qt,
+                               (long long)N, d, nq, (long long)g.npad, dist);
         MQ_HIP(hipGetLastError());
     }
     // segment winners live in the (much larger) pool region of the other paths: nq * S * 128 keys
@@ -942,7 +1039,7 @@ static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int
     float* qtmp = (float*)(ws + g.off_qtmp);
     u64* lists = (u64*)(ws + g.off_lists);
     if (metric == MQ_METRIC_L2 && nq < MQ_KNN_L2_DIRECT_BELOW)
-        return knn_search_l2_direct(packed_dev, N, d, queries_dev, nq, k, l2norm_queries, id_offset, D_dev, I_dev, ws_dev, g, st);
+        return knn_search_l2_direct(packed_dev, nullptr, N, d, queries_dev, nq, k, l2norm_queries, id_offset, D_dev, I_dev, ws_dev, g, st);
 
     // queries -> panel layout (+ optional "L2norm," transform, + ||q||^2); padded queries are zero
     MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
@@ -955,7 +1052,7 @@ static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int
     if (N > 0) {
         ScanArgs a;
         a.Xp = packed_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = lists;
-        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = dbg_ptr(); a.only = nullptr;
+        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = dbg_ptr(); a.only = nullptr; a.d = d;
         const dim3 grid((unsigned)(g.nqt * g.S)), block(1024);
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
         if (metric == MQ_METRIC_IP) {
@@ -999,20 +1096,11 @@ size_t mq_knn_screen_bytes(int64_t n_rows, int d, int metric) {
     return (size_t)mq_padded_rows(n_rows) * (size_t)screen_dp(d, metric) * 2;
 }
 
-int mq_knn_screen_prepare(const float* packed_dev, const float* sqnorm_dev, int64_t capacity_rows, int d, int metric,
-                          int64_t row_offset, int64_t n, float* rowmajor_dev, uint16_t* bf16_dev, float* xstats_dev,
-                          const float* center_dev, void* stream) {
-    if (n == 0) return MQ_OK;
-    if (!packed_dev || !sqnorm_dev || !rowmajor_dev || !bf16_dev || !xstats_dev || n < 0 || d <= 0 || row_offset < 0 ||
-        row_offset + n > capacity_rows)
-        return MQ_EINVAL;
-    if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    const int dpad = mq_padded_dim(d), dp = screen_dp(d, metric);
-    float* rm = rowmajor_dev + (size_t)row_offset * d;
-    const int64_t total = n * (int64_t)d;
-    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, packed_dev, d, dpad, row_offset, n, rm);
-    MQ_HIP(hipGetLastError());
+// bf16 screening copy + error statistics of rows [row_offset, row_offset + n) of the row-major store
+static int screen_copy_and_stats(const float* sqnorm_dev, int d, int metric, int64_t row_offset, int64_t n, float* rowmajor_dev,
+                                 uint16_t* bf16_dev, float* xstats_dev, const float* center_dev, hipStream_t st) {
+    const int dp = screen_dp(d, metric);
+    const float* rm = rowmajor_dev + (size_t)row_offset * d;
     const int64_t quads = n * (int64_t)(dp / 4);
     hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, rm, n, d, dp,
                        (unsigned short*)bf16_dev + (size_t)row_offset * dp, metric == MQ_METRIC_L2 ? 1 : 0, sqnorm_dev + row_offset,
@@ -1024,6 +1112,38 @@ int mq_knn_screen_prepare(const float* packed_dev, const float* sqnorm_dev, int6
     return MQ_OK;
 }
 
+int mq_knn_screen_prepare(const float* packed_dev, const float* sqnorm_dev, int64_t capacity_rows, int d, int metric,
+                          int64_t row_offset, int64_t n, float* rowmajor_dev, uint16_t* bf16_dev, float* xstats_dev,
+                          const float* center_dev, void* stream) {
+    if (n == 0) return MQ_OK;
+    if (!packed_dev || !sqnorm_dev || !rowmajor_dev || !bf16_dev || !xstats_dev || n < 0 || d <= 0 || row_offset < 0 ||
+        row_offset + n > capacity_rows)
+        return MQ_EINVAL;
+    if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int dpad = mq_padded_dim(d);
+    float* rm = rowmajor_dev + (size_t)row_offset * d;
+    const int64_t total = n * (int64_t)d;
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, packed_dev, d, dpad, row_offset, n, rm);
+    MQ_HIP(hipGetLastError());
+    return screen_copy_and_stats(sqnorm_dev, d, metric, row_offset, n, rowmajor_dev, bf16_dev, xstats_dev, center_dev, st);
+}
+
+int mq_knn_screen_add_rows_f32(const float* rows_dev, int64_t n, int d, int64_t row_offset, int l2norm, int metric,
+                               int64_t capacity_rows, float* sqnorm_dev, float* rowmajor_dev, uint16_t* bf16_dev,
+                               float* xstats_dev, const float* center_dev, void* stream) {
+    if (n == 0) return MQ_OK;
+    if (!rows_dev || !sqnorm_dev || !rowmajor_dev || !bf16_dev || !xstats_dev || n < 0 || d <= 0 || row_offset < 0 ||
+        row_offset + n > capacity_rows)
+        return MQ_EINVAL;
+    if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(store_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, rows_dev, n, d, mq_padded_dim(d), row_offset,
+                       l2norm, rowmajor_dev, sqnorm_dev);
+    MQ_HIP(hipGetLastError());
+    return screen_copy_and_stats(sqnorm_dev, d, metric, row_offset, n, rowmajor_dev, bf16_dev, xstats_dev, center_dev, st);
+}
+
 int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev, const float* rowmajor_dev,
                                const uint16_t* bf16_dev, const float* xstats_dev, int64_t N, int d, const float* queries_dev,
                                int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev,
@@ -1032,7 +1152,9 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
     const int l2 = metric == MQ_METRIC_L2;
     const int dp = screen_dp(d, metric);
-    if (!packed_dev || !sqnorm_dev || !rowmajor_dev || !bf16_dev || !xstats_dev || !queries_dev || !D_dev || !I_dev || !ws_dev)
+    // packed_dev may be NULL (an index that keeps no panel copy): the exact-scan fallback and FAISS's small-batch L2 form then
+    // read the row-major copy
+    if (!sqnorm_dev || !rowmajor_dev || !bf16_dev || !xstats_dev || !queries_dev || !D_dev || !I_dev || !ws_dev)
         return MQ_EINVAL;
     if (N <= 0 || d <= 0 || nq < 0 || k <= 0) return MQ_EINVAL;
     if (k > MQ_KNN_MAX_K) return MQ_EUNSUPPORTED;
@@ -1041,7 +1163,8 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     if (ws_bytes < g.total) return MQ_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (l2 && nq < MQ_KNN_L2_DIRECT_BELOW)
-        return knn_search_l2_direct(packed_dev, N, d, queries_dev, nq, k, l2norm_queries, id_offset, D_dev, I_dev, ws_dev, g, st);
+        return knn_search_l2_direct(packed_dev, rowmajor_dev, N, d, queries_dev, nq, k, l2norm_queries, id_offset, D_dev, I_dev, ws_dev,
+                                    g, st);
     char* ws = (char*)ws_dev;
     float* Qp = (float*)(ws + g.off_qp);
     float* qn = (float*)(ws + g.off_qn);
@@ -1122,9 +1245,25 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
             MQ_HIP(hipGetLastError());
         }
         ScanArgs a;
-        a.Xp = packed_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = pools;
+        a.Xp = packed_dev ? packed_dev : rowmajor_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = pools; a.d = d;
         a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = nullptr; a.only = ovf;
-        if (l2) {
+        const dim3 fgrid((unsigned)(g.nqt * g.S)), fblock(1024);
+        if (!packed_dev) {
+            if (l2) {
+                MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<MQ_METRIC_L2, true>);
+                hipLaunchKernelGGL((knn_scan_kernel<MQ_METRIC_L2, true>), fgrid, fblock, LDS_TOTAL, st, a);
+            } else {
+                MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<MQ_METRIC_IP, true>);
+                hipLaunchKernelGGL((knn_scan_kernel<MQ_METRIC_IP, true>), fgrid, fblock, LDS_TOTAL, st, a);
+            }
+            MQ_HIP(hipGetLastError());
+            if (l2)
+                hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(128), 0, st, pools, nq, g.S, k,
+                                   (long long)id_offset, D_dev, (long long*)I_dev, (const int*)ovf);
+            else
+                hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, st, pools, nq, g.S, k,
+                                   (long long)id_offset, D_dev, (long long*)I_dev, (const int*)ovf);
+        } else if (l2) {
             MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<MQ_METRIC_L2>);
             hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_L2>, dim3((unsigned)(g.nqt * g.S)), dim3(1024), LDS_TOTAL, st, a);
             MQ_HIP(hipGetLastError());

@@ -109,7 +109,8 @@ class MI355XFlatIndex(BaseIndex):
     """Exact IP / L2 index over an fp32 matrix held in HBM in the kernel's panel layout."""
 
     def __init__(self, device: Optional[Union[int, list]] = None, string_factory: Optional[str] = None,
-                 metric_type: Optional[int] = None, custom_index=None, id_offset: int = 0, screen: Optional[bool] = None):
+                 metric_type: Optional[int] = None, custom_index=None, id_offset: int = 0, screen: Optional[bool] = None,
+                 keep_panel: Optional[bool] = None):
         if custom_index is not None:
             raise ValueError("custom_index is a FAISS object; MI355XFlatIndex builds its own index")
         self.device = device
@@ -132,6 +133,13 @@ class MI355XFlatIndex(BaseIndex):
         if screen is None:
             screen = os.environ.get("MQ_KNN_SCREEN", "1") != "0"
         self.screen = bool(screen)  # both metrics: the L2 screen ranks by q.x - ||x||^2/2 (two extra bf16 columns)
+        # A screened index holds the fp32 rows row-major (re-scoring) and a bf16 copy (screening): 1.5x the matrix.  The
+        # panel-layout fp32 copy only feeds the exact scan -- the fallback of query tiles whose screening buffers overflow --
+        # which can read the row-major copy instead (same MFMA sequence, slower operand path), so it is not kept unless
+        # asked for (keep_panel=True / MQ_KNN_KEEP_PANEL=1: 2.5x the matrix, full-speed fallback).
+        if keep_panel is None:
+            keep_panel = (not self.screen) or os.environ.get("MQ_KNN_KEEP_PANEL", "0") == "1"
+        self.keep_panel = bool(keep_panel) or not self.screen
         self._rowmajor = None  # torch.float32 [capacity, d] (screened path only)
         self._bf16 = None      # torch.uint8 bf16 copy
         self._xmax2 = None     # torch.float32 [3]: max ||x||^2, max ||xc - bf16(xc)||^2, max ||xc||^2 (kept by mq_knn_screen_prepare)
@@ -160,11 +168,12 @@ class MI355XFlatIndex(BaseIndex):
             # appending without a known total: grow by 1.5x so that repeated add() calls copy O(N) rows overall
             cap = int(lib.mq_padded_rows(max(n_total, self._capacity + self._capacity // 2)))
         dpad = int(lib.mq_padded_dim(self.d))
-        new_packed = torch.zeros(cap * dpad, dtype=torch.float32, device=self._torch_device)
+        new_packed = torch.zeros(cap * dpad, dtype=torch.float32, device=self._torch_device) if self.keep_panel else None
         new_sqnorm = torch.zeros(cap, dtype=torch.float32, device=self._torch_device)
-        if self._packed is not None and self.ntotal > 0:
+        if self._sqnorm is not None and self.ntotal > 0:
             # panels are contiguous: the old buffer is a prefix of the new one
-            new_packed[: self._packed.numel()].copy_(self._packed)
+            if self.keep_panel:
+                new_packed[: self._packed.numel()].copy_(self._packed)
             new_sqnorm[: self._sqnorm.numel()].copy_(self._sqnorm)
         if self.screen:
             new_rm = torch.empty((cap, self.d), dtype=torch.float32, device=self._torch_device)
@@ -195,6 +204,8 @@ class MI355XFlatIndex(BaseIndex):
             return
         self._ensure_capacity(max(self.ntotal + n, total_hint or 0), d, exact=bool(total_hint))
         stream = torch.cuda.current_stream(self._torch_device).cuda_stream
+        if not self.keep_panel:
+            return self._add_rows_only(vecs, n, stream)
         first = 0
         if self.ntotal % 64 != 0:
             # finish the open panel: stored tail rows (already transformed) + the first new rows (transformed here)
@@ -245,6 +256,33 @@ class MI355XFlatIndex(BaseIndex):
                 self.ntotal += dev.shape[0]
                 # `dev` must outlive the kernel: synchronise before it is released
                 torch.cuda.current_stream(self._torch_device).synchronize()
+
+    def _upload(self, part):
+        import torch
+        if isinstance(part, torch.Tensor):
+            return part.to(device=self._torch_device, dtype=torch.float32).contiguous()
+        part = np.ascontiguousarray(part)
+        if not part.flags.writeable:
+            part = part.copy()
+        return torch.from_numpy(part).to(self._torch_device, non_blocking=False)
+
+    def _add_rows_only(self, vecs, n, stream):
+        """add() of a screened index without a panel copy: the rows go straight to the row-major store (any row offset, no
+        open-panel bookkeeping) with the "L2norm," transform and ||x||^2 of the packing kernel, then to the bf16 copy."""
+        import torch
+        lib = _lib.load()
+        with torch.cuda.device(self._torch_device):
+            for i in range(0, n, _UPLOAD_ROWS):
+                dev = self._upload(vecs[i:i + _UPLOAD_ROWS])
+                if self._xmax2 is None:
+                    self._xmax2 = torch.zeros(3, dtype=torch.float32, device=self._torch_device)
+                    self._center = self._choose_center(dev)
+                _lib.check(lib.mq_knn_screen_add_rows_f32(
+                    dev.data_ptr(), dev.shape[0], self.d, self.ntotal, int(self.do_l2norm), self.metric_type, self._capacity,
+                    self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(), self._xmax2.data_ptr(),
+                    self._center.data_ptr() if self._center is not None else None, stream), "mq_knn_screen_add_rows_f32")
+                self.ntotal += dev.shape[0]
+                torch.cuda.current_stream(self._torch_device).synchronize()  # `dev` must outlive the kernels
 
     def _choose_center(self, first_rows):
         """Centre of the bf16 screening copy: the mean of the first rows added (as stored, i.e. after "L2norm,").  Any
@@ -302,7 +340,7 @@ class MI355XFlatIndex(BaseIndex):
         ``out`` = (D, I) preallocated contiguous CUDA tensors to write into (e.g. views of a shard record)."""
         import torch
         lib = _lib.load()
-        if self._packed is None:
+        if self._sqnorm is None:
             raise ValueError("the index is empty: call add_vectors first")
         if queries.dim() != 2 or queries.shape[1] != self.d:
             raise ValueError(f"Shape of query must be 2D with {self.d} columns, got {tuple(queries.shape)}")
@@ -334,7 +372,7 @@ class MI355XFlatIndex(BaseIndex):
                 Dq, Iq = D[s:e], I[s:e]
                 if self.screen:
                     _lib.check(lib.mq_knn_search_screened_f32(
-                        self._packed.data_ptr(), self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(),
+                        self._packed.data_ptr() if self._packed is not None else None, self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(),
                         self._xmax2.data_ptr(), self.ntotal, self.d, q.data_ptr(), q.shape[0], k, self.metric_type,
                         int(self.do_l2norm),
                         self.id_offset, Dq.data_ptr(), Iq.data_ptr(), ws.data_ptr(), ws.numel(), stream, None, None),
@@ -413,6 +451,8 @@ class MI355XFlatIndex(BaseIndex):
         import torch
         lib = _lib.load()
         n = self.ntotal - start if n is None else n
+        if self._packed is None:
+            return self._rowmajor[start:start + n].cpu().numpy()
         out = torch.empty((n, self.d), dtype=torch.float32, device=self._torch_device)
         stream = torch.cuda.current_stream(self._torch_device).cuda_stream
         with torch.cuda.device(self._torch_device):
