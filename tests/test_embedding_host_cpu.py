@@ -95,6 +95,27 @@ def test_expand_query_variants():
     assert expand_query(b, key="input", kb=kb, run=Run(), tokenizer=_Tok()) == ["q1 [SEP] One", "q2 [SEP] Zero"]
 
 
+def test_query_expansion_from_a_run_file_through_dataset_embed(tmp_path):
+    """meerqat/ir/embedding.py:262-263 (`run = Run.from_file(run)`): the JSON run file the search wrote, read without ranx,
+    best document first whatever the file's order; the top-1 document's name is appended to the question."""
+    import json
+    from datasets import Dataset, load_from_disk
+    from viquae_amd.ir.embedding import dataset_embed, load_run
+    run_path = tmp_path / "run.json"
+    run_path.write_text(json.dumps({"a": {"0": 0.1, "1": 0.9}, "b": {"0": 0.7, "1": 0.7}}))
+    run = load_run(str(run_path))
+    assert list(run.run["a"]) == ["1", "0"] and list(run.run["b"]) == ["0", "1"]          # sorted, ties keep the file's order
+    with pytest.raises(NotImplementedError):
+        load_run(str(tmp_path / "run.trec"))
+    Dataset.from_dict({"input": ["q1", "q2"], "id": ["a", "b"]}).save_to_disk(str(tmp_path / "ds"))
+    kb = [{"wikidata_label": "Zero"}, {"wikidata_label": "One"}]
+    tok = _Tok()
+    dataset_embed(str(tmp_path / "ds"), output_path=str(tmp_path / "out"), run=str(run_path), model=_Model(), tokenizer=tok,
+                  key="input", kb=kb, call="get_text_features", save_as="emb", map_kwargs={"batch_size": 8})
+    assert tok.seen == ["q1 [SEP] One", "q2 [SEP] Zero"]
+    assert np.asarray(load_from_disk(str(tmp_path / "out"))["emb"]).shape == (2, 4)
+
+
 def test_image_embed_handles_unreadable_images(tmp_path, monkeypatch):
     from PIL import Image
     from viquae_amd.data import loading

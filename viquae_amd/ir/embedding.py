@@ -123,6 +123,27 @@ def _model_device(model):
     return None
 
 
+class _JsonRun:
+    """What ``expand_query`` reads of a ranx ``Run``: ``.run[q_id]`` iterates the documents best first."""
+
+    def __init__(self, run):
+        self.run = {q: dict(sorted(docs.items(), key=lambda kv: -kv[1])) for q, docs in run.items()}
+
+
+def load_run(path):
+    """``ranx.Run.from_file`` (meerqat/ir/embedding.py:262-263) when ranx is installed; otherwise the JSON run file
+    ({q_id: {doc_id: score}}, what the reference's search writes) read directly, each query sorted by descending score
+    like ranx does (stable: equal scores keep the file's order)."""
+    try:
+        from ranx import Run
+    except ImportError:
+        if not str(path).endswith(".json"):
+            raise NotImplementedError(f"{path}: only JSON run files can be read without ranx")
+        with open(path, "rt") as file:
+            return _JsonRun(json.load(file))
+    return Run.from_file(path)
+
+
 def dataset_embed(dataset_path, map_kwargs={}, output_path=None, keep_columns=None, run=None, qe_predictions=None,
                   qe_predictions_key=None, **fn_kwargs):
     """load_from_disk -> Dataset.map(embed, batched=True) -> save_to_disk."""
@@ -135,7 +156,7 @@ def dataset_embed(dataset_path, map_kwargs={}, output_path=None, keep_columns=No
         keep_columns = set(keep_columns)
         dataset = dataset.remove_columns([c for c in dataset.column_names if c not in keep_columns])
     if run is not None:
-        raise NotImplementedError("query expansion from a ranx Run needs ranx (not installed); pass qe_predictions instead")
+        run = load_run(run)
     if qe_predictions is not None:
         assert qe_predictions_key is not None
         with open(qe_predictions, "rt") as file:
