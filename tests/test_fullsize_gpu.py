@@ -166,3 +166,49 @@ def test_config3_search_half_1p5M_x_512_l2norm_flat():
     assert (I1 >= 0).all() and (I1 < N).all()
     srt = I1.sort(dim=1).values
     assert (srt[:, 1:] != srt[:, :-1]).all()
+
+
+@pytest.mark.parametrize("amp", [128, 2])
+def test_config1_integer_lattice_variants_against_torch_mm(amp):
+    """SURVEY 8(d) config 1, second variant: a 1.5M x 768 KB of integers.  Every fp32 summation order is exact on such data
+    (|score| <= 768 * 128^2 < 2^24), so a plain torch matmul is an INDEPENDENT oracle at full size: the scores must equal its
+    top-100 values bit for bit and the ids must follow FAISS's rule (every row above the k-th score, then the LOWEST ids among
+    the rows that tie with it).  amp = 128: few ties, the bf16 screen is exact on these integers and does all the work;
+    amp = 2 with queries that have 3 non-zero components (|score| <= 12): ~12,000 rows share the best score of a query,
+    every query tile overflows and is recomputed by the exact scan from the row-major rows (this index keeps no panel copy)."""
+    import torch
+    from viquae_amd.index import MI355XFlatIndex
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(7 + amp)
+    idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
+    X = torch.empty((N, D), dtype=torch.float32, device=dev)
+    for s in range(0, N, 1 << 16):
+        n = min(1 << 16, N - s)
+        X[s:s + n] = torch.randint(-amp, amp + 1, (n, D), generator=g, device=dev).float()
+        idx.add(X[s:s + n], total_hint=N)
+    assert idx._packed is None
+    Q = torch.randint(-amp, amp + 1, (NQ, D), generator=g, device=dev).float()
+    if amp == 2:
+        keep = torch.zeros((NQ, D), device=dev)
+        keep.scatter_(1, torch.rand((NQ, D), generator=g, device=dev).topk(3, dim=1).indices, 1.0)
+        Q = torch.where(Q == 0, torch.ones_like(Q), Q) * keep
+    Dv, Iv = idx.search_device(Q, K)
+    flagged = idx.screen_stats(NQ, K)[0]
+    assert flagged == (0 if amp == 128 else NQ // 256)
+    for q0 in list(range(0, NQ, 1024)) + [NQ - 256]:          # five blocks of 256 queries, one per 1024 + the last tile
+        S = Q[q0:q0 + 256] @ X.T                               # exact: integers
+        top = S.topk(K, dim=1).values
+        Db, Ib = Dv[q0:q0 + 256], Iv[q0:q0 + 256]
+        assert torch.equal(top, Db)
+        assert torch.equal(S.gather(1, Ib), Db)                # the returned ids carry the returned scores
+        kth = Db[:, -1:]
+        need = K - (S > kth).sum(dim=1, keepdim=True)          # slots left for rows that tie with the k-th score
+        tie = S == kth
+        lowest = tie & (tie.cumsum(dim=1) <= need)             # the `need` lowest ids among them
+        got = torch.zeros_like(tie)
+        got.scatter_(1, Ib, Db == kth)
+        assert torch.equal(got, lowest)
+        srt = torch.where(Db[:, 1:] == Db[:, :-1], Ib[:, 1:] - Ib[:, :-1], torch.ones_like(Ib[:, 1:]))
+        assert (srt > 0).all()                                 # equal scores are listed by ascending id
+        del S, tie, lowest, got
