@@ -75,6 +75,35 @@ def build_shard(idx, rows, seed, device):
         idx.add(torch.randn((n, DIM), generator=g, device=device, dtype=torch.float32), total_hint=rows)
 
 
+def mfma_ceiling(device, stream, achieved_tflops):
+    """What the bf16 matrix pipe of THIS box sustains with no operand movement at all (csrc/diag.hip: 16 waves per CU looping
+    over v_mfma_f32_32x32x16_bf16 on register operands), zero operands vs N(0,1)-like random ones: the power management lowers
+    the clock on random data, so `peak` (the nominal 2.5 PFLOP/s) is not reachable by any kernel on the bench's operands.
+    Measured outside the timed region; `frac` above stays relative to the nominal peak."""
+    import torch
+    from viquae_amd import _lib
+    lib = _lib.load()
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    out = torch.empty(cus * 1024, dtype=torch.float32, device=device)
+    iters = 8000
+    flops = 2.0 * 32 * 32 * 16 * 16 * iters * 16 * cus
+    res = {}
+    for name, rnd in (("zero_operands", 0), ("random_operands", 1)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        times = []
+        for rep in range(3):  # the first launch settles the clocks
+            e0.record(stream)
+            _lib.check(lib.mq_diag_mfma_bf16_loop(iters, rnd, cus, out.data_ptr(), stream.cuda_stream), "mq_diag_mfma_bf16_loop")
+            e1.record(stream)
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1))
+        res[name + "_tflops"] = round(flops / (min(times[1:]) * 1e-3) / 1e12, 1)
+    res["frac_of_random_operand_ceiling"] = round(achieved_tflops / res["random_operands_tflops"], 4)
+    res["what"] = ("mq_diag_mfma_bf16_loop: register-only bf16 MFMA loop on all CUs (no LDS, no HBM); the random-operand figure is the "
+                   "ceiling of any bf16 GEMM-shaped kernel on this data under the chip's power limit")
+    return res
+
+
 def cpu_baseline(idx, Q, seconds):
     """CPU legs on the GPU box's host cores, each on a BOUNDED sample of the same workload (ALL queries of the step, so
     every core has work, against the first `rows` KB rows sized by a calibration run), scaled by rows to the metric's
@@ -446,6 +475,11 @@ def main():
                 "traffic_from_profile": traffic[1],
             },
         }
+        if world == 1 and mode == "screened":
+            try:
+                rec["roofline"]["sustained_mfma_ceiling"] = mfma_ceiling(device, stream, achieved)
+            except Exception as e:  # a diagnostic, never a reason to lose the line
+                rec["roofline"]["sustained_mfma_ceiling"] = {"error": repr(e)}
         if multi:
             rec["config"]["rccl"] = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
                                      "launched_by": "torch.distributed.run"}

@@ -337,6 +337,15 @@ int mq_image_preprocess_u8(const uint8_t *src_dev, const int64_t *geom_dev, int 
                            int crop_w, int filter, int flags, double rescale_factor, const float *mean3_host,
                            const float *std3_host, float *out_dev, void *ws_dev, size_t ws_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Measurement aid (csrc/diag.hip; no reference counterpart, not on the product path): `workgroups` x 16 waves loop over
+ * `iters` x 16 v_mfma_f32_32x32x16_bf16 on register operands (zero, or N(0,1)-like random when random_operands != 0), no
+ * memory traffic: 2*32*32*16 * 16 * iters * 16 * workgroups FLOP per launch.  bench.py times it for the matrix-pipe rate
+ * this chip SUSTAINS on such operands (its power management lowers the clock on random data).  out_dev: workgroups * 1024
+ * floats (keeps the accumulators observable).
+ * ------------------------------------------------------------------------------------------- */
+int mq_diag_mfma_bf16_loop(int iters, int random_operands, int workgroups, float *out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

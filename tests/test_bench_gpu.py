@@ -34,6 +34,24 @@ def test_single_gpu_line_with_both_exact_paths_and_cpu_baseline():
     cpu = rec["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= cpu.keys() and cpu["kind"] == "port" and cpu["value"] > 0
     assert set(cpu["legs"]) == {"fmaf_chain_oracle", "blas_sgemm_topk"}
+    ceil = rec["roofline"]["sustained_mfma_ceiling"]          # the register-only MFMA loop timed on the same box
+    assert 1000 < ceil["random_operands_tflops"] <= ceil["zero_operands_tflops"] * 1.02 < 2700
+    assert 0 < ceil["frac_of_random_operand_ceiling"] < 1
+
+
+def test_diag_mfma_loop_through_the_c_abi():
+    import torch
+    from viquae_amd import _lib
+    lib = _lib.load()
+    out = torch.full((2 * 1024,), 7.0, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.mq_diag_mfma_bf16_loop(3, 0, 2, out.data_ptr(), s), "mq_diag_mfma_bf16_loop")
+    torch.cuda.synchronize()
+    assert (out == 0).all()                                   # zero operands
+    _lib.check(lib.mq_diag_mfma_bf16_loop(3, 1, 2, out.data_ptr(), s), "mq_diag_mfma_bf16_loop")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and (out != 0).any()
+    assert lib.mq_diag_mfma_bf16_loop(3, 1, 0, out.data_ptr(), s) == -1      # MQ_EINVAL
 
 
 def test_multi_rank_path_through_rccl_world_1():
