@@ -785,6 +785,9 @@ __global__ __launch_bounds__(128) void shard_merge_kernel(const float* __restric
 #ifdef MQ_PROBE8
 #include "knn_probe8.inc"
 #endif
+#if defined(MQ_PROBE2X8) || defined(MQ_ABL_SYNTHEPI)
+#include "knn_probe2x8.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1215,7 +1218,10 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         a.dbg = dbg_ptr();
         a.N = N; a.dp = dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx_screen; a.nchunks = g.nchunks;
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
-#ifdef MQ_PROBE8
+#if defined(MQ_PROBE2X8)
+        MQ_DYNAMIC_LDS(P2_LDS, screen_probe2x8_kernel);
+        hipLaunchKernelGGL(screen_probe2x8_kernel, dim3((unsigned)(g.nqt * g.S * 2)), dim3(512), P2_LDS, st, a);
+#elif defined(MQ_PROBE8)
         MQ_DYNAMIC_LDS(S_LDS_TOTAL, screen_probe8_kernel);
         hipLaunchKernelGGL(screen_probe8_kernel, dim3((unsigned)(g.nqt * g.S)), dim3(512), S_LDS_TOTAL, st, a);
 #else
