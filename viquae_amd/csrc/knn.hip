@@ -874,9 +874,10 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
             if (want > 0) { if (q == want) g.qpx = g.qpx_screen = q; continue; }
             // default: the largest Q working set that still leaves half of L2 to the KB stream (the screening scan's
             // queries are bf16: twice as many tiles fit, and every XCD group then streams a smaller part of the shard:
-            // 4 tiles per XCD instead of 2 took 2.7 % off the 4096-query scan)
+            // 4 tiles per XCD instead of 2 took 2.7 % off the 4096-query scan; 8 tiles -- 3.1 MB of bf16 queries at d = 768, the
+            // shard then crosses the fabric twice instead of four times -- another 0.8 %: 8.27 -> 8.20 ms; 16 tiles 8.52)
             if ((size_t)q * TQ * g.dpad * 4 <= (size_t)2 << 20 || g.qpx == 0) g.qpx = q;
-            if ((size_t)q * TQ * g.dpad * 2 <= (size_t)2 << 20 || g.qpx_screen == 0) g.qpx_screen = q;
+            if ((size_t)q * TQ * screen_dp(d, MQ_METRIC_IP) * 2 <= (size_t)13 << 18 || g.qpx_screen == 0) g.qpx_screen = q;
         }
     }
     size_t o = 0;
