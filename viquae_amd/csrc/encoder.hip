@@ -390,37 +390,60 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
     continue;
 #endif
     const int m0 = cur.m0, n0 = cur.n0;
-    const int nb0 = n0 + 64 * wc + i, nb1 = nb0 + 32;
-    float bias0 = 0.f, bias1 = 0.f;
-    if (EPI != EPI_NONE) {
-        if (nb0 < N) bias0 = bias[nb0];
-        if (nb1 < N) bias1 = bias[nb1];
-    }
-    const int mbase = m0 + 64 * wr + 4 * kg;
+    // the C-store epilogue, instantiated twice: a tile that lies wholly inside C (every tile of the encoder shapes) carries no
+    // bound tests and no exec-mask juggling around its 64 stores per lane
+    auto epilogue = [&](auto full_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const int nb0 = n0 + 64 * wc + i, nb1 = nb0 + 32;
+        float bias0 = 0.f, bias1 = 0.f;
+        if (EPI != EPI_NONE) {
+            if (FULL || nb0 < N) bias0 = bias[nb0];
+            if (FULL || nb1 < N) bias1 = bias[nb1];
+        }
+        const int mbase = m0 + 64 * wr + 4 * kg;
+        // EPI_BIAS_RESIDUAL: the residual of four accumulator rows (16 values per lane) is requested in one burst, behind a
+        // scheduling barrier -- left alone, the compiler loads two values, waits, stores, loads two more (the fragment
+        // registers are free here, but its scheduler keeps the pressure low), and the wave pays the round trip 32 times
+        float rres[16];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int mr0 = mbase + (reg & 3) + 8 * (reg >> 2), mr1 = mr0 + 32;
-        float v00 = acc00[reg] + bias0, v01 = acc01[reg] + bias1, v10 = acc10[reg] + bias0, v11 = acc11[reg] + bias1;
-        if (EPI == EPI_BIAS_GELU) { v00 = gelu_erf(v00); v01 = gelu_erf(v01); v10 = gelu_erf(v10); v11 = gelu_erf(v11); }
-        if (EPI == EPI_BIAS_QUICKGELU) { v00 = quick_gelu(v00); v01 = quick_gelu(v01); v10 = quick_gelu(v10); v11 = quick_gelu(v11); }
-        if (EPI == EPI_BIAS_RESIDUAL) {
-            if (mr0 < M && nb0 < N) v00 += R[(size_t)mr0 * N + nb0];
-            if (mr0 < M && nb1 < N) v01 += R[(size_t)mr0 * N + nb1];
-            if (mr1 < M && nb0 < N) v10 += R[(size_t)mr1 * N + nb0];
-            if (mr1 < M && nb1 < N) v11 += R[(size_t)mr1 * N + nb1];
+        for (int reg = 0; reg < 16; ++reg) {
+            const int mr0 = mbase + (reg & 3) + 8 * (reg >> 2), mr1 = mr0 + 32;
+            const bool in00 = FULL || (mr0 < M && nb0 < N), in01 = FULL || (mr0 < M && nb1 < N);
+            const bool in10 = FULL || (mr1 < M && nb0 < N), in11 = FULL || (mr1 < M && nb1 < N);
+            if (EPI == EPI_BIAS_RESIDUAL && (reg & 3) == 0) {  // (a second group in flight ahead of the stores spills: slower)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ma = mbase + u + 8 * (reg >> 2), mb = ma + 32;
+                    rres[4 * u + 0] = (FULL || (ma < M && nb0 < N)) ? R[(size_t)ma * N + nb0] : 0.f;
+                    rres[4 * u + 1] = (FULL || (ma < M && nb1 < N)) ? R[(size_t)ma * N + nb1] : 0.f;
+                    rres[4 * u + 2] = (FULL || (mb < M && nb0 < N)) ? R[(size_t)mb * N + nb0] : 0.f;
+                    rres[4 * u + 3] = (FULL || (mb < M && nb1 < N)) ? R[(size_t)mb * N + nb1] : 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float v00 = acc00[reg] + bias0, v01 = acc01[reg] + bias1, v10 = acc10[reg] + bias0, v11 = acc11[reg] + bias1;
+            if (EPI == EPI_BIAS_GELU) { v00 = gelu_erf(v00); v01 = gelu_erf(v01); v10 = gelu_erf(v10); v11 = gelu_erf(v11); }
+            if (EPI == EPI_BIAS_QUICKGELU) { v00 = quick_gelu(v00); v01 = quick_gelu(v01); v10 = quick_gelu(v10); v11 = quick_gelu(v11); }
+            if (EPI == EPI_BIAS_RESIDUAL) {
+                v00 += rres[4 * (reg & 3) + 0];
+                v01 += rres[4 * (reg & 3) + 1];
+                v10 += rres[4 * (reg & 3) + 2];
+                v11 += rres[4 * (reg & 3) + 3];
+            }
+            if (SPLIT_OUT) {  // N is even (checked by the host): a pair of columns is in or out together
+                store_split_pair(v00, in00, Ch, Cl, (size_t)mr0 * N + (nb0 & ~1), lane);
+                store_split_pair(v01, in01, Ch, Cl, (size_t)mr0 * N + (nb1 & ~1), lane);
+                store_split_pair(v10, in10, Ch, Cl, (size_t)mr1 * N + (nb0 & ~1), lane);
+                store_split_pair(v11, in11, Ch, Cl, (size_t)mr1 * N + (nb1 & ~1), lane);
+            } else {
+                if (in00) C[(size_t)mr0 * N + nb0] = v00;
+                if (in01) C[(size_t)mr0 * N + nb1] = v01;
+                if (in10) C[(size_t)mr1 * N + nb0] = v10;
+                if (in11) C[(size_t)mr1 * N + nb1] = v11;
+            }
         }
-        if (SPLIT_OUT) {  // N is even (checked by the host): a pair of columns is in or out together
-            store_split_pair(v00, mr0 < M && nb0 < N, Ch, Cl, (size_t)mr0 * N + (nb0 & ~1), lane);
-            store_split_pair(v01, mr0 < M && nb1 < N, Ch, Cl, (size_t)mr0 * N + (nb1 & ~1), lane);
-            store_split_pair(v10, mr1 < M && nb0 < N, Ch, Cl, (size_t)mr1 * N + (nb0 & ~1), lane);
-            store_split_pair(v11, mr1 < M && nb1 < N, Ch, Cl, (size_t)mr1 * N + (nb1 & ~1), lane);
-        } else {
-            if (mr0 < M && nb0 < N) C[(size_t)mr0 * N + nb0] = v00;
-            if (mr0 < M && nb1 < N) C[(size_t)mr0 * N + nb1] = v01;
-            if (mr1 < M && nb0 < N) C[(size_t)mr1 * N + nb0] = v10;
-            if (mr1 < M && nb1 < N) C[(size_t)mr1 * N + nb1] = v11;
-        }
-    }
+    };
+    if (m0 + GT <= M && n0 + GT <= N) epilogue(std::true_type{}); else epilogue(std::false_type{});
     if (next >= ntiles) break;
     tile = next;
     cur = nxt;
