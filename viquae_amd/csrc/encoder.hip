@@ -234,6 +234,21 @@ __device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8_
     }
 }
 
+// four values -> their packed (hi, lo) bf16 quadruples (8 bytes each), the arithmetic of split8()
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4(const float x0, const float x1, const float x2, const float x3, uint2& hi, uint2& lo) {
+    const float x[4] = {x0, x1, x2, x3};
+    bf16x4_t h4, l4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h = (__bf16)x[e];
+        h4[e] = h;
+        l4[e] = (__bf16)(x[e] - (float)h);
+    }
+    hi = __builtin_bit_cast(uint2, h4);
+    lo = __builtin_bit_cast(uint2, l4);
+}
+
 __global__ void split_bf16_kernel(const float* __restrict__ src, long long n, unsigned short* __restrict__ hi,
                                   unsigned short* __restrict__ lo) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -891,31 +906,45 @@ __global__ __launch_bounds__(WIDE ? 512 : 256) void attention_x3_kernel(const fl
     }
 
     // key blocks of NK keys with the online softmax (see attention_mfma_kernel): one pass when L <= NK
+    const float scale2 = scale * 1.4426950408889634f;  // softmax(x) = 2^(x log2 e - max) / sum: one multiply folded into the scale
     float m_run = -INFINITY, den = 0.f;
     f32x16 oacc0 = {0}, oacc1 = {0};
     for (int kb0 = 0; kb0 < (MULTI ? L : 1); kb0 += NK) {  // !MULTI: exactly one pass, known at compile time
     if (kb0) __syncthreads();  // the previous block's K / V are dead
-    for (int e = tid; e < nt_live * 32 * (DH / 4); e += nthr) {
-        const int j = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
-        float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
-        if (kb0 + j < L) {
-            kf = *reinterpret_cast<const float4*>(base + (size_t)(kb0 + j) * ld + H + c4);
-            vf = *reinterpret_cast<const float4*>(base + (size_t)(kb0 + j) * ld + 2 * H + c4);
-        }
-        // K row j: four consecutive d -> 8 bytes inside chunk c4 / 8
-        const unsigned k01 = split_bits(kf.x), k23 = split_bits(kf.y), k45 = split_bits(kf.z), k67 = split_bits(kf.w);
-        const int koff = j * 128 + (((c4 >> 3) ^ ((j >> 1) & 7)) * 16) + (c4 & 7) * 2;
-        *reinterpret_cast<uint2*>(Kh + koff) = make_uint2((k01 & 0xFFFFu) | (k23 << 16), (k45 & 0xFFFFu) | (k67 << 16));
-        *reinterpret_cast<uint2*>(Kl + koff) = make_uint2((k01 >> 16) | (k23 & 0xFFFF0000u), (k45 >> 16) | (k67 & 0xFFFF0000u));
-        // V^T rows c4 .. c4+3, column j
-        const float vv[4] = {vf.x, vf.y, vf.z, vf.w};
+    // K / V staging, one item = 4 consecutive keys x 4 consecutive d: K rows leave as 8-byte (hi, lo) pieces as before; V^T
+    // gets, for each of the 4 d, the 4 keys as ONE 8-byte piece per (hi, lo) instead of four 2-byte stores (keys 4 kq .. + 3
+    // share a 16-byte chunk), and the conversions run on packed pairs
+    for (int e = tid; e < nt_live * 8 * (DH / 4); e += nthr) {
+        const int kq = e / (DH / 4), c4 = (e % (DH / 4)) * 4, j0 = 4 * kq;
+        float4 kf[4], vf[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int u = 0; u < 4; ++u) {
+            kf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vf[u] = kf[u];
+            if (kb0 + j0 + u < L) {
+                kf[u] = *reinterpret_cast<const float4*>(base + (size_t)(kb0 + j0 + u) * ld + H + c4);
+                vf[u] = *reinterpret_cast<const float4*>(base + (size_t)(kb0 + j0 + u) * ld + 2 * H + c4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // K row j0 + u: four consecutive d -> 8 bytes inside chunk c4 / 8
+            const int j = j0 + u;
+            uint2 h2, l2;
+            split4(kf[u].x, kf[u].y, kf[u].z, kf[u].w, h2, l2);
+            const int koff = j * 128 + (((c4 >> 3) ^ ((j >> 1) & 7)) * 16) + (c4 & 7) * 2;
+            *reinterpret_cast<uint2*>(Kh + koff) = h2;
+            *reinterpret_cast<uint2*>(Kl + koff) = l2;
+        }
+        const float vv[4][4] = {{vf[0].x, vf[1].x, vf[2].x, vf[3].x}, {vf[0].y, vf[1].y, vf[2].y, vf[3].y},
+                                {vf[0].z, vf[1].z, vf[2].z, vf[3].z}, {vf[0].w, vf[1].w, vf[2].w, vf[3].w}};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {  // V^T row c4 + jj, columns j0 .. j0 + 3
             const int d = c4 + jj;
-            const unsigned vb = split_bits(vv[jj]);
-            const int voff = d * (NK * 2) + (((j >> 3) ^ (d & (NCH - 1))) * 16) + (j & 7) * 2;
-            *reinterpret_cast<unsigned short*>(Vth + voff) = (unsigned short)(vb & 0xFFFFu);
-            *reinterpret_cast<unsigned short*>(Vtl + voff) = (unsigned short)(vb >> 16);
+            uint2 h2, l2;
+            split4(vv[jj][0], vv[jj][1], vv[jj][2], vv[jj][3], h2, l2);
+            const int voff = d * (NK * 2) + (((j0 >> 3) ^ (d & (NCH - 1))) * 16) + (j0 & 7) * 2;
+            *reinterpret_cast<uint2*>(Vth + voff) = h2;
+            *reinterpret_cast<uint2*>(Vtl + voff) = l2;
         }
     }
     for (int j = tid; j < NK; j += nthr)
@@ -948,7 +977,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256) void attention_x3_kernel(const fl
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int key = 32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
-            float sv = sacc[t][reg] * scale + addm[key];
+            float sv = sacc[t][reg] * scale2 + addm[key];   // scores in units of log2 e: the exponentials below are v_exp_f32
             if (causal && kb0 + key > qrow) sv = -INFINITY;
             sacc[t][reg] = sv;
             mx = fmaxf(mx, sv);
@@ -961,14 +990,14 @@ __global__ __launch_bounds__(WIDE ? 512 : 256) void attention_x3_kernel(const fl
         if (t >= nt_live) break;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const float p = (sacc[t][reg] == -INFINITY) ? 0.f : expf(sacc[t][reg] - mx);
+            const float p = (sacc[t][reg] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(sacc[t][reg] - mx);
             sacc[t][reg] = p;
             bsum += p;
         }
     }
     bsum += __shfl_xor(bsum, 32);
     if (kb0) {  // rescale what the earlier blocks accumulated to the new maximum
-        const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - mx);
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - mx);
         den *= alpha;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) { oacc0[reg] *= alpha; oacc1[reg] *= alpha; }
@@ -986,11 +1015,13 @@ __global__ __launch_bounds__(WIDE ? 512 : 256) void attention_x3_kernel(const fl
             float p8[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float lo_half = sacc[t][8 * g + r], hi_half = sacc[t][8 * g + 4 + r];
-                const float send = kg ? lo_half : hi_half;          // what the partner lane needs from me
-                const float recv = __shfl_xor(send, 32);
-                p8[r] = kg ? recv : lo_half;                        // keys +0..3: held by the lower lane
-                p8[4 + r] = kg ? hi_half : recv;                    // keys +4..7: held by the upper lane
+                // keys +0..3 are held by the lower lane (its registers 8g + r), keys +4..7 by the upper lane (8g + 4 + r):
+                // v_permlane32_swap exchanges the upper half of the first operand with the lower half of the second, which is
+                // exactly this regrouping (one VALU instruction instead of select + ds_bpermute + two selects)
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sacc[t][8 * g + r]),
+                                                                 __float_as_uint(sacc[t][8 * g + 4 + r]), false, false);
+                p8[r] = __uint_as_float(sw[0]);
+                p8[4 + r] = __uint_as_float(sw[1]);
             }
             bf16x8_t ph, pl;
             split8(make_float4(p8[0], p8[1], p8[2], p8[3]), make_float4(p8[4], p8[5], p8[6], p8[7]), ph, pl);
