@@ -633,22 +633,28 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
             const float t0 = tau[q0], t1 = tau[q1];
             u64* P0 = mylists + (size_t)q0 * POOL;
             u64* P1 = P0 + POOL;
+            // `rag` (compile-time): the chunk reaches past the last row (the shard's last chunk only); the ordinary chunk gets
+            // its own copy of the loop without the row-bound tests
+            auto append = [&](auto rag) __attribute__((always_inline)) {
+                constexpr bool RAG = decltype(rag)::value;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const unsigned r0 = rowbase + 2 * ((reg & 3) + 8 * (reg >> 2));
-                const bool v0 = !ragged || r0 < nrows;
-                const bool v1 = !ragged || r0 + 1 < nrows;
-                const float g00 = acc00[reg], g01 = acc01[reg], g10 = acc10[reg], g11 = acc11[reg];
-                const bool p00 = v0 && g00 > t0;
-                const bool p01 = v0 && g01 > t1;
-                const bool p10 = v1 && g10 > t0;
-                const bool p11 = v1 && g11 > t1;
-                if (__builtin_amdgcn_ballot_w64(p00 || p01 || p10 || p11) == 0ull) continue;
-                if (p00) P0[atomicAdd(&gcnt[q0], 1)] = make_key(g00, r0);
-                if (p01) P1[atomicAdd(&gcnt[q1], 1)] = make_key(g01, r0);
-                if (p10) P0[atomicAdd(&gcnt[q0], 1)] = make_key(g10, r0 + 1);
-                if (p11) P1[atomicAdd(&gcnt[q1], 1)] = make_key(g11, r0 + 1);
-            }
+                for (int reg = 0; reg < 16; ++reg) {
+                    const unsigned r0 = rowbase + 2 * ((reg & 3) + 8 * (reg >> 2));
+                    const bool v0 = !RAG || r0 < nrows;
+                    const bool v1 = !RAG || r0 + 1 < nrows;
+                    const float g00 = acc00[reg], g01 = acc01[reg], g10 = acc10[reg], g11 = acc11[reg];
+                    const bool p00 = v0 && g00 > t0;
+                    const bool p01 = v0 && g01 > t1;
+                    const bool p10 = v1 && g10 > t0;
+                    const bool p11 = v1 && g11 > t1;
+                    if (__builtin_amdgcn_ballot_w64(p00 || p01 || p10 || p11) == 0ull) continue;
+                    if (p00) P0[atomicAdd(&gcnt[q0], 1)] = make_key(g00, r0);
+                    if (p01) P1[atomicAdd(&gcnt[q1], 1)] = make_key(g01, r0);
+                    if (p10) P0[atomicAdd(&gcnt[q0], 1)] = make_key(g10, r0 + 1);
+                    if (p11) P1[atomicAdd(&gcnt[q1], 1)] = make_key(g11, r0 + 1);
+                }
+            };
+            if (ragged) append(std::true_type{}); else append(std::false_type{});
         }
         MQ_T(1)
         __syncthreads();  // appended keys are in L2 (vmcnt(0) precedes the barrier), counters final
