@@ -37,7 +37,24 @@ extern "C" {
 #define MQ_METRIC_IP 0 /* faiss.METRIC_INNER_PRODUCT, "metric_type": 0 in experiments/ir/..../search/config.json */
 #define MQ_METRIC_L2 1 /* faiss.METRIC_L2 (FAISS default when metric_type is None) */
 
-#define MQ_KNN_MAX_K 128 /* largest k of the fused scan; the reference uses k=100 (ir/search.py:12) */
+/* `--k` is a user option of the reference (meerqat/ir/search.py:12,135; default 100) and faiss IndexFlat takes any k.  One
+ * fused scan keeps up to MQ_KNN_FUSED_K neighbours; a larger k (up to MQ_KNN_MAX_K, FAISS-GPU's own limit) is served by
+ * ceil(k / 128) scans, round r + 1 admitting only candidates strictly below the last (score, id) key of round r -- the
+ * rounds' results concatenate into the exact sorted top-k.  Such calls always take the exact fp32 scan. */
+#define MQ_KNN_FUSED_K 128
+#define MQ_KNN_MAX_K 2048
+
+/* `flags` of the search entry points (the argument was `l2norm_queries`, 0 / 1, before the tie order became a parameter):
+ *   MQ_KNN_FLAG_L2NORM_QUERIES  apply the index's "L2norm," transform to the queries first;
+ *   MQ_KNN_FLAG_TIE_ID_DESC     among EXACTLY equal scores the HIGHER id is the better one -- for membership at the k-th
+ *                               boundary and for the order of the output alike.  Default (bit clear): the LOWER id is better.
+ * Which of several exactly tied rows FAISS keeps and in which order it reports them depends on its version and on k
+ * (value-only heaps before 1.7.3, cmp2(val, id) heaps since, a reservoir + partition at k >= 100; oracle/knn_oracle.c
+ * states what is known): both orders here are THIS LIBRARY'S documented policies, neither is a claim about FAISS.
+ * mq_topk_merge_*: OR MQ_MERGE_TIE_ID_DESC into `metric` to merge shard results produced with MQ_KNN_FLAG_TIE_ID_DESC. */
+#define MQ_KNN_FLAG_L2NORM_QUERIES 1
+#define MQ_KNN_FLAG_TIE_ID_DESC 2
+#define MQ_MERGE_TIE_ID_DESC 0x100
 
 /* faiss::distance_compute_blas_threshold.  A METRIC_L2 search of FEWER queries than this takes FAISS's
  * sequential path: distances are the direct sums of (q[k] - x[k])^2 (faiss fvec_L2sqr), not the BLAS form
@@ -81,23 +98,27 @@ int mq_l2norm_rows_f32(float *rows_dev, int64_t n, int d, void *stream);
  *   packed_dev/sqnorm_dev : the KB shard (N rows) as written by mq_pack_rows_f32
  *   queries_dev           : [nq, d] row-major fp32
  *   metric                : MQ_METRIC_IP or MQ_METRIC_L2
- *   l2norm_queries        : apply the index's "L2norm," transform to the queries first
+ *   flags                 : MQ_KNN_FLAG_* (above); 0 or 1 mean what `l2norm_queries` meant
  *   id_offset             : added to every returned row id (global id of the shard's row 0)
- *   D_dev [nq,k] fp32, I_dev [nq,k] int64: best first; equal scores by ascending id; unfilled
- *                           slots are (-inf | +inf, -1) as FAISS leaves them
- *   ws_dev/ws_bytes       : scratch of at least mq_knn_workspace_bytes(N, d, nq, k)
+ *   D_dev [nq,k] fp32, I_dev [nq,k] int64: best first; equal scores by ascending id (descending with
+ *                           MQ_KNN_FLAG_TIE_ID_DESC); unfilled slots are (-FLT_MAX | +FLT_MAX, -1): FAISS's heap
+ *                           neutral values (CMin::neutral() / CMax::neutral()), what it reports when k > ntotal
+ *   ws_dev/ws_bytes       : scratch of at least mq_knn_workspace_bytes_metric(N, d, nq, k, metric)
  * Scores are the k-ordered fp32 fma chain (see oracle/knn_oracle.c); selection is exact.
+ * mq_knn_workspace_bytes covers either metric; the _metric variant leaves out what an inner-product search never touches
+ * (the [nq][N] distance matrix of FAISS's small-batch L2 form: 114 MB per 1.5M-row shard at 19 queries).
  * ------------------------------------------------------------------------------------------- */
 size_t mq_knn_workspace_bytes(int64_t N, int d, int nq, int k);
+size_t mq_knn_workspace_bytes_metric(int64_t N, int d, int nq, int k, int metric);
 int mq_knn_search_f32(const float *packed_dev, const float *sqnorm_dev, int64_t N, int d, const float *queries_dev,
-                      int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float *D_dev,
+                      int nq, int k, int metric, int flags, int64_t id_offset, float *D_dev,
                       int64_t *I_dev, void *ws_dev, size_t ws_bytes, void *stream);
 
 /* Same call; additionally records the caller's hipEvent_t handles (may be NULL) on `stream`
  * immediately before and after the scan kernel (knn_scan_kernel), so that a benchmark can time the
  * dominant kernel on the stream it is launched on. */
 int mq_knn_search_f32_ev(const float *packed_dev, const float *sqnorm_dev, int64_t N, int d, const float *queries_dev,
-                         int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float *D_dev,
+                         int nq, int k, int metric, int flags, int64_t id_offset, float *D_dev,
                          int64_t *I_dev, void *ws_dev, size_t ws_bytes, void *stream, void *ev_scan_begin,
                          void *ev_scan_end);
 
@@ -123,7 +144,8 @@ int mq_knn_search_f32_ev(const float *packed_dev, const float *sqnorm_dev, int64
  * Query tiles whose bounded candidate buffers overflow are recomputed by the exact scan inside the
  * same call (from the panel copy, or from the row-major copy when packed_dev is NULL: same MFMA sequence, same bits, a
  * slower operand path); FAISS's small-batch L2 form (MQ_KNN_L2_DIRECT_BELOW) likewise reads whichever copy exists.
- * Workspace: mq_knn_workspace_bytes (covers both paths).
+ * Workspace: mq_knn_workspace_bytes (covers both paths).  k > MQ_KNN_FUSED_K: the call is served by the exact scan
+ * in ceil(k / 128) rounds (the bounded screening buffers are sized for the reference's k = 100).
  * ------------------------------------------------------------------------------------------- */
 size_t mq_knn_screen_bytes(int64_t n_rows, int d, int metric);
 int mq_knn_screen_prepare(const float *packed_dev, const float *sqnorm_dev, int64_t capacity_rows, int d, int metric,
@@ -134,7 +156,7 @@ int mq_knn_screen_add_rows_f32(const float *rows_dev, int64_t n, int d, int64_t 
                                float *xstats_dev, const float *center_dev, void *stream);
 int mq_knn_search_screened_f32(const float *packed_dev, const float *sqnorm_dev, const float *rowmajor_dev,
                                const uint16_t *bf16_dev, const float *xstats_dev, int64_t N, int d,
-                               const float *queries_dev, int nq, int k, int metric, int l2norm_queries, int64_t id_offset,
+                               const float *queries_dev, int nq, int k, int metric, int flags, int64_t id_offset,
                                float *D_dev, int64_t *I_dev, void *ws_dev, size_t ws_bytes, void *stream,
                                void *ev_scan_begin, void *ev_scan_end);
 /* Telemetry of the last screened search held in ws_dev (synchronises the stream): out[0] = query
@@ -148,7 +170,8 @@ int mq_knn_screen_stats(int64_t N, int d, int nq, int k, const void *ws_dev, int
 int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[8]);
 
 /* Merge per-shard results after the all-gather (new step; no reference
- * counterpart): Ds/Is [nshards, nq, k] with GLOBAL ids -> the k best per query. */
+ * counterpart): Ds/Is [nshards, nq, k] with GLOBAL ids -> the k best per query.  metric: MQ_METRIC_IP / MQ_METRIC_L2,
+ * optionally OR-ed with MQ_MERGE_TIE_ID_DESC; any k <= MQ_KNN_MAX_K. */
 int mq_topk_merge_f32(const float *Ds_dev, const int64_t *Is_dev, int nshards, int nq, int k, int metric,
                       float *D_dev, int64_t *I_dev, void *stream);
 
@@ -345,6 +368,13 @@ int mq_image_preprocess_u8(const uint8_t *src_dev, const int64_t *geom_dev, int 
  * floats (keeps the accumulators observable).
  * ------------------------------------------------------------------------------------------- */
 int mq_diag_mfma_bf16_loop(int iters, int random_operands, int workgroups, float *out_dev, void *stream);
+
+/* What the matrix instruction RETURNS: out_dev[32][32] fp32 = A . B^T for A_dev, B_dev = 32 rows x dp bf16 (row-major, dp a
+ * multiple of 16), one v_mfma_f32_32x32x16_bf16 per 16 columns in column order, each chained on the previous result -- the
+ * accumulation of csrc/knn_screen.inc's screening scan.  tests/test_screened_gpu.py bounds its distance to the float64 sum of
+ * the same bf16 operands by the accumulation term of the screening margin (the one term of the bound that rests on the
+ * instruction's undocumented internal summation). */
+int mq_diag_mfma_bf16_dot(const uint16_t *A_dev, const uint16_t *B_dev, int dp, float *out_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,17 @@ def lib():
         L.oracle_knn_f32_ex.argtypes = [fp, ctypes.c_int64, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_int64, fp, fp]
         L.oracle_knn_f32_ex.restype = ctypes.c_int
+        L.oracle_knn_f32_ex2.argtypes = [fp, ctypes.c_int64, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, fp, fp]
+        L.oracle_knn_f32_ex2.restype = ctypes.c_int
+        L.oracle_topk_merge_ex.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp]
+        L.oracle_topk_merge_ex.restype = ctypes.c_int
+        L.oracle_heap_init.argtypes = [ctypes.c_int, ctypes.c_int, fp, fp]
+        L.oracle_heap_init.restype = None
+        L.oracle_heap_add_block.argtypes = [fp, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, fp, fp]
+        L.oracle_heap_add_block.restype = None
+        L.oracle_heap_finish.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp]
+        L.oracle_heap_finish.restype = None
         L.oracle_l2norm_rows_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int]
         L.oracle_l2norm_rows_f32.restype = None
         L.oracle_sqnorm_rows_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int, fp]
@@ -73,15 +84,17 @@ def sqnorm_rows(x):
 
 FLT_MAX = float(np.finfo(np.float32).max)  # FAISS's heap neutral value: what an unfilled slot reports (+ for L2, - for IP)
 L2_FORMS = {"auto": 0, "expanded": 1, "direct": 2}
+TIE_ORDERS = {"id_asc": 0, "id_desc": 1}  # knn_oracle.c header: this library's documented tie policy, not FAISS's
 
 
-def knn(X, Q, k, metric=0, id_offset=0, l2norm=False, l2_form="auto"):
+def knn(X, Q, k, metric=0, id_offset=0, l2norm=False, l2_form="auto", tie_order="id_asc"):
     """Brute-force top-k of Q against X; returns (D f32 [nq,k], I i64 [nq,k]).
 
     ``l2norm=True`` applies the "L2norm," transform to both sides first (FAISS
     NormalizationTransform on add and on search).  ``l2_form`` (metric 1): "auto" = FAISS's rule
     (fewer than 20 queries: direct sum of (q-x)^2; otherwise ||q||^2+||x||^2-2<q,x> clamped at 0),
-    or force "expanded" / "direct"."""
+    or force "expanded" / "direct".  ``tie_order``: "id_asc" (default: among exactly equal scores the lower id
+    is better) or "id_desc" (the higher id is better), for membership at the k-th boundary and output order alike."""
     X, Q = _f32(X), _f32(Q)
     if Q.ndim != 2 or X.ndim != 2 or Q.shape[1] != X.shape[1]:
         raise ValueError("shape mismatch")
@@ -90,73 +103,62 @@ def knn(X, Q, k, metric=0, id_offset=0, l2norm=False, l2_form="auto"):
     nq, d = Q.shape
     D = np.empty((nq, k), dtype=np.float32)
     I = np.empty((nq, k), dtype=np.int64)
-    rc = lib().oracle_knn_f32_ex(X.ctypes.data, X.shape[0], d, Q.ctypes.data, nq, k, int(metric), L2_FORMS[l2_form],
-                                 int(id_offset), D.ctypes.data, I.ctypes.data)
+    rc = lib().oracle_knn_f32_ex2(X.ctypes.data, X.shape[0], d, Q.ctypes.data, nq, k, int(metric), L2_FORMS[l2_form],
+                                  TIE_ORDERS[tie_order], int(id_offset), D.ctypes.data, I.ctypes.data)
     if rc != 0:
-        raise ValueError(f"oracle_knn_f32_ex failed: {rc}")
+        raise ValueError(f"oracle_knn_f32_ex2 failed: {rc}")
     return D, I
 
 
-def topk_merge(Ds, Is, metric=0):
+def topk_merge(Ds, Is, metric=0, tie_order="id_asc"):
     """Merge [nshards,nq,k] per-shard lists (global ids) into the k best per query."""
     Ds = _f32(Ds)
     Is = np.ascontiguousarray(Is, dtype=np.int64)
     ns, nq, k = Ds.shape
     D = np.empty((nq, k), dtype=np.float32)
     I = np.empty((nq, k), dtype=np.int64)
-    rc = lib().oracle_topk_merge(Ds.ctypes.data, Is.ctypes.data, ns, nq, k, int(metric), D.ctypes.data, I.ctypes.data)
+    rc = lib().oracle_topk_merge_ex(Ds.ctypes.data, Is.ctypes.data, ns, nq, k, int(metric), TIE_ORDERS[tie_order],
+                                    D.ctypes.data, I.ctypes.data)
     if rc != 0:
         raise ValueError(f"oracle_topk_merge failed: {rc}")
     return D, I
 
 
-def knn_blas(X, Q, k, metric=0, block=1 << 16, threads=None):
-    """The same search organised the way FAISS's IndexFlat runs it for 20 or more queries
-    (faiss/utils/distances.cpp, exhaustive_inner_product_blas / exhaustive_L2sqr_blas): database blocks
-    through sgemm, then FAISS's heap rule -- a score enters a query's result only if it beats the query's
-    current k-th best.  Vectorised: after the first block (a plain top-k), a block's scores are compared with
-    the per-query thresholds and only the few survivors are merged (a full top-k of every 4096 x 65536 score
-    block cost 2.5x the sgemm).  Scores carry the BLAS library's summation order, not the fmaf chain of
-    knn(): this is bench.py's fast CPU leg (all cores through torch's BLAS), compared with knn() only up to
-    float64 near-ties (tests/test_oracle_cpu.py)."""
+def knn_blas(X, Q, k, metric=0, block=1024, threads=None, query_block=4096):
+    """The same search ORGANISED the way FAISS's IndexFlat runs it for 20 or more queries
+    (faiss/utils/distances.cpp, exhaustive_inner_product_blas / exhaustive_L2sqr_blas): blocks of ``query_block`` (4096 =
+    distance_compute_blas_query_bs) queries x ``block`` (1024 = distance_compute_blas_database_bs) database rows go through
+    the host BLAS's sgemm (torch.mm = MKL here, all cores, into one reused buffer), then FAISS's result-handler rule in
+    C / OpenMP over the queries (knn_oracle.c::oracle_heap_add_block): a score enters a query's heap only if it beats the
+    heap's current k-th best strictly.  Scores carry the BLAS library's summation order, not the fmaf chain of knn(): this
+    is bench.py's fast CPU leg, compared with knn() only up to float64 near-ties (tests/test_oracle_cpu.py)."""
     import torch
     if threads:
         torch.set_num_threads(int(threads))
     X, Q = _f32(X), _f32(Q)
     Xt, Qt = torch.from_numpy(X), torch.from_numpy(Q)
     nq, N = Qt.shape[0], Xt.shape[0]
-    qn = (Qt * Qt).sum(1) if metric == 1 else None
-    best_v = torch.full((nq, k), -FLT_MAX)            # goodness (ip, or -distance), best first; unfilled = neutral value
-    best_i = torch.full((nq, k), -1, dtype=torch.int64)
-    for s in range(0, N, block):
-        xb = Xt[s:s + block]
-        S = Qt @ xb.T
-        if metric == 1:
-            S = -(qn[:, None] + (xb * xb).sum(1)[None, :] - 2.0 * S).clamp_min_(0.0)
-        if s == 0:
-            kk = min(k, S.shape[1])
-            v, i = torch.topk(S, kk, dim=1)
-            best_v[:, :kk], best_i[:, :kk] = v, i
-            continue
-        rows, cols = (S > best_v[:, -1:]).nonzero(as_tuple=True)   # strict, like FAISS's heap
-        if rows.numel() == 0:
-            continue
-        counts = torch.bincount(rows, minlength=nq)
-        width = int(counts.max())
-        first = torch.cumsum(counts, 0) - counts
-        pos = torch.arange(rows.numel()) - first[rows]
-        cand_v = torch.full((nq, width), -FLT_MAX)
-        cand_i = torch.full((nq, width), -1, dtype=torch.int64)
-        cand_v[rows, pos] = S[rows, cols]
-        cand_i[rows, pos] = cols + s
-        allv, alli = torch.cat([best_v, cand_v], 1), torch.cat([best_i, cand_i], 1)
-        best_v, sel = torch.topk(allv, k, dim=1)
-        best_i = torch.gather(alli, 1, sel)
-    order = torch.argsort(best_v, dim=1, descending=True, stable=True)
-    D, I = torch.gather(best_v, 1, order), torch.gather(best_i, 1, order)
-    I = torch.where(D > -FLT_MAX, I, torch.full_like(I, -1))
-    D = D.numpy()
-    return (-D if metric == 1 else D).astype(np.float32), I.numpy()
+    L = lib()
+    D = np.empty((nq, k), dtype=np.float32)
+    I = np.empty((nq, k), dtype=np.int64)
+    S = torch.empty((min(query_block, max(nq, 1)), block), dtype=torch.float32)
+    for q0 in range(0, nq, query_block):
+        qb = Qt[q0:q0 + query_block]
+        n = qb.shape[0]
+        hv = np.empty((n, k), dtype=np.float32)
+        hi = np.empty((n, k), dtype=np.int64)
+        L.oracle_heap_init(n, k, hv.ctypes.data, hi.ctypes.data)
+        qn = (qb * qb).sum(1) if metric == 1 else None
+        for s in range(0, N, block):
+            xb = Xt[s:s + block]
+            nb = xb.shape[0]
+            Sb = S[:n, :nb] if nb == block else torch.empty((n, nb), dtype=torch.float32)
+            torch.mm(qb, xb.T, out=Sb)
+            if metric == 1:  # FAISS: ||q||^2 + ||x||^2 - 2 <q, x>, clamped at 0; the heap keeps the goodness -distance
+                Sb.mul_(-2.0).add_(qn[:, None]).add_((xb * xb).sum(1)[None, :]).clamp_min_(0.0).neg_()
+            L.oracle_heap_add_block(Sb.data_ptr(), n, Sb.stride(0), s, nb, k, hv.ctypes.data, hi.ctypes.data)
+        L.oracle_heap_finish(n, k, int(metric), hv.ctypes.data, hi.ctypes.data, D[q0:q0 + n].ctypes.data, I[q0:q0 + n].ctypes.data)
+    return D, I
 
 
 # ----------------------------------------------------------------------------------------------

@@ -4,7 +4,8 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product
  * path (viquae_amd/ fails loudly when the HIP library is missing).
  *
- * PARITY STATUS: "parity unpinned" against FAISS itself.  The arithmetic lives
+ * PARITY STATUS: "parity unpinned" against FAISS itself (tie membership / order
+ * inside equal-score runs and FAISS's BLAS summation order in particular).  The arithmetic lives
  * in the third-party module `faiss` (faiss-gpu>=1.7.1, /root/reference/
  * requirements.txt:14), which is neither vendored in /root/reference nor
  * installable here, and the reference's only test (tests/search.py:1-20) is
@@ -31,15 +32,47 @@
  *                 (q[k] - x[k])^2 directly -- no cancellation, no clamp.
  *     The two forms differ in the last bits of every distance and markedly near 0
  *     (near-duplicates), so both are restated; `l2_form` selects (0 = FAISS's rule).
- *   - a result-heap per query, initialised with (-FLT_MAX | +FLT_MAX, id -1)
+ *   - a result list per query, initialised with (-FLT_MAX | +FLT_MAX, id -1)
  *     (faiss heap neutral values: CMin::neutral() = lowest(), CMax::neutral() =
- *     max()), scanned over ascending database ids with a STRICT comparison: an
- *     equal score never displaces an earlier id, so the lower id wins membership
- *     at the k-th boundary; unfilled slots keep id -1 and +-FLT_MAX
- *     (3.4028235e+38, what FAISS prints when k > ntotal).  NaN, +-inf on the
- *     wrong side and the neutral value itself never enter.
- *   - output order: best first; equal scores by ascending id (documented
- *     choice; FAISS's order inside an equal-score run is version dependent).
+ *     max()); a score must beat the current k-th best STRICTLY to enter
+ *     (FAISS: `if (C::cmp(threshold, dis))`), so NaN, +-inf on the wrong side and
+ *     the neutral value itself never enter; unfilled slots keep id -1 and
+ *     +-FLT_MAX (3.4028235e+38, what FAISS prints when k > ntotal).
+ *   - TIES ARE THIS LIBRARY'S DOCUMENTED POLICY, NOT FAISS'S.  Which of several
+ *     rows with EXACTLY equal scores is kept at the k-th boundary, and in which
+ *     order an equal-score run is reported, depends in FAISS on the version and on
+ *     k (stated from FAISS's public sources as best known -- no copy of FAISS
+ *     exists in this image, nothing here can check it):
+ *       faiss 1.7.1 - 1.7.2 (the reference pins >= 1.7.1): value-only binary heaps
+ *         (HeapResultHandler / heap_replace_top compare `val` alone); membership
+ *         and order inside a tie follow the heap's sift pattern -- deterministic
+ *         but not a function of the ids;
+ *       faiss >= 1.7.3: the heaps sift with C::cmp2(val1, val2, id1, id2); for inner
+ *         product (CMin) the heap top is the smallest (score, id), so among entries
+ *         tied at the current minimum the LOWEST id is evicted first and
+ *         heap_reorder emits equal scores by DESCENDING id; for L2 (CMax) the
+ *         largest (distance, id) is evicted first and equal distances come out by
+ *         ASCENDING id.  A newcomer still needs a strictly better VALUE than the
+ *         threshold to enter, whatever its id;
+ *       k >= distance_compute_min_k_reservoir (= 100, the reference's k) on the
+ *         BLAS path (>= 20 queries): ReservoirBlockResultHandler -- candidates
+ *         strictly better than the threshold are appended to a 2k-entry reservoir
+ *         that is cut back to k with partition_fuzzy when full; membership among
+ *         boundary ties is whatever that partition leaves, and the final order comes
+ *         from the heap the reservoir is poured into.
+ *     This file implements ONE total order, parameterised by `tie_order`:
+ *       0 (id_asc, default): better = higher score, then LOWER id.  Equal scores are
+ *         reported by ascending id and the lowest ids win membership at the k-th
+ *         boundary.  (FAISS >= 1.7.3's L2 heap order; pre-1.7.3 folklore for IP.)
+ *       1 (id_desc): better = higher score, then HIGHER id (FAISS >= 1.7.3's
+ *         inner-product heap ORDER; note FAISS's membership rule is still "strictly
+ *         better value", which no total order on (score, id) reproduces for k-th
+ *         boundary ties -- a user who needs FAISS's exact tie sets must compare
+ *         equal-score runs as sets).
+ *     The HIP library implements the same two orders (MQ_KNN_FLAG_TIE_ID_DESC);
+ *     bit-exact tests compare like with like.  Wherever a test or document says
+ *     "FAISS" about ties, it means "unverified"; equal-score runs should be compared
+ *     as sets against any real FAISS build.
  *
  * Summation order (the one thing FAISS leaves to BLAS): every inner product and
  * squared norm here is the k-ordered fp32 chain acc = fmaf(a[k], b[k], acc),
@@ -88,12 +121,12 @@ void oracle_sqnorm_rows_f32(const float *rows, int64_t n, int d, float *out) {
     for (int64_t i = 0; i < n; ++i) out[i] = chain_dot(rows + i * (int64_t)d, rows + i * (int64_t)d, d);
 }
 
-/* insert (g,id) into a best-first sorted list of length k (strict: caller checked
- * g > list[k-1].g, or the slot is empty) */
-static inline void list_insert(ent_t *list, int k, float g, int64_t id) {
+/* insert (g,id) into a best-first sorted list of length k (caller checked that (g,id) beats
+ * list[k-1] or that the slot is empty).  ids arrive ascending: under id_asc an equal-score
+ * newcomer goes AFTER the existing ones, under id_desc BEFORE them. */
+static inline void list_insert(ent_t *list, int k, float g, int64_t id, int tie_desc) {
     int p = k - 1;
-    /* ids arrive ascending, so on equal g the newcomer goes after existing ones */
-    while (p > 0 && (list[p - 1].id < 0 || list[p - 1].g < g)) {
+    while (p > 0 && (list[p - 1].id < 0 || list[p - 1].g < g || (tie_desc && list[p - 1].g == g))) {
         list[p] = list[p - 1];
         --p;
     }
@@ -110,10 +143,11 @@ static inline void list_insert(ent_t *list, int k, float g, int64_t id) {
 
 /* l2_form (metric 1 only): 0 = FAISS's rule (direct below 20 queries, expanded otherwise),
  * 1 = expanded ||q||^2 + ||x||^2 - 2<q,x> clamped at 0, 2 = direct sum of (q-x)^2. */
-int oracle_knn_f32_ex(const float *X, int64_t N, int d, const float *Q, int nq, int k, int metric, int l2_form,
-                      int64_t id_offset, float *D, int64_t *I) {
+int oracle_knn_f32_ex2(const float *X, int64_t N, int d, const float *Q, int nq, int k, int metric, int l2_form,
+                       int tie_order, int64_t id_offset, float *D, int64_t *I) {
     if (N < 0 || d <= 0 || nq < 0 || k <= 0 || (metric != 0 && metric != 1)) return -1;
-    if (l2_form < 0 || l2_form > 2) return -1;
+    if (l2_form < 0 || l2_form > 2 || tie_order < 0 || tie_order > 1) return -1;
+    const int tie_desc = tie_order == 1;
     const int direct = metric == 1 && (l2_form == 2 || (l2_form == 0 && nq < FAISS_BLAS_THRESHOLD));
     int nblk = (nq + QB - 1) / QB;
     float *xn = NULL;
@@ -170,9 +204,11 @@ int oracle_knn_f32_ex(const float *X, int64_t N, int d, const float *Q, int nq, 
                 }
             }
             for (int j = 0; j < nb; ++j) {
-                if (acc[j] > thr[j]) { /* strict; false for NaN */
-                    ent_t *l = lists + (size_t)j * k;
-                    list_insert(l, k, acc[j], i);
+                /* strict against the k-th best (false for NaN; the neutral value never enters); under id_desc a later
+                 * (higher) id with the k-th best's score beats it */
+                ent_t *l = lists + (size_t)j * k;
+                if (acc[j] > thr[j] || (tie_desc && acc[j] == thr[j] && l[k - 1].id >= 0)) {
+                    list_insert(l, k, acc[j], i, tie_desc);
                     thr[j] = l[k - 1].id < 0 ? -FLT_MAX : l[k - 1].g;
                 }
             }
@@ -196,6 +232,11 @@ int oracle_knn_f32_ex(const float *X, int64_t N, int d, const float *Q, int nq, 
     return 0;
 }
 
+int oracle_knn_f32_ex(const float *X, int64_t N, int d, const float *Q, int nq, int k, int metric, int l2_form,
+                      int64_t id_offset, float *D, int64_t *I) {
+    return oracle_knn_f32_ex2(X, N, d, Q, nq, k, metric, l2_form, 0, id_offset, D, I);
+}
+
 int oracle_knn_f32(const float *X, int64_t N, int d, const float *Q, int nq, int k, int metric,
                    int64_t id_offset, float *D, int64_t *I) {
     return oracle_knn_f32_ex(X, N, d, Q, nq, k, metric, 0, id_offset, D, I);
@@ -206,9 +247,9 @@ int oracle_knn_f32(const float *X, int64_t N, int d, const float *Q, int nq, int
  * [nshards, nq, k] best-first lists with global ids; output the k best per query,
  * ordered by (score better first, id ascending); id -1 entries are empty.
  */
-int oracle_topk_merge(const float *Ds, const int64_t *Is, int nshards, int nq, int k, int metric, float *D,
-                      int64_t *I) {
-    if (nshards <= 0 || nq < 0 || k <= 0) return -1;
+int oracle_topk_merge_ex(const float *Ds, const int64_t *Is, int nshards, int nq, int k, int metric, int tie_order,
+                         float *D, int64_t *I) {
+    if (nshards <= 0 || nq < 0 || k <= 0 || tie_order < 0 || tie_order > 1) return -1;
     for (int q = 0; q < nq; ++q) {
         int *pos = (int *)calloc((size_t)nshards, sizeof(int));
         for (int s = 0; s < k; ++s) {
@@ -220,7 +261,7 @@ int oracle_topk_merge(const float *Ds, const int64_t *Is, int nshards, int nq, i
                 size_t o = ((size_t)h * nq + q) * k + pos[h];
                 if (Is[o] < 0) continue;
                 float g = metric == 1 ? -Ds[o] : Ds[o];
-                if (best < 0 || g > bg || (g == bg && Is[o] < bid)) {
+                if (best < 0 || g > bg || (g == bg && (tie_order ? Is[o] > bid : Is[o] < bid))) {
                     best = h;
                     bg = g;
                     bid = Is[o];
@@ -238,6 +279,94 @@ int oracle_topk_merge(const float *Ds, const int64_t *Is, int nshards, int nq, i
         free(pos);
     }
     return 0;
+}
+
+int oracle_topk_merge(const float *Ds, const int64_t *Is, int nshards, int nq, int k, int metric, float *D,
+                      int64_t *I) {
+    return oracle_topk_merge_ex(Ds, Is, nshards, nq, k, metric, 0, D, I);
+}
+
+/*
+ * FAISS's ORGANISATION of the search for >= 20 queries (faiss/utils/distances.cpp,
+ * exhaustive_inner_product_blas / exhaustive_L2sqr_blas): blocks of
+ * distance_compute_blas_query_bs = 4096 queries x distance_compute_blas_database_bs = 1024 rows go
+ * through sgemm, then a result handler walks each query's row of the block in ascending database
+ * order and lets a score in iff it beats the query's current k-th best strictly
+ * (HeapBlockResultHandler::add_results: `if (C::cmp(thresh, dis)) heap_replace_top(...)`).
+ * The caller (oracle/knn.py::knn_blas) runs the sgemm on the host BLAS and hands the block here;
+ * this is the CPU baseline's fast leg, not the bit-exact checker (its scores carry the BLAS's
+ * summation order).  Binary heap per query, top = worst entry under THIS library's id_asc order
+ * (smaller goodness, then larger id), so that the final membership equals oracle_knn_f32's on
+ * exact ties; a newcomer needs a strictly better value, like FAISS.
+ *   S   [nq][ld] goodness (inner product, or -distance) of database rows j0 .. j0 + nb - 1
+ *   hv / hi [nq][k] heap storage, prepared by oracle_heap_init
+ */
+static inline int heap_worse(float ga, int64_t ia, float gb, int64_t ib) { return ga < gb || (ga == gb && ia > ib); }
+
+void oracle_heap_init(int nq, int k, float *hv, int64_t *hi) {
+    for (size_t e = 0; e < (size_t)nq * k; ++e) {
+        hv[e] = -FLT_MAX;
+        hi[e] = -1;
+    }
+}
+
+void oracle_heap_add_block(const float *S, int nq, int64_t ld, int64_t j0, int nb, int k, float *hv, int64_t *hi) {
+#pragma omp parallel for schedule(static)
+    for (int q = 0; q < nq; ++q) {
+        const float *s = S + (size_t)q * ld;
+        float *v = hv + (size_t)q * k;
+        int64_t *id = hi + (size_t)q * k;
+        float thr = v[0];
+        for (int j = 0; j < nb; ++j) {
+            const float g = s[j];
+            if (!(g > thr)) continue; /* strict; false for NaN */
+            /* replace the top (worst) and sift down */
+            int p = 0;
+            const int64_t gid = j0 + j;
+            for (;;) {
+                int c = 2 * p + 1;
+                if (c >= k) break;
+                if (c + 1 < k && heap_worse(v[c + 1], id[c + 1] < 0 ? INT64_MAX : id[c + 1], v[c], id[c] < 0 ? INT64_MAX : id[c])) ++c;
+                if (!heap_worse(v[c], id[c] < 0 ? INT64_MAX : id[c], g, gid)) break;
+                v[p] = v[c];
+                id[p] = id[c];
+                p = c;
+            }
+            v[p] = g;
+            id[p] = gid;
+            thr = v[0];
+        }
+    }
+}
+
+static int ent_cmp_best_first(const void *a, const void *b) {
+    const ent_t *x = (const ent_t *)a, *y = (const ent_t *)b;
+    if (x->id < 0 || y->id < 0) return (x->id < 0) - (y->id < 0);
+    if (x->g != y->g) return x->g > y->g ? -1 : 1;
+    return x->id < y->id ? -1 : (x->id > y->id);
+}
+
+/* heap_reorder: best first (equal scores by ascending id), neutral values in the unfilled slots */
+void oracle_heap_finish(int nq, int k, int metric, const float *hv, const int64_t *hi, float *D, int64_t *I) {
+#pragma omp parallel for schedule(static)
+    for (int q = 0; q < nq; ++q) {
+        ent_t *e = (ent_t *)malloc(sizeof(ent_t) * (size_t)k);
+        for (int s = 0; s < k; ++s) {
+            e[s].g = hv[(size_t)q * k + s];
+            e[s].id = hi[(size_t)q * k + s];
+        }
+        qsort(e, (size_t)k, sizeof(ent_t), ent_cmp_best_first);
+        for (int s = 0; s < k; ++s) {
+            if (e[s].id < 0) {
+                D[(size_t)q * k + s] = metric == 1 ? FLT_MAX : -FLT_MAX;
+                I[(size_t)q * k + s] = -1;
+            } else {
+                D[(size_t)q * k + s] = (metric == 1 ? -e[s].g : e[s].g) + 0.0f;
+                I[(size_t)q * k + s] = e[s].id;
+            }
+        }
+        free(e);
+    }
 }
 
 int oracle_num_threads(void) {

@@ -170,6 +170,7 @@ def test_encoders_match_hf_on_checkpoint_like_weights(name, cfgname, kind, gemm,
     err = float(np.abs(got - want).max())
     print(f"{name} [{gemm}]: max |HIP - HF| = {err:.3e} on outputs of rms {scale:.2f}, max {np.abs(want).max():.1f}")
     assert err < TOL * scale
+    assert err < TOL, "north_star's bar is ABSOLUTE (1e-3 fp32): it must hold on these outputs of magnitude up to 24 as well"
 
 
 def test_dpr_hidden_states_match_oracle_layerwise():

@@ -70,7 +70,7 @@ def test_dataset_level_api_and_errors():
     with pytest.raises(MissingIndex):
         ds.search_batch("nope", z["X"][:2], k=3)
     with pytest.raises(NotImplementedError):
-        ds.search_batch("idx", z["X"][:2], k=129)
+        ds.search_batch("idx", z["X"][:2], k=2049)  # MQ_KNN_MAX_K = 2048 (k = 129 .. 2048: tests/test_tie_order_bigk_gpu.py)
 
 
 def test_save_path_then_load(tmp_path):

@@ -176,3 +176,61 @@ def test_l2norm_rows_close_to_numpy():
     b = X / np.linalg.norm(X, axis=1, keepdims=True)
     assert np.allclose(a, b, rtol=0, atol=2e-7)
     assert np.isnan(ok.l2norm_rows(np.zeros((1, 4), np.float32))).all()  # no epsilon, like the reference
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("k", [1, 7, 100, 300])
+def test_tie_order_is_a_total_order_parameter(metric, k):
+    """tie_order = id_asc / id_desc on tie-heavy integer data (every fp32 summation order is exact there): the result must be
+    the k first rows of the full lexicographic sort by (score best first, id ascending | descending) -- membership at the
+    k-th boundary and the order inside equal-score runs alike.  This is THIS LIBRARY'S documented policy (knn_oracle.c
+    header), not a statement about FAISS."""
+    rng = np.random.default_rng(5)
+    X = rng.integers(-2, 3, (700, 16)).astype(np.float32)
+    Q = rng.integers(-2, 3, (23, 16)).astype(np.float32)
+    S = Q.astype(np.float64) @ X.astype(np.float64).T
+    if metric == 1:
+        S = -((Q.astype(np.float64)[:, None, :] - X.astype(np.float64)[None, :, :]) ** 2).sum(2)
+    ids = np.broadcast_to(np.arange(X.shape[0]), S.shape)
+    for tie, id_key in (("id_asc", ids), ("id_desc", -ids)):
+        order = np.lexsort((id_key, -S), axis=1)[:, :k]
+        D, I = ok.knn(X, Q, k, metric=metric, tie_order=tie)
+        assert np.array_equal(I, order), tie
+        want = np.take_along_axis(S, order, 1)
+        assert np.array_equal(D, (-want if metric == 1 else want).astype(np.float32))
+    # the two orders agree as SETS wherever the k-th and (k+1)-th scores differ
+    Da, Ia = ok.knn(X, Q, k, metric=metric, tie_order="id_asc")
+    Dd, Id = ok.knn(X, Q, k, metric=metric, tie_order="id_desc")
+    assert np.array_equal(Da, Dd)
+    full = np.sort(S, axis=1)[:, ::-1]
+    for q in range(len(Q)):
+        if k < X.shape[0] and full[q, k - 1] != full[q, k]:
+            assert set(Ia[q]) == set(Id[q])
+
+
+def test_shard_merge_follows_the_tie_order():
+    rng = np.random.default_rng(6)
+    X = rng.integers(-1, 2, (512, 8)).astype(np.float32)
+    Q = rng.integers(-1, 2, (9, 8)).astype(np.float32)
+    for tie in ("id_asc", "id_desc"):
+        parts = [ok.knn(X[s:s + 128], Q, 20, metric=0, id_offset=s, tie_order=tie) for s in range(0, 512, 128)]
+        D, I = ok.topk_merge(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), 0, tie_order=tie)
+        Dw, Iw = ok.knn(X, Q, 20, metric=0, tie_order=tie)
+        assert np.array_equal(D, Dw) and np.array_equal(I, Iw)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_blas_leg_equals_the_chain_oracle_on_lattice_data(metric):
+    """FAISS's organisation (sgemm blocks + the strict-'>' heap rule in C) on integer data, where the BLAS summation order
+    cannot matter: scores AND ids equal the fmaf-chain oracle, ties at the k-th boundary included; ragged last block,
+    k larger than one block, more than one query block."""
+    rng = np.random.default_rng(7)
+    X = rng.integers(-3, 4, (3000, 32)).astype(np.float32)
+    Q = rng.integers(-3, 4, (70, 32)).astype(np.float32)
+    for k, block, qb in ((100, 1024, 4096), (10, 700, 32), (1200, 1024, 64)):
+        D, I = ok.knn(X, Q, k, metric=metric, l2_form="expanded")
+        Db, Ib = ok.knn_blas(X, Q, k, metric=metric, block=block, query_block=qb)
+        assert np.array_equal(D, Db) and np.array_equal(I, Ib), (k, block, qb)
+    Db, Ib = ok.knn_blas(X[:40], Q, 64, metric=metric)  # k > ntotal: neutral values and -1
+    D, I = ok.knn(X[:40], Q, 64, metric=metric, l2_form="expanded")
+    assert np.array_equal(D, Db) and np.array_equal(I, Ib)

@@ -27,6 +27,7 @@ SIGNATURES = {
     "mq_unpack_rows_f32": (c_int, [c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr, c_ptr]),
     "mq_l2norm_rows_f32": (c_int, [c_ptr, c_i64, c_int, c_ptr]),
     "mq_knn_workspace_bytes": (c_sz, [c_i64, c_int, c_int, c_int]),
+    "mq_knn_workspace_bytes_metric": (c_sz, [c_i64, c_int, c_int, c_int, c_int]),
     "mq_knn_search_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_int, c_int, c_i64,
                                   c_ptr, c_ptr, c_ptr, c_sz, c_ptr]),
     "mq_knn_search_f32_ev": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_int, c_int, c_i64,
@@ -34,6 +35,7 @@ SIGNATURES = {
     "mq_knn_screen_bytes": (c_sz, [c_i64, c_int, c_int]),
     "mq_knn_screen_prepare": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mq_diag_mfma_bf16_loop": (c_int, [c_int, c_int, c_int, c_ptr, c_ptr]),
+    "mq_diag_mfma_bf16_dot": (c_int, [c_ptr, c_ptr, c_int, c_ptr, c_ptr]),
     "mq_knn_screen_add_rows_f32": (c_int, [c_ptr, c_i64, c_int, c_i64, c_int, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mq_knn_search_screened_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_int, c_int,
                                            c_i64, c_ptr, c_ptr, c_ptr, c_sz, c_ptr, c_ptr, c_ptr]),

@@ -53,9 +53,31 @@ __global__ __launch_bounds__(1024) void mfma_loop_kernel(int iters, int random_o
     for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
     if (out) out[tid] = s;
 }
+
+// What v_mfma_f32_32x32x16_bf16 RETURNS for a 32 x 32 tile of dot products over dp columns, accumulated like the screening
+// scan accumulates them: one MFMA per 16 columns, in column order, each taking the previous result as its C operand.  Lane l
+// feeds row l & 31, columns 16 s + 8 (l >> 5) .. + 7 of step s; C/D: out[row 8 (reg >> 2) + (reg & 3) + 4 (l >> 5)][column l & 31].
+__global__ __launch_bounds__(64) void mfma_dot_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, int dp,
+                                                      float* __restrict__ out) {
+    const int lane = threadIdx.x, i = lane & 31, kg = lane >> 5;
+    f32x16_t c = {0};
+    for (int k0 = 0; k0 < dp; k0 += 16) {
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(A + (size_t)i * dp + k0 + 8 * kg);
+        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(B + (size_t)i * dp + k0 + 8 * kg);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) out[(8 * (reg >> 2) + (reg & 3) + 4 * kg) * 32 + i] = c[reg];
+}
 }  // namespace
 
 extern "C" {
+int mq_diag_mfma_bf16_dot(const uint16_t* A_dev, const uint16_t* B_dev, int dp, float* out_dev, void* stream) {
+    if (!A_dev || !B_dev || !out_dev || dp <= 0 || dp % 16 != 0) return MQ_EINVAL;
+    hipLaunchKernelGGL(mfma_dot_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A_dev, B_dev, dp, out_dev);
+    return hipGetLastError() == hipSuccess ? MQ_OK : MQ_EHIP;
+}
+
 int mq_diag_mfma_bf16_loop(int iters, int random_operands, int workgroups, float* out_dev, void* stream) {
     if (iters < 0 || workgroups <= 0 || !out_dev) return MQ_EINVAL;
     hipLaunchKernelGGL(mfma_loop_kernel, dim3((unsigned)workgroups), dim3(1024), 0, (hipStream_t)stream, iters, random_operands, out_dev);

@@ -51,7 +51,9 @@ constexpr int LDS_XS = 0;                                   // [NSTAGE][4][16][6
 constexpr int LDS_QS = LDS_XS + NSTAGE * 4 * BK * 64 * 4;   // [NSTAGE][4][16][64] f32
 constexpr int LDS_CNT = LDS_QS + NSTAGE * 4 * BK * 64 * 4;  // gcnt[256] int, tau[256] f32
 constexpr int LDS_TOTAL = LDS_CNT + 2 * TQ * 4;
-static_assert(MQ_KNN_MAX_K + TN <= POOL, "a compacted pool must take every row of one more chunk");
+constexpr int KF = MQ_KNN_FUSED_K;  // neighbours one fused scan keeps; a larger k runs ceil(k / KF) rounds (see knn_search_impl)
+static_assert(KF + TN <= POOL, "a compacted pool must take every row of one more chunk");
+static_assert(KF == 128, "sort128_desc / the merge kernels are written for 128-entry lists");
 
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
 
@@ -275,7 +277,18 @@ struct ScanArgs {
     unsigned long long* dbg;  // MQ_TIMING builds only
     int d;                    // row stride of the row-major operand (XROW instantiations)
     const int* only;          // optional [nqt] flags: scan only the flagged query tiles (fallback of the screened path)
+    unsigned flip;            // tie order: 0 = lower id wins an exact tie (key low word = ~row), 0xFFFFFFFF = higher id wins
+    const u64* ceil;          // CEIL instantiations: per-query key ceiling -- only keys strictly below it are candidates
 };
+
+// Tie order.  A key is (orderable score << 32) | ~(row ^ flip): with flip = 0 the lower row has the larger key (id_asc, the
+// default), with flip = 0xFFFFFFFF the higher row has (id_desc).  The score compare against tau stays STRICT; under id_desc a
+// later row that ties the k-th best must still enter (it beats it), so compact_pool publishes the next float BELOW the k-th
+// best score as tau.
+__device__ __forceinline__ float tau_of(u64 T, unsigned flip) {
+    const float t = key_score(T);
+    return flip ? nextafterf(t, -INFINITY) : t;
+}
 
 // ---- per-query candidate pool (HBM, owned by one workgroup) ------------------------------------
 // A candidate that beats the query's threshold tau is appended, unsorted, to the query's pool: slot
@@ -354,7 +367,7 @@ __device__ __forceinline__ u64 wave_kth_largest(const u64 (&v)[PR], int k) {
 // survivors best-first and zero-fill up to k (end of the slab).
 // The entries were stored by other waves of this workgroup: read them past the CU's L1 (agent-scope
 // relaxed loads are served by L2), after the caller's __syncthreads().
-__device__ __forceinline__ int compact_pool(u64* __restrict__ P, int g, int k, float* tau_q, int lane, bool sorted) {
+__device__ __forceinline__ int compact_pool(u64* __restrict__ P, int g, int k, float* tau_q, int lane, bool sorted, unsigned flip) {
     u64 v[PR];
 #pragma unroll
     for (int r = 0; r < PR; ++r)
@@ -372,7 +385,7 @@ __device__ __forceinline__ int compact_pool(u64* __restrict__ P, int g, int k, f
             if (keep) P[base + __builtin_popcountll(m & lt)] = v[r];
             base += __builtin_popcountll(m);
         }
-        if (lane == 0) *tau_q = key_score(T);
+        if (lane == 0) *tau_q = tau_of(T, flip);
         ng = k;
         if (!sorted) return ng;
         // the packed survivors were written by this wave; re-read them (own stores, same wave: program order)
@@ -408,7 +421,9 @@ __device__ __forceinline__ int compact_pool(u64* __restrict__ P, int g, int k, f
 // LDS-DMA of the panel layout would, so the MFMA sequence -- hence every score bit -- is the same; rows >= N and k >= d read
 // as zero like the panel padding.  Slower than the DMA path (64-byte row pieces, a 4-way bank conflict on the transposing
 // ds_write): it only runs for query tiles whose screening buffers overflowed.
-template <int METRIC, bool XROW = false>
+// CEIL: one round of a search for more than KF neighbours -- a candidate must also lie strictly below the query's key
+// ceiling (the last key the previous round reported), tested on the rare append path only.
+template <int METRIC, bool XROW = false, bool CEIL = false>
 __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Xs = reinterpret_cast<float*>(smem + LDS_XS);
@@ -633,6 +648,12 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
             const float t0 = tau[q0], t1 = tau[q1];
             u64* P0 = mylists + (size_t)q0 * POOL;
             u64* P1 = P0 + POOL;
+            const unsigned flip = a.flip;
+            u64 ceil0 = ~0ull, ceil1 = ~0ull;
+            if (CEIL) {
+                ceil0 = a.ceil[qt * TQ + q0];
+                ceil1 = a.ceil[qt * TQ + q1];
+            }
             // `rag` (compile-time): the chunk reaches past the last row (the shard's last chunk only); the ordinary chunk gets
             // its own copy of the loop without the row-bound tests
             auto append = [&](auto rag) __attribute__((always_inline)) {
@@ -648,10 +669,19 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
                     const bool p10 = v1 && g10 > t0;
                     const bool p11 = v1 && g11 > t1;
                     if (__builtin_amdgcn_ballot_w64(p00 || p01 || p10 || p11) == 0ull) continue;
-                    if (p00) P0[atomicAdd(&gcnt[q0], 1)] = make_key(g00, r0);
-                    if (p01) P1[atomicAdd(&gcnt[q1], 1)] = make_key(g01, r0);
-                    if (p10) P0[atomicAdd(&gcnt[q0], 1)] = make_key(g10, r0 + 1);
-                    if (p11) P1[atomicAdd(&gcnt[q1], 1)] = make_key(g11, r0 + 1);
+                    if (CEIL) {
+                        const u64 k00 = make_key(g00, r0 ^ flip), k01 = make_key(g01, r0 ^ flip);
+                        const u64 k10 = make_key(g10, (r0 + 1) ^ flip), k11 = make_key(g11, (r0 + 1) ^ flip);
+                        if (p00 && k00 < ceil0) P0[atomicAdd(&gcnt[q0], 1)] = k00;
+                        if (p01 && k01 < ceil1) P1[atomicAdd(&gcnt[q1], 1)] = k01;
+                        if (p10 && k10 < ceil0) P0[atomicAdd(&gcnt[q0], 1)] = k10;
+                        if (p11 && k11 < ceil1) P1[atomicAdd(&gcnt[q1], 1)] = k11;
+                    } else {
+                        if (p00) P0[atomicAdd(&gcnt[q0], 1)] = make_key(g00, r0 ^ flip);
+                        if (p01) P1[atomicAdd(&gcnt[q1], 1)] = make_key(g01, r0 ^ flip);
+                        if (p10) P0[atomicAdd(&gcnt[q0], 1)] = make_key(g10, (r0 + 1) ^ flip);
+                        if (p11) P1[atomicAdd(&gcnt[q1], 1)] = make_key(g11, (r0 + 1) ^ flip);
+                    }
                 }
             };
             if (ragged) append(std::true_type{}); else append(std::false_type{});
@@ -669,7 +699,7 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
             const int g = __builtin_amdgcn_readfirstlane(gcnt[q]);
             if (g > POOL - TN || last) {
                 u64* P = mylists + (size_t)q * POOL;
-                const int ng = compact_pool(P, g, k, &tau[q], lane, last);
+                const int ng = compact_pool(P, g, k, &tau[q], lane, last, a.flip);
                 if (lane == 0) gcnt[q] = ng;
             }
         }
@@ -686,18 +716,19 @@ struct Ent {
     float g;
     long long id;  // < 0: empty
 };
-__device__ __forceinline__ bool better(const Ent& x, const Ent& y) {
+// total order of the results: higher goodness first, then the lower id (desc = false) or the higher id (desc = true)
+__device__ __forceinline__ bool better(const Ent& x, const Ent& y, bool desc) {
     if (y.id < 0) return x.id >= 0;
     if (x.id < 0) return false;
-    return x.g > y.g || (x.g == y.g && x.id < y.id);
+    return x.g > y.g || (x.g == y.g && (desc ? x.id > y.id : x.id < y.id));
 }
 
 // count of entries in sorted (best first) list L[0..k) that are better than e
-__device__ __forceinline__ int count_better(const Ent* L, int k, const Ent& e) {
+__device__ __forceinline__ int count_better(const Ent* L, int k, const Ent& e, bool desc) {
     int lo = 0, hi = k;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (better(L[mid], e)) lo = mid + 1; else hi = mid;
+        if (better(L[mid], e, desc)) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
@@ -705,7 +736,7 @@ __device__ __forceinline__ int count_better(const Ent* L, int k, const Ent& e) {
 // Sequentially rank-merges nlists sorted lists of k entries; entry fetch is a functor so the same
 // body serves the slab lists (packed keys) and the shard lists (D, I arrays).  128 threads, k <= 128.
 template <typename Fetch>
-__device__ __forceinline__ void merge_lists(int nlists, int k, Fetch fetch, Ent* Ra, Ent* Rb, Ent* Ls, Ent& out) {
+__device__ __forceinline__ void merge_lists(int nlists, int k, Fetch fetch, Ent* Ra, Ent* Rb, Ent* Ls, Ent& out, bool desc) {
     const int t = threadIdx.x;
     const Ent empty = {0.f, -1};
     Ra[t] = (t < k) ? fetch(0, t) : empty;
@@ -718,11 +749,11 @@ __device__ __forceinline__ void merge_lists(int nlists, int k, Fetch fetch, Ent*
         __syncthreads();
         const Ent r = cur[t], l = Ls[t];
         if (r.id >= 0) {
-            const int p = t + count_better(Ls, k, r);
+            const int p = t + count_better(Ls, k, r, desc);
             if (p < k) nxt[p] = r;
         }
         if (l.id >= 0) {
-            const int p = t + count_better(cur, k, l);
+            const int p = t + count_better(cur, k, l, desc);
             if (p < k) nxt[p] = l;
         }
         __syncthreads();
@@ -731,10 +762,15 @@ __device__ __forceinline__ void merge_lists(int nlists, int k, Fetch fetch, Ent*
     out = cur[t];
 }
 
+// kout / col0: the [nq, kout] result arrays receive this launch's k entries at columns [col0, col0 + k) (kout = k, col0 = 0
+// for an ordinary search; a search for more than KF neighbours writes one KF-wide column block per round).  next_ceil
+// (optional): the key of the round's LAST entry -- the next round's candidates lie strictly below it -- or 0 ("nothing
+// left") when the round found fewer than k rows.
 template <int METRIC>
 __global__ __launch_bounds__(128) void slab_merge_kernel(const u64* __restrict__ lists, int nq, int S, int k,
                                                          long long id_offset, float* __restrict__ D,
-                                                         long long* __restrict__ I, const int* __restrict__ only) {
+                                                         long long* __restrict__ I, const int* __restrict__ only,
+                                                         unsigned flip, int kout, int col0, u64* __restrict__ next_ceil) {
     __shared__ Ent Ra[128], Rb[128], Ls[128];
     const int q = blockIdx.x;
     if (only && only[q / TQ] == 0) return;
@@ -743,25 +779,26 @@ __global__ __launch_bounds__(128) void slab_merge_kernel(const u64* __restrict__
         const u64 key = lists[(((size_t)qt * S + s) * TQ + ql) * (size_t)POOL + t];
         Ent e;
         e.g = key_score(key);
-        e.id = key ? (long long)key_row(key) : -1;
+        e.id = key ? (long long)(key_row(key) ^ flip) : -1;
         return e;
     };
     Ent out;
-    merge_lists(S, k, fetch, Ra, Rb, Ls, out);
+    merge_lists(S, k, fetch, Ra, Rb, Ls, out, flip != 0u);
     const int t = threadIdx.x;
     if (t < k) {
         float d;
         if (out.id < 0) d = (METRIC == MQ_METRIC_L2) ? FLT_MAX : -FLT_MAX;  // unfilled slot: FAISS reports its heap neutral value
         else d = ((METRIC == MQ_METRIC_L2) ? -out.g : out.g) + 0.0f;
-        D[(size_t)q * k + t] = d;
-        I[(size_t)q * k + t] = out.id < 0 ? -1 : out.id + id_offset;
+        D[(size_t)q * kout + col0 + t] = d;
+        I[(size_t)q * kout + col0 + t] = out.id < 0 ? -1 : out.id + id_offset;
+        if (next_ceil && t == k - 1) next_ceil[q] = out.id < 0 ? 0ull : make_key(out.g, (unsigned)out.id ^ flip);
     }
 }
 
 template <int METRIC>
 __global__ __launch_bounds__(128) void shard_merge_kernel(const float* __restrict__ Ds, const long long* __restrict__ Is,
                                                           size_t d_stride, size_t i_stride, int nshards, int nq, int k,
-                                                          float* __restrict__ D, long long* __restrict__ I) {
+                                                          float* __restrict__ D, long long* __restrict__ I, bool desc) {
     // d_stride / i_stride: elements between two shards' [nq,k] blocks (nq*k for two dense arrays; the
     // all-gathered per-rank records {scores | ids} give record_bytes/4 and record_bytes/8)
     __shared__ Ent Ra[128], Rb[128], Ls[128];
@@ -775,7 +812,7 @@ __global__ __launch_bounds__(128) void shard_merge_kernel(const float* __restric
         return e;
     };
     Ent out;
-    merge_lists(nshards, k, fetch, Ra, Rb, Ls, out);
+    merge_lists(nshards, k, fetch, Ra, Rb, Ls, out, desc);
     const int t = threadIdx.x;
     if (t < k) {
         float d;
@@ -783,6 +820,48 @@ __global__ __launch_bounds__(128) void shard_merge_kernel(const float* __restric
         else d = ((METRIC == MQ_METRIC_L2) ? -out.g : out.g) + 0.0f;
         D[(size_t)q * k + t] = d;
         I[(size_t)q * k + t] = out.id < 0 ? -1 : out.id;
+    }
+}
+
+// Shard merge for k > KF (any k): every entry of every list finds its rank in the merged order by counting, with binary
+// searches in the other (sorted, best-first) lists, the entries that beat it; ids are unique across shards, so ranks are
+// unique.  One 256-thread workgroup per query; the lists stay in HBM / L2 (W x k x 12 bytes per query).
+template <int METRIC>
+__global__ __launch_bounds__(256) void shard_merge_big_kernel(const float* __restrict__ Ds, const long long* __restrict__ Is,
+                                                              size_t d_stride, size_t i_stride, int nshards, int nq, int k,
+                                                              float* __restrict__ D, long long* __restrict__ I, bool desc) {
+    const int q = blockIdx.x;
+    const size_t qo = (size_t)q * (size_t)k;
+    auto fetch = [&](int s, int t) {
+        Ent e;
+        e.id = Is[(size_t)s * i_stride + qo + t];
+        const float d = Ds[(size_t)s * d_stride + qo + t];
+        e.g = (METRIC == MQ_METRIC_L2) ? -d : d;
+        return e;
+    };
+    for (int t = threadIdx.x; t < k; t += 256) {
+        D[qo + t] = (METRIC == MQ_METRIC_L2) ? FLT_MAX : -FLT_MAX;
+        I[qo + t] = -1;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nshards * k; e += 256) {
+        const int s = e / k, t = e % k;
+        const Ent x = fetch(s, t);
+        if (x.id < 0) continue;
+        int rank = t;
+        for (int o = 0; o < nshards && rank < k; ++o) {
+            if (o == s) continue;
+            int lo = 0, hi = k;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (better(fetch(o, mid), x, desc)) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            D[qo + rank] = ((METRIC == MQ_METRIC_L2) ? -x.g : x.g) + 0.0f;
+            I[qo + rank] = x.id;
+        }
     }
 }
 
@@ -847,12 +926,15 @@ struct Geometry {
     // FAISS's small-batch L2 path (knn_direct.inc): transposed queries + the [nq][npad] distance matrix
     size_t off_dqt, off_ddist;
     int64_t npad;
+    size_t off_ceil;  // u64 [nqpad]: per-query key ceilings of a search for more than KF neighbours
 };
 
 // bf16 row length of the screening copy: d (inner product) or d + 2 (L2: the (h, l) pair of -||x||^2 / 2), padded to 64
 int screen_dp(int d, int metric) { return (int)round_up(d + (metric == MQ_METRIC_L2 ? 2 : 0), SBK); }
 
-Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
+// metric: MQ_METRIC_IP / MQ_METRIC_L2, or -1 = unknown (reserve what either needs).  Only the L2 metric has the small-batch
+// direct form whose [nq][npad] distance matrix lives at the END of the workspace, so every other offset is metric-independent.
+Geometry geometry(int64_t N, int d, int nq, int k, int cus, int metric = -1) {
     Geometry g;
     g.dpad = (int)round_up(d, BK);
     g.nqpad = round_up(nq > 0 ? nq : 1, TQ);
@@ -905,9 +987,10 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus) {
     g.off_cand = o;   o += nq1 * RMAX * 4;
     g.off_ckeys = o;  o += nq1 * RMAX * 8;
     g.off_ccount = o; o += (size_t)round_up((int64_t)nq1 * 4, 256);
+    g.off_ceil = o;   o += (size_t)g.nqpad * 8;
     g.npad = round_up(N > 0 ? N : 1, TN);
     g.off_dqt = g.off_ddist = o;
-    if (nq > 0 && nq < MQ_KNN_L2_DIRECT_BELOW) {
+    if (nq > 0 && nq < MQ_KNN_L2_DIRECT_BELOW && metric != MQ_METRIC_IP) {
         g.off_dqt = o;   o += (size_t)round_up((int64_t)g.dpad * DIRECT_NQ * 4, 256);
         g.off_ddist = o; o += (size_t)nq * (size_t)g.npad * 4;
     }
@@ -979,6 +1062,11 @@ size_t mq_knn_workspace_bytes(int64_t N, int d, int nq, int k) {
     return geometry(N, d, nq, k, num_cus()).total;
 }
 
+size_t mq_knn_workspace_bytes_metric(int64_t N, int d, int nq, int k, int metric) {
+    if (N < 0 || d <= 0 || nq < 0 || k <= 0 || k > MQ_KNN_MAX_K || (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2)) return 0;
+    return geometry(N, d, nq, k, num_cus(), metric).total;
+}
+
 int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[8]) {
     if (!out || N < 0 || d <= 0 || nq < 0 || k <= 0 || k > MQ_KNN_MAX_K) return MQ_EINVAL;
     const Geometry g = geometry(N, d, nq, k, num_cus());
@@ -993,17 +1081,26 @@ int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[8]) {
     return MQ_OK;
 }
 
+// tie order of a call: key low word = ~(row ^ flip)
+static inline unsigned tie_flip(int flags) { return (flags & MQ_KNN_FLAG_TIE_ID_DESC) ? 0xFFFFFFFFu : 0u; }
+
+// rounds of a search: ceil(k / KF) fused selections of up to KF neighbours each; round r > 0 only admits keys strictly below
+// the last key of round r - 1 (keys are unique, so the rounds' results concatenate into the exact sorted top-k)
+static inline int n_rounds(int k) { return (k + KF - 1) / KF; }
+
 // metric L2 with fewer than 20 queries: FAISS's sequential path, d = sum_k (q[k] - x[k])^2 (knn_direct.inc)
 static int knn_search_l2_direct(const float* packed_dev, const float* rowmajor_dev, int64_t N, int d, const float* queries_dev, int nq, int k,
-                                int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev, void* ws_dev,
+                                int flags, int64_t id_offset, float* D_dev, int64_t* I_dev, void* ws_dev,
                                 const Geometry& g, hipStream_t st) {
     char* ws = (char*)ws_dev;
     float* qtmp = (float*)(ws + g.off_qtmp);
     float* Qt = (float*)(ws + g.off_dqt);
     float* dist = (float*)(ws + g.off_ddist);
     u64* lists = (u64*)(ws + g.off_lists);
+    u64* ceil = (u64*)(ws + g.off_ceil);
+    const unsigned flip = tie_flip(flags);
     const float* q_rm = queries_dev;
-    if (l2norm_queries) {
+    if (flags & MQ_KNN_FLAG_L2NORM_QUERIES) {
         MQ_HIP(hipMemcpyAsync(qtmp, queries_dev, (size_t)nq * d * 4, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, qtmp, (int64_t)nq, d);
         MQ_HIP(hipGetLastError());
@@ -1022,82 +1119,121 @@ static int knn_search_l2_direct(const float* packed_dev, const float* rowmajor_d
                                (long long)N, d, nq, (long long)g.npad, dist);
         MQ_HIP(hipGetLastError());
     }
-    // segment winners live in the (much larger) pool region of the other paths: nq * S * 128 keys
-    hipLaunchKernelGGL(l2_direct_select_kernel, dim3((unsigned)g.S, (unsigned)nq), dim3(256), 0, st, dist, (long long)N,
-                       (long long)g.npad, seg, k, lists);
+    const int R = n_rounds(k);
+    for (int r = 0; r < R; ++r) {
+        const int kr = k - r * KF < KF ? k - r * KF : KF;
+        // segment winners live in the (much larger) pool region of the other paths: nq * S * 128 keys
+        hipLaunchKernelGGL(l2_direct_select_kernel, dim3((unsigned)g.S, (unsigned)nq), dim3(256), 0, st, dist, (long long)N,
+                           (long long)g.npad, seg, kr, lists, flip, r ? (const u64*)ceil : (const u64*)nullptr);
+        MQ_HIP(hipGetLastError());
+        hipLaunchKernelGGL(l2_direct_final_kernel, dim3((unsigned)nq), dim3(256), 0, st, lists, g.S, kr, (long long)id_offset, D_dev,
+                           (long long*)I_dev, flip, k, r * KF, r + 1 < R ? ceil : (u64*)nullptr);
+        MQ_HIP(hipGetLastError());
+    }
+    return MQ_OK;
+}
+
+}  // extern "C"
+// launch of one exact scan (8 instantiations: metric x operand layout x key ceiling)
+template <int METRIC>
+static int launch_scan_m(bool xrow, bool ceil, const ScanArgs& a, hipStream_t st) {
+    const dim3 grid((unsigned)(a.nqt * a.S)), block(1024);
+    if (!xrow && !ceil) { MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<METRIC, false, false>); hipLaunchKernelGGL((knn_scan_kernel<METRIC, false, false>), grid, block, LDS_TOTAL, st, a); }
+    else if (xrow && !ceil) { MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<METRIC, true, false>); hipLaunchKernelGGL((knn_scan_kernel<METRIC, true, false>), grid, block, LDS_TOTAL, st, a); }
+    else if (!xrow) { MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<METRIC, false, true>); hipLaunchKernelGGL((knn_scan_kernel<METRIC, false, true>), grid, block, LDS_TOTAL, st, a); }
+    else { MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<METRIC, true, true>); hipLaunchKernelGGL((knn_scan_kernel<METRIC, true, true>), grid, block, LDS_TOTAL, st, a); }
     MQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(l2_direct_final_kernel, dim3((unsigned)nq), dim3(256), 0, st, lists, g.S, k, (long long)id_offset, D_dev,
-                       (long long*)I_dev);
+    return MQ_OK;
+}
+static int launch_scan(int metric, bool xrow, bool ceil, const ScanArgs& a, hipStream_t st) {
+    return metric == MQ_METRIC_L2 ? launch_scan_m<MQ_METRIC_L2>(xrow, ceil, a, st) : launch_scan_m<MQ_METRIC_IP>(xrow, ceil, a, st);
+}
+extern "C" {
+static int launch_slab_merge(int metric, const u64* lists, int nq, int S, int k, int64_t id_offset, float* D_dev, int64_t* I_dev,
+                             const int* only, unsigned flip, int kout, int col0, u64* next_ceil, hipStream_t st) {
+    if (metric == MQ_METRIC_IP)
+        hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, st, lists, nq, S, k, (long long)id_offset,
+                           D_dev, (long long*)I_dev, only, flip, kout, col0, next_ceil);
+    else
+        hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(128), 0, st, lists, nq, S, k, (long long)id_offset,
+                           D_dev, (long long*)I_dev, only, flip, kout, col0, next_ceil);
     MQ_HIP(hipGetLastError());
     return MQ_OK;
 }
 
+// The exact scan over a shard whose query panels (a.Qp, a.qn) are ready: one fused scan + slab merge per round of KF
+// neighbours (ONE round for k <= 128, the reference's k = 100).  a.Xp = the panel copy, or the row-major copy (xrow).
+static int exact_scan_rounds(int metric, bool xrow, ScanArgs a, const Geometry& g, int nq, int k, int64_t id_offset,
+                             float* D_dev, int64_t* I_dev, char* ws, const int* only, hipStream_t st, void* ev0, void* ev1) {
+    u64* ceil = (u64*)(ws + g.off_ceil);
+    const int R = n_rounds(k);
+    for (int r = 0; r < R; ++r) {
+        const int kr = k - r * KF < KF ? k - r * KF : KF;
+        a.k = kr;
+        a.ceil = r ? ceil : nullptr;
+        a.only = only;
+        if (r == 0 && ev0) MQ_HIP(hipEventRecord((hipEvent_t)ev0, st));
+        const int rc = launch_scan(metric, xrow, r > 0, a, st);
+        if (rc != MQ_OK) return rc;
+        if (r == 0 && ev1) MQ_HIP(hipEventRecord((hipEvent_t)ev1, st));
+        const int rm = launch_slab_merge(metric, a.lists, nq, g.S, kr, id_offset, D_dev, I_dev, only, a.flip, k, r * KF,
+                                         r + 1 < R ? ceil : (u64*)nullptr, st);
+        if (rm != MQ_OK) return rm;
+    }
+    return MQ_OK;
+}
+
 static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int64_t N, int d, const float* queries_dev,
-                           int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev,
+                           int nq, int k, int metric, int flags, int64_t id_offset, float* D_dev, int64_t* I_dev,
                            void* ws_dev, size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
     if (nq == 0) return MQ_OK;
     if (!packed_dev || !sqnorm_dev || !queries_dev || !D_dev || !I_dev || !ws_dev) return MQ_EINVAL;
     if (N < 0 || d <= 0 || nq < 0 || k <= 0 || (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2)) return MQ_EINVAL;
+    if (flags & ~(MQ_KNN_FLAG_L2NORM_QUERIES | MQ_KNN_FLAG_TIE_ID_DESC)) return MQ_EINVAL;
     if (k > MQ_KNN_MAX_K) return MQ_EUNSUPPORTED;
     if (N >= 0xFFFFFFFFll) return MQ_EUNSUPPORTED;  // 32-bit local row ids
-    const Geometry g = geometry(N, d, nq, k, num_cus());
+    const Geometry g = geometry(N, d, nq, k, num_cus(), metric);
     if (ws_bytes < g.total) return MQ_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)ws_dev;
     float* Qp = (float*)(ws + g.off_qp);
     float* qn = (float*)(ws + g.off_qn);
-    float* qtmp = (float*)(ws + g.off_qtmp);
     u64* lists = (u64*)(ws + g.off_lists);
     if (metric == MQ_METRIC_L2 && nq < MQ_KNN_L2_DIRECT_BELOW)
-        return knn_search_l2_direct(packed_dev, nullptr, N, d, queries_dev, nq, k, l2norm_queries, id_offset, D_dev, I_dev, ws_dev, g, st);
+        return knn_search_l2_direct(packed_dev, nullptr, N, d, queries_dev, nq, k, flags, id_offset, D_dev, I_dev, ws_dev, g, st);
 
     // queries -> panel layout (+ optional "L2norm," transform, + ||q||^2); padded queries are zero
     MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
-    const float* qsrc = queries_dev;
-    (void)qtmp;
-    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((nq + PANEL - 1) / PANEL)), dim3(256), 0, st, qsrc, (int64_t)nq, d,
-                       g.dpad, (int64_t)0, l2norm_queries, Qp, qn);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((nq + PANEL - 1) / PANEL)), dim3(256), 0, st, queries_dev, (int64_t)nq, d,
+                       g.dpad, (int64_t)0, (flags & MQ_KNN_FLAG_L2NORM_QUERIES) ? 1 : 0, Qp, qn, (const int*)nullptr);
     MQ_HIP(hipGetLastError());
 
-    if (N > 0) {
-        ScanArgs a;
-        a.Xp = packed_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = lists;
-        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = dbg_ptr(); a.only = nullptr; a.d = d;
-        const dim3 grid((unsigned)(g.nqt * g.S)), block(1024);
-        if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
-        if (metric == MQ_METRIC_IP) {
-            MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<MQ_METRIC_IP>);
-            hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_IP>, grid, block, LDS_TOTAL, st, a);
-        } else {
-            MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<MQ_METRIC_L2>);
-            hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_L2>, grid, block, LDS_TOTAL, st, a);
-        }
-        MQ_HIP(hipGetLastError());
-        if (ev_scan_end) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_end, st));
-    } else {
-        MQ_HIP(hipMemsetAsync(lists, 0, (size_t)g.nqt * g.S * TQ * (size_t)POOL * 8, st));
+    ScanArgs a;
+    a.Xp = packed_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = lists;
+    a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = dbg_ptr(); a.only = nullptr; a.d = d;
+    a.flip = tie_flip(flags); a.ceil = nullptr;
+    if (N > 0)
+        return exact_scan_rounds(metric, false, a, g, nq, k, id_offset, D_dev, I_dev, ws, nullptr, st, ev_scan_begin, ev_scan_end);
+    MQ_HIP(hipMemsetAsync(lists, 0, (size_t)g.nqt * g.S * TQ * (size_t)POOL * 8, st));
+    for (int r = 0; r < n_rounds(k); ++r) {
+        const int kr = k - r * KF < KF ? k - r * KF : KF;
+        const int rm = launch_slab_merge(metric, lists, nq, g.S, kr, id_offset, D_dev, I_dev, nullptr, a.flip, k, r * KF, nullptr, st);
+        if (rm != MQ_OK) return rm;
     }
-    if (metric == MQ_METRIC_IP)
-        hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, st, lists, nq, g.S, k,
-                           (long long)id_offset, D_dev, (long long*)I_dev, (const int*)nullptr);
-    else
-        hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(128), 0, st, lists, nq, g.S, k,
-                           (long long)id_offset, D_dev, (long long*)I_dev, (const int*)nullptr);
-    MQ_HIP(hipGetLastError());
     return MQ_OK;
 }
 
 int mq_knn_search_f32(const float* packed_dev, const float* sqnorm_dev, int64_t N, int d, const float* queries_dev,
-                      int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev,
+                      int nq, int k, int metric, int flags, int64_t id_offset, float* D_dev, int64_t* I_dev,
                       void* ws_dev, size_t ws_bytes, void* stream) {
-    return knn_search_impl(packed_dev, sqnorm_dev, N, d, queries_dev, nq, k, metric, l2norm_queries, id_offset, D_dev,
+    return knn_search_impl(packed_dev, sqnorm_dev, N, d, queries_dev, nq, k, metric, flags, id_offset, D_dev,
                            I_dev, ws_dev, ws_bytes, stream, nullptr, nullptr);
 }
 
 int mq_knn_search_f32_ev(const float* packed_dev, const float* sqnorm_dev, int64_t N, int d, const float* queries_dev,
-                         int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev,
+                         int nq, int k, int metric, int flags, int64_t id_offset, float* D_dev, int64_t* I_dev,
                          void* ws_dev, size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
-    return knn_search_impl(packed_dev, sqnorm_dev, N, d, queries_dev, nq, k, metric, l2norm_queries, id_offset, D_dev,
+    return knn_search_impl(packed_dev, sqnorm_dev, N, d, queries_dev, nq, k, metric, flags, id_offset, D_dev,
                            I_dev, ws_dev, ws_bytes, stream, ev_scan_begin, ev_scan_end);
 }
 
@@ -1156,10 +1292,13 @@ int mq_knn_screen_add_rows_f32(const float* rows_dev, int64_t n, int d, int64_t 
 
 int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev, const float* rowmajor_dev,
                                const uint16_t* bf16_dev, const float* xstats_dev, int64_t N, int d, const float* queries_dev,
-                               int nq, int k, int metric, int l2norm_queries, int64_t id_offset, float* D_dev, int64_t* I_dev,
+                               int nq, int k, int metric, int flags, int64_t id_offset, float* D_dev, int64_t* I_dev,
                                void* ws_dev, size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
     if (nq == 0) return MQ_OK;
     if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
+    if (flags & ~(MQ_KNN_FLAG_L2NORM_QUERIES | MQ_KNN_FLAG_TIE_ID_DESC)) return MQ_EINVAL;
+    const int l2norm_queries = (flags & MQ_KNN_FLAG_L2NORM_QUERIES) ? 1 : 0;
+    const unsigned flip = tie_flip(flags);
     const int l2 = metric == MQ_METRIC_L2;
     const int dp = screen_dp(d, metric);
     // packed_dev may be NULL (an index that keeps no panel copy): the exact-scan fallback and FAISS's small-batch L2 form then
@@ -1169,11 +1308,11 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     if (N <= 0 || d <= 0 || nq < 0 || k <= 0) return MQ_EINVAL;
     if (k > MQ_KNN_MAX_K) return MQ_EUNSUPPORTED;
     if (N >= 0xFFFFFFFFll) return MQ_EUNSUPPORTED;
-    const Geometry g = geometry(N, d, nq, k, num_cus());
+    const Geometry g = geometry(N, d, nq, k, num_cus(), metric);
     if (ws_bytes < g.total) return MQ_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (l2 && nq < MQ_KNN_L2_DIRECT_BELOW)
-        return knn_search_l2_direct(packed_dev, rowmajor_dev, N, d, queries_dev, nq, k, l2norm_queries, id_offset, D_dev, I_dev, ws_dev,
+        return knn_search_l2_direct(packed_dev, rowmajor_dev, N, d, queries_dev, nq, k, flags, id_offset, D_dev, I_dev, ws_dev,
                                     g, st);
     char* ws = (char*)ws_dev;
     float* Qp = (float*)(ws + g.off_qp);
@@ -1196,6 +1335,20 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, qtmp, (int64_t)nq, d);
         MQ_HIP(hipGetLastError());
         q_rm = qtmp;
+    }
+    if (k > KF) {
+        // More than 128 neighbours: the bounded screening buffers are sized for the reference's k = 100; the exact scan
+        // serves the call in ceil(k / 128) rounds (from the panel copy, or from the row-major copy of an index without one).
+        MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
+        hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((nq + PANEL - 1) / PANEL)), dim3(256), 0, st, q_rm, (int64_t)nq, d,
+                           g.dpad, (int64_t)0, 0, Qp, qn, (const int*)nullptr);
+        MQ_HIP(hipGetLastError());
+        ScanArgs a;
+        a.Xp = packed_dev ? packed_dev : rowmajor_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = pools; a.d = d;
+        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = nullptr; a.only = nullptr;
+        a.flip = flip; a.ceil = nullptr;
+        return exact_scan_rounds(metric, packed_dev == nullptr, a, g, nq, k, id_offset, D_dev, I_dev, ws, nullptr, st, ev_scan_begin,
+                                 ev_scan_end);
     }
     // The fp32 panel copy of the queries (+ ||q||^2) serves the exact-scan fallback -- and, for the L2 metric, the
     // re-scoring (||q||^2).  With the inner product it is made after the screened pipeline, for flagged tiles only.
@@ -1243,10 +1396,10 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
                        (const unsigned*)(ws + g.off_gthr), (const unsigned*)(ws + g.off_smax), g.ms, ovf, nq, g.S, k, cand, ccount);
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq, RMAX / 64), dim3(256), 0, st, rowmajor_dev, q_rm, d, cand, ccount, ckeys,
-                       l2 ? (const float*)qn : (const float*)nullptr, sqnorm_dev);
+                       l2 ? (const float*)qn : (const float*)nullptr, sqnorm_dev, flip);
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(final_select_kernel, dim3((unsigned)nq), dim3(64), 0, st, ckeys, ccount, ovf, k, (long long)id_offset, D_dev,
-                       (long long*)I_dev, l2);
+                       (long long*)I_dev, l2, flip);
     MQ_HIP(hipGetLastError());
     // 5. query tiles whose bounded buffers overflowed are recomputed by the exact scan (no-op otherwise:
     //    every workgroup of an unflagged tile returns at once)
@@ -1260,36 +1413,9 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         ScanArgs a;
         a.Xp = packed_dev ? packed_dev : rowmajor_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = pools; a.d = d;
         a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = nullptr; a.only = ovf;
-        const dim3 fgrid((unsigned)(g.nqt * g.S)), fblock(1024);
-        if (!packed_dev) {
-            if (l2) {
-                MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<MQ_METRIC_L2, true>);
-                hipLaunchKernelGGL((knn_scan_kernel<MQ_METRIC_L2, true>), fgrid, fblock, LDS_TOTAL, st, a);
-            } else {
-                MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<MQ_METRIC_IP, true>);
-                hipLaunchKernelGGL((knn_scan_kernel<MQ_METRIC_IP, true>), fgrid, fblock, LDS_TOTAL, st, a);
-            }
-            MQ_HIP(hipGetLastError());
-            if (l2)
-                hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(128), 0, st, pools, nq, g.S, k,
-                                   (long long)id_offset, D_dev, (long long*)I_dev, (const int*)ovf);
-            else
-                hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, st, pools, nq, g.S, k,
-                                   (long long)id_offset, D_dev, (long long*)I_dev, (const int*)ovf);
-        } else if (l2) {
-            MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<MQ_METRIC_L2>);
-            hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_L2>, dim3((unsigned)(g.nqt * g.S)), dim3(1024), LDS_TOTAL, st, a);
-            MQ_HIP(hipGetLastError());
-            hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(128), 0, st, pools, nq, g.S, k,
-                               (long long)id_offset, D_dev, (long long*)I_dev, (const int*)ovf);
-        } else {
-            MQ_DYNAMIC_LDS(LDS_TOTAL, knn_scan_kernel<MQ_METRIC_IP>);
-            hipLaunchKernelGGL(knn_scan_kernel<MQ_METRIC_IP>, dim3((unsigned)(g.nqt * g.S)), dim3(1024), LDS_TOTAL, st, a);
-            MQ_HIP(hipGetLastError());
-            hipLaunchKernelGGL(slab_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, st, pools, nq, g.S, k,
-                               (long long)id_offset, D_dev, (long long*)I_dev, (const int*)ovf);
-        }
-        MQ_HIP(hipGetLastError());
+        a.flip = flip; a.ceil = nullptr;
+        const int rc = exact_scan_rounds(metric, packed_dev == nullptr, a, g, nq, k, id_offset, D_dev, I_dev, ws, ovf, st, nullptr, nullptr);
+        if (rc != MQ_OK) return rc;
     }
     return MQ_OK;
 }
@@ -1298,7 +1424,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
  * out[1] = total candidates re-scored, out[2] = max candidates of one query.  Synchronises the stream. */
 int mq_knn_screen_stats(int64_t N, int d, int nq, int k, const void* ws_dev, int64_t out[8], void* stream) {
     if (!ws_dev || !out || nq <= 0) return MQ_EINVAL;
-    const Geometry g = geometry(N, d, nq, k, num_cus());
+    const Geometry g = geometry(N, d, nq, k, num_cus());  // the offsets read here do not depend on the metric
     MQ_HIP(hipStreamSynchronize((hipStream_t)stream));
     const size_t npc = (size_t)g.nqt * g.S * TQ * NSL;
     int* ovf = (int*)malloc((size_t)g.nqt * 4);
@@ -1332,17 +1458,27 @@ int mq_knn_screen_stats(int64_t N, int d, int nq, int k, const void* ws_dev, int
 }
 
 static int topk_merge_impl(const float* Ds_dev, const int64_t* Is_dev, size_t d_stride, size_t i_stride, int nshards, int nq,
-                           int k, int metric, float* D_dev, int64_t* I_dev, void* stream) {
+                           int k, int metric_and_tie, float* D_dev, int64_t* I_dev, void* stream) {
     if (nq == 0) return MQ_OK;
     if (!Ds_dev || !Is_dev || !D_dev || !I_dev || nshards <= 0 || nq < 0 || k <= 0) return MQ_EINVAL;
+    const bool desc = (metric_and_tie & MQ_MERGE_TIE_ID_DESC) != 0;
+    const int metric = metric_and_tie & ~MQ_MERGE_TIE_ID_DESC;
     if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
     if (k > MQ_KNN_MAX_K) return MQ_EUNSUPPORTED;
-    if (metric == MQ_METRIC_IP)
-        hipLaunchKernelGGL(shard_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, (hipStream_t)stream, Ds_dev,
-                           (const long long*)Is_dev, d_stride, i_stride, nshards, nq, k, D_dev, (long long*)I_dev);
+    hipStream_t st = (hipStream_t)stream;
+    if (k > KF) {
+        if (metric == MQ_METRIC_IP)
+            hipLaunchKernelGGL(shard_merge_big_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(256), 0, st, Ds_dev, (const long long*)Is_dev,
+                               d_stride, i_stride, nshards, nq, k, D_dev, (long long*)I_dev, desc);
+        else
+            hipLaunchKernelGGL(shard_merge_big_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(256), 0, st, Ds_dev, (const long long*)Is_dev,
+                               d_stride, i_stride, nshards, nq, k, D_dev, (long long*)I_dev, desc);
+    } else if (metric == MQ_METRIC_IP)
+        hipLaunchKernelGGL(shard_merge_kernel<MQ_METRIC_IP>, dim3((unsigned)nq), dim3(128), 0, st, Ds_dev,
+                           (const long long*)Is_dev, d_stride, i_stride, nshards, nq, k, D_dev, (long long*)I_dev, desc);
     else
-        hipLaunchKernelGGL(shard_merge_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(128), 0, (hipStream_t)stream, Ds_dev,
-                           (const long long*)Is_dev, d_stride, i_stride, nshards, nq, k, D_dev, (long long*)I_dev);
+        hipLaunchKernelGGL(shard_merge_kernel<MQ_METRIC_L2>, dim3((unsigned)nq), dim3(128), 0, st, Ds_dev,
+                           (const long long*)Is_dev, d_stride, i_stride, nshards, nq, k, D_dev, (long long*)I_dev, desc);
     MQ_HIP(hipGetLastError());
     return MQ_OK;
 }

@@ -37,7 +37,9 @@ from . import _lib
 
 METRIC_INNER_PRODUCT = 0  # faiss.METRIC_INNER_PRODUCT
 METRIC_L2 = 1  # faiss.METRIC_L2
-MAX_K = 128
+MAX_K = 2048  # MQ_KNN_MAX_K; one fused scan keeps 128, a larger k runs ceil(k / 128) exact scans (include/meerqat_hip.h)
+FLAG_L2NORM_QUERIES, FLAG_TIE_ID_DESC, MERGE_TIE_ID_DESC = 1, 2, 0x100  # MQ_KNN_FLAG_*, MQ_MERGE_TIE_ID_DESC
+TIE_ORDERS = ("id_asc", "id_desc")
 _MAGIC = b"MQFLAT01"
 _UPLOAD_ROWS = 1 << 16  # rows per host->device staging copy (multiple of 64)
 _QUERY_CHUNK = 1 << 14
@@ -110,7 +112,7 @@ class MI355XFlatIndex(BaseIndex):
 
     def __init__(self, device: Optional[Union[int, list]] = None, string_factory: Optional[str] = None,
                  metric_type: Optional[int] = None, custom_index=None, id_offset: int = 0, screen: Optional[bool] = None,
-                 keep_panel: Optional[bool] = None):
+                 keep_panel: Optional[bool] = None, tie_order: Optional[str] = None):
         if custom_index is not None:
             raise ValueError("custom_index is a FAISS object; MI355XFlatIndex builds its own index")
         self.device = device
@@ -120,6 +122,14 @@ class MI355XFlatIndex(BaseIndex):
         if self.metric_type not in (METRIC_INNER_PRODUCT, METRIC_L2):
             raise ValueError(f"Unsupported metric_type {metric_type} (0 = inner product, 1 = L2)")
         self.do_l2norm = parse_string_factory(string_factory)
+        # Which of several EXACTLY tied rows is the better one: "id_asc" (default, the lower id) or "id_desc" (the higher
+        # id), for membership at the k-th boundary and output order alike.  Both are this library's documented policies;
+        # FAISS's own behaviour on exact ties depends on its version and on k (oracle/knn_oracle.c).
+        # MQ_KNN_TIE_ORDER sets the default.
+        tie_order = tie_order or os.environ.get("MQ_KNN_TIE_ORDER", "id_asc")
+        if tie_order not in TIE_ORDERS:
+            raise ValueError(f"tie_order must be one of {TIE_ORDERS}, got {tie_order!r}")
+        self.tie_order = tie_order
         self.id_offset = int(id_offset)
         self.ntotal = 0
         self.d = None
@@ -347,8 +357,7 @@ class MI355XFlatIndex(BaseIndex):
         if k < 1:
             raise ValueError("k must be >= 1")
         if k > MAX_K:
-            raise NotImplementedError(f"k={k} > {MAX_K}: the fused MI355X scan keeps at most {MAX_K} neighbours "
-                                      "(the reference uses k=100)")
+            raise NotImplementedError(f"k={k} > {MAX_K} (MQ_KNN_MAX_K, FAISS-GPU's own limit)")
         nq = queries.shape[0]
         if self.ntotal == 0:
             raise ValueError("the index is empty: call add_vectors first")
@@ -367,19 +376,21 @@ class MI355XFlatIndex(BaseIndex):
             chunk = _SCREEN_QUERY_CHUNK if self.screen else _QUERY_CHUNK
             for s, e in query_chunks(nq, chunk):
                 q = queries[s:e]
-                nb = int(lib.mq_knn_workspace_bytes(self.ntotal, self.d, q.shape[0], k))
+                self._last_call_nq = e - s  # screen_stats reads the workspace geometry of the LAST C-ABI call
+                nb = int(lib.mq_knn_workspace_bytes_metric(self.ntotal, self.d, q.shape[0], k, self.metric_type))
                 ws = self._workspace(nb)
                 Dq, Iq = D[s:e], I[s:e]
+                flags = (FLAG_L2NORM_QUERIES if self.do_l2norm else 0) | (FLAG_TIE_ID_DESC if self.tie_order == "id_desc" else 0)
                 if self.screen:
                     _lib.check(lib.mq_knn_search_screened_f32(
                         self._packed.data_ptr() if self._packed is not None else None, self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(),
                         self._xmax2.data_ptr(), self.ntotal, self.d, q.data_ptr(), q.shape[0], k, self.metric_type,
-                        int(self.do_l2norm),
+                        flags,
                         self.id_offset, Dq.data_ptr(), Iq.data_ptr(), ws.data_ptr(), ws.numel(), stream, None, None),
                         "mq_knn_search_screened_f32")
                 else:
                     _lib.check(lib.mq_knn_search_f32(self._packed.data_ptr(), self._sqnorm.data_ptr(), self.ntotal, self.d,
-                                                     q.data_ptr(), q.shape[0], k, self.metric_type, int(self.do_l2norm),
+                                                     q.data_ptr(), q.shape[0], k, self.metric_type, flags,
                                                      self.id_offset, Dq.data_ptr(), Iq.data_ptr(), ws.data_ptr(), ws.numel(),
                                                      stream), "mq_knn_search_f32")
         return D, I
@@ -440,7 +451,8 @@ class MI355XFlatIndex(BaseIndex):
         import ctypes
         lib = _lib.load()
         if nq > _SCREEN_QUERY_CHUNK:
-            nq = nq % _SCREEN_QUERY_CHUNK or _SCREEN_QUERY_CHUNK
+            # the size of the last piece search_device cut (query_chunks moves 40 queries into a short tail)
+            nq = getattr(self, "_last_call_nq", None) or query_chunks(nq, _SCREEN_QUERY_CHUNK)[-1][1] - query_chunks(nq, _SCREEN_QUERY_CHUNK)[-1][0]
         out = (ctypes.c_int64 * 8)()
         _lib.check(lib.mq_knn_screen_stats(self.ntotal, self.d, nq, k, self._ws.data_ptr(), out,
                                            __import__("torch").cuda.current_stream(self._torch_device).cuda_stream))
@@ -471,13 +483,13 @@ class MI355XFlatIndex(BaseIndex):
             f.write(rows.tobytes())
 
     @classmethod
-    def load(cls, file: Union[str, PurePath], device=None, storage_options: Optional[dict] = None):
+    def load(cls, file: Union[str, PurePath], device=None, storage_options: Optional[dict] = None, tie_order=None):
         """FaissIndex.load (datasets/search.py:399-416).  Reads this class's own files and the FAISS files
         the reference's ``save_path`` / ``dataset.save_faiss_index`` wrote for the factories it ships
         (IndexFlat, and IndexPreTransform(NormalizationTransform, IndexFlat) for "L2norm,Flat")."""
         path = os.fspath(file)
         n, d, metric, l2norm, data_off = read_index_file_header(path)
-        idx = cls(device=device, string_factory="L2norm,Flat" if l2norm else "Flat", metric_type=metric)
+        idx = cls(device=device, string_factory="L2norm,Flat" if l2norm else "Flat", metric_type=metric, tie_order=tie_order)
         if n:
             rows = np.fromfile(path, dtype=np.float32, count=n * d, offset=data_off).reshape(n, d)
             # rows were stored after normalisation: do not normalise twice on load
@@ -557,20 +569,28 @@ def read_index_file_header(path):
     raise ValueError(f"{path} is neither an MI355XFlatIndex file nor a FAISS Flat index file")
 
 
-def iter_arrow_column(dataset, column):
+def iter_arrow_column(dataset, column, start=0, stop=None):
     """Yields numpy [rows,d] fp32 blocks of a ``list<float>`` column without going through Python
-    lists (the reference's add loop: datasets/search.py:311-313 -> list -> ndarray)."""
+    lists (the reference's add loop: datasets/search.py:311-313 -> list -> ndarray).  ``start`` / ``stop``
+    restrict the walk to a row range (a rank's shard): only those rows are decoded or read."""
     import pyarrow as pa
     table = getattr(dataset, "data", None)
     indices = getattr(dataset, "_indices", None)
+    n_rows = len(dataset)
+    stop = n_rows if stop is None else min(int(stop), n_rows)
+    start = max(0, int(start))
+    if start >= stop:
+        return
     if table is None or indices is not None:
         # selected/shuffled dataset: fall back to formatted access, still batched
         ds = dataset.with_format("numpy", columns=[column])
-        for i in range(0, len(ds), 1 << 15):
-            block = ds[i:i + (1 << 15)][column]
+        for i in range(start, stop, 1 << 15):
+            block = ds[i:min(i + (1 << 15), stop)][column]
             yield np.ascontiguousarray(np.stack(block) if isinstance(block, list) else block, dtype=np.float32)
         return
     col = table.column(column)
+    if start or stop < n_rows:
+        col = col.slice(start, stop - start)  # zero-copy: the chunks outside the range are never touched
     for chunk in col.chunks:
         if len(chunk) == 0:
             continue

@@ -130,13 +130,15 @@ class KnowledgeBase:
 
     def add_or_load_faiss_index(self, column, index_name=None, load=False, save_path=None, string_factory=None,
                                 device=None, metric_type=None, batch_size=1000, train_size=None, file=None,
-                                faiss_verbose=None, **kwargs):
+                                faiss_verbose=None, tie_order=None, **kwargs):
         """Builds (or loads from ``file``) the exact index over ``column`` and registers it as
         ``index_name``.  Returns ``do_L2norm`` (inferred from 'L2norm' in ``string_factory``).
 
         The reference's GPU work-around (normalise the column with numpy, strip "L2norm" from the
         factory; meerqat/ir/search.py:238-244) is unnecessary here: the "L2norm," transform is
-        applied on device while packing (csrc/knn.hip), for any ``device``."""
+        applied on device while packing (csrc/knn.hip), for any ``device``.  ``tie_order`` (extra key, "id_asc" |
+        "id_desc"): which of several EXACTLY tied rows ranks first -- this library's policy knob, see
+        viquae_amd.index.MI355XFlatIndex and INTEGRATION.md section D."""
         if kwargs:
             warnings.warn(f"add_or_load_faiss_index: ignoring unknown arguments {sorted(kwargs)}")
         if index_name is None:
@@ -148,19 +150,15 @@ class KnowledgeBase:
         if load:
             if file is None:
                 raise ValueError("load=True needs `file` (the path passed to save_faiss_index / save_path)")
-            index = make_flat_index(device=device, string_factory=string_factory, metric_type=metric_type)
+            index = make_flat_index(device=device, string_factory=string_factory, metric_type=metric_type, tie_order=tie_order)
             if isinstance(index, ShardedFlatIndex):
                 index.load_rows(file)  # every rank reads only its own row range
             elif isinstance(index, MI355XFlatIndex):
-                index = MI355XFlatIndex.load(file, device=device)
+                index = MI355XFlatIndex.load(file, device=device, tie_order=tie_order)
             else:
-                from ..index import read_index_file_header
-                n, d, metric, l2norm, off = read_index_file_header(file)
-                index = make_flat_index(device=device, string_factory="Flat", metric_type=metric)  # rows already normalised
-                index.add_vectors(np.fromfile(file, dtype=np.float32, count=n * d, offset=off).reshape(n, d))
-                index.do_l2norm = bool(l2norm)
+                index.load_rows(file)  # LocalShardsFlatIndex: metric and "L2norm," from the file, set on EVERY shard
         else:
-            index = make_flat_index(device=device, string_factory=string_factory, metric_type=metric_type)
+            index = make_flat_index(device=device, string_factory=string_factory, metric_type=metric_type, tie_order=tie_order)
             index.add_vectors(self.dataset, column=column, batch_size=batch_size, train_size=train_size,
                               faiss_verbose=faiss_verbose)
             if save_path is not None:

@@ -73,7 +73,13 @@ def _gathered_views(buf, world, nq, k):
     return Ds, Is
 
 
-def _hip_merge_records(records, world, nq, k, metric):
+def _merge_metric(metric, tie_order):
+    """`metric` argument of the mq_topk_merge_* entries: the metric, OR-ed with MQ_MERGE_TIE_ID_DESC."""
+    from .index import MERGE_TIE_ID_DESC
+    return int(metric) | (MERGE_TIE_ID_DESC if tie_order == "id_desc" else 0)
+
+
+def _hip_merge_records(records, world, nq, k, metric, tie_order="id_asc"):
     """All-gathered records (CUDA uint8 [world * record_bytes]) -> merged (D, I) through the C ABI."""
     import torch
     from . import _lib
@@ -81,13 +87,13 @@ def _hip_merge_records(records, world, nq, k, metric):
     D = torch.empty((nq, k), dtype=torch.float32, device=records.device)
     I = torch.empty((nq, k), dtype=torch.int64, device=records.device)
     with torch.cuda.device(records.device):
-        _lib.check(lib.mq_topk_merge_records_f32(records.data_ptr(), world, nq, k, int(metric), D.data_ptr(), I.data_ptr(),
+        _lib.check(lib.mq_topk_merge_records_f32(records.data_ptr(), world, nq, k, _merge_metric(metric, tie_order), D.data_ptr(), I.data_ptr(),
                                                  torch.cuda.current_stream(records.device).cuda_stream),
                    "mq_topk_merge_records_f32")
     return D, I
 
 
-def _hip_merge(Ds, Is, metric):
+def _hip_merge(Ds, Is, metric, tie_order="id_asc"):
     """[W,nq,k] contiguous CUDA tensors -> merged (D, I) through mq_topk_merge_f32."""
     import torch
     from . import _lib
@@ -97,7 +103,7 @@ def _hip_merge(Ds, Is, metric):
     D = torch.empty((nq, k), dtype=torch.float32, device=Ds.device)
     I = torch.empty((nq, k), dtype=torch.int64, device=Ds.device)
     with torch.cuda.device(Ds.device):
-        _lib.check(lib.mq_topk_merge_f32(Ds.data_ptr(), Is.data_ptr(), W, nq, k, int(metric), D.data_ptr(),
+        _lib.check(lib.mq_topk_merge_f32(Ds.data_ptr(), Is.data_ptr(), W, nq, k, _merge_metric(metric, tie_order), D.data_ptr(),
                                          I.data_ptr(), torch.cuda.current_stream(Ds.device).cuda_stream),
                    "mq_topk_merge_f32")
     return D, I
@@ -137,7 +143,7 @@ class _ShardedBase(BaseIndex):
 
 class ShardedFlatIndex(_ShardedBase):
     def __init__(self, string_factory: Optional[str] = None, metric_type: Optional[int] = None, group=None,
-                 local_index=None, merge_fn=None, device=None, screen=None, always_gather=False):
+                 local_index=None, merge_fn=None, device=None, screen=None, always_gather=False, tie_order=None):
         import torch.distributed as dist
         self.group = group
         # always_gather: run the collective and the record merge even with ONE rank (tests / 1-GPU profiling of the N>1 path)
@@ -149,10 +155,12 @@ class ShardedFlatIndex(_ShardedBase):
         self.do_l2norm = parse_string_factory(string_factory)
         if local_index is None:
             from .index import _resolve_device
-            local_index = MI355XFlatIndex(device=device, string_factory=string_factory, metric_type=metric_type, screen=screen)
+            local_index = MI355XFlatIndex(device=device, string_factory=string_factory, metric_type=metric_type, screen=screen,
+                                          tie_order=tie_order)
             # resolved NOW: a rank whose shard turns out empty still needs a device for its records
             local_index._torch_device = _resolve_device(device)
         self.local = local_index
+        self.tie_order = getattr(local_index, "tie_order", None) or tie_order or "id_asc"
         self.merge_fn = merge_fn  # None -> mq_topk_merge_records_f32 on the gathered buffer
         self.ntotal = 0
         self.d = getattr(local_index, "d", None)
@@ -185,21 +193,19 @@ class ShardedFlatIndex(_ShardedBase):
             n = len(vectors)
             lo, hi = shard_bounds(n, self.world, self.rank)
             self.local.id_offset = lo
-            seen = 0
             pend = None
             d = None
-            for block in iter_arrow_column(vectors, column):
-                d = block.shape[1]
-                b_lo, b_hi = seen, seen + block.shape[0]
-                seen = b_hi
-                s, e = max(lo, b_lo), min(hi, b_hi)
-                if s < e:
-                    part = block[s - b_lo:e - b_lo]
-                    pend = part if pend is None else np.concatenate([pend, part])
-                    full = (pend.shape[0] // 64) * 64
-                    if full:
-                        self.local.add(pend[:full], total_hint=hi - lo)
-                        pend = pend[full:]
+            # only THIS rank's rows are decoded (host time and IO scale with N, not world x N)
+            for part in iter_arrow_column(vectors, column, lo, hi):
+                d = part.shape[1]
+                pend = part if pend is None else np.concatenate([pend, part])
+                full = (pend.shape[0] // 64) * 64
+                if full:
+                    self.local.add(pend[:full], total_hint=hi - lo)
+                    pend = pend[full:]
+            if d is None and n:  # an empty shard still needs the dimension
+                for first in iter_arrow_column(vectors, column, 0, 1):
+                    d = first.shape[1]
             if pend is not None and pend.shape[0]:
                 self.local.add(pend, total_hint=hi - lo)
             self._set_total(n, d)
@@ -224,8 +230,10 @@ class ShardedFlatIndex(_ShardedBase):
 
     def _merge(self, gathered, nq, k):
         if self.merge_fn is None:
-            return _hip_merge_records(gathered, self.world, nq, k, self.metric_type)
+            return _hip_merge_records(gathered, self.world, nq, k, self.metric_type, self.tie_order)
         Ds, Is = _gathered_views(gathered, self.world, nq, k)
+        if self.tie_order != "id_asc":
+            return self.merge_fn(Ds, Is, self.metric_type, tie_order=self.tie_order)
         return self.merge_fn(Ds, Is, self.metric_type)
 
     def search_device(self, queries, k, chunk=None):
@@ -306,13 +314,18 @@ class ShardedFlatIndex(_ShardedBase):
         n, d, metric, l2norm, data_off = read_index_file_header(path)
         lo, hi = shard_bounds(n, self.world, self.rank)
         self.local.id_offset = lo
+        # FaissIndex.load reads metric and transform from the FILE (datasets/search.py:399-416): a load config may omit
+        # string_factory / metric_type, so the shard must scan with what the file says, like _merge and _fill_empty do
+        if getattr(self.local, "ntotal", 0):
+            raise ValueError("load_rows fills an EMPTY sharded index")
         self.metric_type, self.do_l2norm = int(metric), bool(l2norm)
+        self.string_factory = "L2norm,Flat" if l2norm else "Flat"
+        self.local.metric_type = int(metric)
         if hi > lo:
             rows = np.fromfile(path, dtype=np.float32, count=(hi - lo) * d, offset=data_off + lo * d * 4).reshape(hi - lo, d)
-            keep = getattr(self.local, "do_l2norm", False)
             self.local.do_l2norm = False  # stored rows are already normalised
             self.local.add(rows, total_hint=hi - lo)
-            self.local.do_l2norm = keep
+        self.local.do_l2norm = bool(l2norm)
         self._set_total(n, d)
         return self
 
@@ -322,7 +335,7 @@ class LocalShardsFlatIndex(_ShardedBase):
     copied peer-to-peer to the first device, merged there."""
 
     def __init__(self, devices, string_factory: Optional[str] = None, metric_type: Optional[int] = None, screen=None,
-                 allow_repeated_devices=False):
+                 allow_repeated_devices=False, tie_order=None):
         import torch
         from . import _lib
         _lib.require_gpu()
@@ -337,8 +350,9 @@ class LocalShardsFlatIndex(_ShardedBase):
         self.metric_type = METRIC_L2 if metric_type is None else int(metric_type)
         self.string_factory = string_factory
         self.do_l2norm = parse_string_factory(string_factory)
-        self.shards = [MI355XFlatIndex(device=g, string_factory=string_factory, metric_type=metric_type, screen=screen)
-                       for g in devices]
+        self.shards = [MI355XFlatIndex(device=g, string_factory=string_factory, metric_type=metric_type, screen=screen,
+                                       tie_order=tie_order) for g in devices]
+        self.tie_order = self.shards[0].tie_order
         for sh, g in zip(self.shards, devices):
             sh._torch_device = torch.device("cuda", g)
         self.ntotal = 0
@@ -381,6 +395,26 @@ class LocalShardsFlatIndex(_ShardedBase):
                 self.shards[r].add(pend[r], total_hint=hi - lo)
         self.ntotal = n
 
+    def load_rows(self, file):
+        """Fill this (empty) index from a whole-matrix file (own format or a FAISS Flat file): metric and the "L2norm,"
+        transform come from the file, like FaissIndex.load; the stored rows are already normalised, the QUERIES of every
+        shard are normalised at search time."""
+        from .index import read_index_file_header
+        path = os.fspath(file)
+        n, d, metric, l2norm, data_off = read_index_file_header(path)
+        if self.ntotal:
+            raise ValueError("load_rows fills an EMPTY index")
+        self.metric_type, self.do_l2norm = int(metric), bool(l2norm)
+        self.string_factory = "L2norm,Flat" if l2norm else "Flat"
+        for sh in self.shards:
+            sh.metric_type, sh.do_l2norm = int(metric), False
+        if n:
+            self.add_vectors(np.memmap(path, dtype=np.float32, mode="r", offset=data_off, shape=(n, d)))
+        for sh in self.shards:
+            sh.do_l2norm = bool(l2norm)
+        self.ntotal, self.d = n, (d or None)
+        return self
+
     def search_device(self, queries, k):
         import torch
         if k < 1:
@@ -408,7 +442,7 @@ class LocalShardsFlatIndex(_ShardedBase):
         for r, record in enumerate(records):
             if record.device != dev0:
                 gathered[r * rec_bytes:(r + 1) * rec_bytes].copy_(record, non_blocking=True)  # peer-to-peer over xGMI
-        return _hip_merge_records(gathered, self.world, nq, k, self.metric_type)
+        return _hip_merge_records(gathered, self.world, nq, k, self.metric_type, self.tie_order)
 
     def save(self, file, storage_options=None):
         path = os.fspath(file)
@@ -426,7 +460,7 @@ def visible_gpus():
     return list(range(torch.cuda.device_count()))
 
 
-def make_flat_index(device=None, string_factory=None, metric_type=None, screen=None):
+def make_flat_index(device=None, string_factory=None, metric_type=None, screen=None, tie_order=None):
     """The index ``KnowledgeBase.add_or_load_faiss_index`` builds, chosen as the reference's ``device``
     key is documented (datasets/search.py:315-347: int >= 0 -> that GPU, int < 0 -> all GPUs, list ->
     those GPUs; None = CPU FAISS there, the process's current GPU here):
@@ -436,13 +470,16 @@ def make_flat_index(device=None, string_factory=None, metric_type=None, screen=N
     * ``device=-1`` / a list of several GPUs in a single process: ``LocalShardsFlatIndex``;
     * otherwise one ``MI355XFlatIndex``."""
     import torch.distributed as dist
+    kw = dict(string_factory=string_factory, metric_type=metric_type, screen=screen)
+    if tie_order is not None:  # only forwarded when asked for: "id_asc" is every class's default
+        kw["tie_order"] = tie_order
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return ShardedFlatIndex(string_factory=string_factory, metric_type=metric_type, device=None, screen=screen)
+        return ShardedFlatIndex(device=None, **kw)
     if isinstance(device, int) and not isinstance(device, bool) and device < 0:
         gpus = visible_gpus()
         if len(gpus) > 1:
-            return LocalShardsFlatIndex(gpus, string_factory=string_factory, metric_type=metric_type, screen=screen)
+            return LocalShardsFlatIndex(gpus, **kw)
         device = 0
     elif isinstance(device, (list, tuple)) and len(device) > 1:
-        return LocalShardsFlatIndex(list(device), string_factory=string_factory, metric_type=metric_type, screen=screen)
-    return MI355XFlatIndex(device=device, string_factory=string_factory, metric_type=metric_type, screen=screen)
+        return LocalShardsFlatIndex(list(device), **kw)
+    return MI355XFlatIndex(device=device, **kw)
