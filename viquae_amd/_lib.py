@@ -100,7 +100,10 @@ def load():
             f"{path} is missing: build it with `python -m viquae_amd.build` (hipcc, gfx950). "
             "viquae_amd has no CPU fallback.")
     lib = ctypes.CDLL(path)
+    ab = bool(os.environ.get("MEERQAT_HIP_LIB"))
     for name, (res, args) in SIGNATURES.items():
+        if ab and not hasattr(lib, name):
+            continue  # A/B against an OLDER build of the ABI (developer switch): entries it lacks stay unbound
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
