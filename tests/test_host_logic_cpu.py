@@ -304,3 +304,33 @@ def test_bench_gpus_n_starts_its_own_ranks_before_touching_a_gpu(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "only 2 GPU" in str(e.value.code) and not seen
+
+
+def test_faiss_file_writer_round_trips_through_the_reader_and_matches_the_hand_assembled_layout(tmp_path):
+    """save() of a "*.faiss" / "*.index" path (or format="faiss") writes what faiss.write_index writes for IndexFlat /
+    IndexPreTransform + NormalizationTransform + IndexFlat (meerqat/ir/search.py:247-248: save_faiss_index): byte-identical
+    to the hand-assembled files of the reader test above, and read back by read_index_file_header."""
+    import struct
+    from viquae_amd.index import index_file_format, index_file_header, read_index_file_header
+    X = np.arange(12, dtype=np.float32).reshape(4, 3)
+
+    def hdr(d, n, metric):
+        return struct.pack("<iqqq?i", d, n, 1 << 20, 1 << 20, True, metric)
+
+    assert index_file_header(4, 3, 1, False, "faiss") == b"IxF2" + hdr(3, 4, 1) + struct.pack("<Q", 12)
+    assert index_file_header(4, 3, 0, True, "faiss") == (b"IxPT" + hdr(3, 4, 0) + struct.pack("<i", 1) + b"VNrm" + struct.pack("<f", 2.0)
+                                                         + struct.pack("<ii?", 3, 3, True) + b"IxFI" + hdr(3, 4, 0) + struct.pack("<Q", 12))
+    assert index_file_format("kb/dpr.faiss") == "faiss" and index_file_format("kb/dpr.index") == "faiss"
+    assert index_file_format("kb/dpr.bin") == "mqflat" and index_file_format("kb/dpr.bin", "faiss") == "faiss"
+    with pytest.raises(ValueError):
+        index_file_format("x", "hnsw")
+    for metric, l2norm, fmt in ((0, False, "faiss"), (1, False, "faiss"), (0, True, "faiss"), (1, True, "faiss"), (0, True, "mqflat")):
+        p = tmp_path / f"m{metric}{int(l2norm)}.{fmt}"
+        head = index_file_header(4, 3, metric, l2norm, fmt)
+        p.write_bytes(head + X.tobytes())
+        n, d, m, l2, off = read_index_file_header(str(p))
+        assert (n, d, m, l2, off) == (4, 3, metric, l2norm, len(head))
+    # an empty index still has a readable header
+    p = tmp_path / "empty.faiss"
+    p.write_bytes(index_file_header(0, 3, 0, False, "faiss"))
+    assert read_index_file_header(str(p))[:4] == (0, 3, 0, False)

@@ -77,6 +77,15 @@ def _worker(rank, world, port, metric, n, out):
         assert again.ntotal == n and again.local.id_offset == lo
         D3, I3 = again.search_batch(Q, 20)
         assert np.array_equal(D3, D) and np.array_equal(I3, I)
+        # "*.index" is written in FAISS's own file format (IndexFlat), any other name in this build's: both load
+        with open(path, "rb") as f:
+            assert f.read(4) == (b"IxFI" if metric == 0 else b"IxF2")
+        idx.save(out + ".rows")
+        with open(out + ".rows", "rb") as f:
+            assert f.read(8) == b"MQFLAT01"
+        D4, I4 = ShardedFlatIndex(string_factory="Flat", metric_type=metric, local_index=_OracleLocal(metric),
+                                  merge_fn=_oracle_merge).load_rows(out + ".rows").search_batch(Q, 20)
+        assert np.array_equal(D4, D) and np.array_equal(I4, I)
         if rank == 0:
             np.savez(out, D=D, I=I, X=X, Q=Q)
         dist.barrier()

@@ -260,3 +260,40 @@ def test_sharded_load_rows_takes_metric_and_transform_from_the_file(tmp_path):
     sh = ShardedFlatIndex().load_rows(path)   # defaults: "Flat", L2 -- the file says "L2norm,Flat", inner product
     assert sh.metric_type == 0 and sh.local.metric_type == 0 and sh.local.do_l2norm and sh.do_l2norm
     _same(sh.search_batch(Q, 20), want, "ShardedFlatIndex.load_rows")
+
+
+@pytest.mark.parametrize("metric,factory", [(0, "Flat"), (1, "Flat"), (0, "L2norm,Flat")])
+def test_save_in_faiss_format_and_load_back(tmp_path, metric, factory):
+    """the reference's save_path (meerqat/ir/search.py:247-248) produces a file FAISS reads back; `save`
+    of a "*.faiss" path writes that layout (IxFI / IxF2, IxPT + VNrm for "L2norm,Flat") and `load` returns the same index."""
+    import datasets
+    from viquae_amd.index import MI355XFlatIndex, read_index_file_header
+    from viquae_amd.ir.search import KnowledgeBase
+    from viquae_amd.sharded import LocalShardsFlatIndex
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((1500, 40), dtype=np.float32) * 2
+    Q = rng.standard_normal((30, 40), dtype=np.float32)
+    ds = datasets.Dataset.from_dict({"vec": [r for r in X]})
+    path = str(tmp_path / "kb.faiss")
+    kb = KnowledgeBase(dataset=ds, index_kwargs={"idx": {"column": "vec", "string_factory": factory, "metric_type": metric,
+                                                          "save_path": path}})
+    want = kb.search_batch("idx", Q, k=60)
+    with open(path, "rb") as f:
+        assert f.read(4) == (b"IxPT" if "L2norm" in factory else (b"IxFI" if metric == 0 else b"IxF2"))
+    n, d, m, l2, off = read_index_file_header(path)
+    assert (n, d, m, l2) == (1500, 40, metric, "L2norm" in factory)
+    back = MI355XFlatIndex.load(path)
+    assert back.do_l2norm == ("L2norm" in factory) and back.metric_type == metric
+    # KnowledgeBase.search_batch normalises the queries on the host as well (idempotent): hand the index the same input
+    from viquae_amd.ir.search import L2norm
+    q_in = L2norm(Q) if "L2norm" in factory else Q
+    got = back.search_batch(q_in, 60)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+    kb2 = KnowledgeBase(dataset=ds, index_kwargs={"idx": {"column": "vec", "load": True, "file": path, "string_factory": factory}})
+    got2 = kb2.search_batch("idx", Q, k=60)
+    assert np.array_equal(got2[1], want[1]) and np.array_equal(got2[0], want[0])
+    # a multi-shard index writes the same file
+    sh = LocalShardsFlatIndex([0, 0, 0], string_factory=factory, metric_type=metric, allow_repeated_devices=True)
+    sh.add_vectors(X)
+    sh.save(str(tmp_path / "kb_shards.faiss"))
+    assert open(str(tmp_path / "kb_shards.faiss"), "rb").read() == open(path, "rb").read()

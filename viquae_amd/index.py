@@ -473,13 +473,16 @@ class MI355XFlatIndex(BaseIndex):
         torch.cuda.current_stream(self._torch_device).synchronize()
         return out.cpu().numpy()
 
-    def save(self, file: Union[str, PurePath], storage_options: Optional[dict] = None):
-        """FaissIndex.save (datasets/search.py:387-397).  Format: 8-byte magic, int64 N, int32 d,
+    def save(self, file: Union[str, PurePath], storage_options: Optional[dict] = None, format: Optional[str] = None):
+        """FaissIndex.save (datasets/search.py:387-397; the reference's ``save_path``, meerqat/ir/search.py:247-248).
+        Two formats, both read back by :meth:`load` (see :func:`index_file_header`): "faiss" -- the file
+        ``faiss.write_index`` produces for this index (IndexFlat, or IndexPreTransform + NormalizationTransform + IndexFlat
+        for "L2norm,Flat"), readable by FAISS itself -- when the path ends in ``.faiss`` / ``.index`` or on request
+        (``format="faiss"`` / MQ_INDEX_FORMAT=faiss); otherwise this build's own "mqflat": 8-byte magic, int64 N, int32 d,
         int32 metric, int32 l2norm, int32 reserved, then N*d fp32 row-major (rows as stored)."""
         rows = self.reconstruct_n() if self.ntotal else np.zeros((0, self.d or 0), np.float32)
         with open(os.fspath(file), "wb") as f:
-            f.write(_MAGIC)
-            f.write(struct.pack("<qiiii", self.ntotal, self.d or 0, self.metric_type, int(self.do_l2norm), 0))
+            f.write(index_file_header(self.ntotal, self.d or 0, self.metric_type, self.do_l2norm, index_file_format(file, format)))
             f.write(rows.tobytes())
 
     @classmethod
@@ -499,6 +502,36 @@ class MI355XFlatIndex(BaseIndex):
         else:
             idx.d = d or None
         return idx
+
+
+def index_file_format(path, format=None):
+    """"faiss" or "mqflat" for a file about to be written: the explicit ``format``, else MQ_INDEX_FORMAT, else by extension
+    (``.faiss`` / ``.index``: what the reference's users call their ``save_path`` files)."""
+    fmt = format or os.environ.get("MQ_INDEX_FORMAT")
+    if fmt is None:
+        fmt = "faiss" if str(path).endswith((".faiss", ".index")) else "mqflat"
+    if fmt not in ("faiss", "mqflat"):
+        raise ValueError(f"unknown index file format {fmt!r} (faiss | mqflat)")
+    return fmt
+
+
+def index_file_header(n, d, metric, l2norm, fmt):
+    """The bytes in front of the row-major fp32 matrix of an index file (its length = the matrix's offset).  "faiss": what
+    faiss/impl/index_write.cpp writes for IndexFlat / IndexPreTransform(NormalizationTransform(d, 2.0), IndexFlat), as
+    published for faiss >= 1.7.1 (see _read_faiss_flat; no FAISS binary in this image: the writer is checked against this
+    reader and against the hand-assembled files of tests/test_host_logic_cpu.py, not against FAISS itself)."""
+    n, d, metric = int(n), int(d), int(metric)
+    if fmt == "mqflat":
+        return _MAGIC + struct.pack("<qiiii", n, d, metric, int(bool(l2norm)), 0)
+
+    def hdr():  # write_index_header: d, ntotal, two dummies (1 << 20), is_trained, metric_type
+        return struct.pack("<iqqq?i", d, n, 1 << 20, 1 << 20, True, metric)
+
+    flat = (b"IxFI" if metric == METRIC_INNER_PRODUCT else b"IxF2") + hdr() + struct.pack("<Q", n * d)
+    if not l2norm:
+        return flat
+    # IndexPreTransform: header, chain length, NormalizationTransform {"VNrm", norm, d_in, d_out, is_trained}, sub-index
+    return b"IxPT" + hdr() + struct.pack("<i", 1) + b"VNrm" + struct.pack("<f", 2.0) + struct.pack("<ii?", d, d, True) + flat
 
 
 def _read_faiss_flat(f, path):

@@ -29,7 +29,7 @@ from typing import Optional
 import numpy as np
 
 from .index import (BatchedSearchResults, BaseIndex, SearchResults, MI355XFlatIndex, METRIC_L2, MAX_K,
-                    _SCREEN_QUERY_CHUNK, _MAGIC, parse_string_factory, query_chunks)
+                    _SCREEN_QUERY_CHUNK, index_file_format, index_file_header, parse_string_factory, query_chunks)
 
 
 _FLT_MAX = float(np.finfo(np.float32).max)
@@ -285,24 +285,24 @@ class ShardedFlatIndex(_ShardedBase):
         return D, I
 
     # ---------------------------------------------------------------- persistence
-    def save(self, file, storage_options=None):
-        """One file in MI355XFlatIndex's format holding the WHOLE matrix: rank 0 writes the header and
-        sizes the file, every rank then writes its own rows at their offset (ranks of one node share
-        the file system; the reference's save_path semantics, meerqat/ir/search.py:247-248)."""
+    def save(self, file, storage_options=None, format=None):
+        """One file in one of MI355XFlatIndex.save's formats (FAISS's own for ``*.faiss`` / ``*.index``) holding the WHOLE
+        matrix: rank 0 writes the header and sizes the file, every rank then writes its own rows at their offset (ranks of
+        one node share the file system; the reference's save_path semantics, meerqat/ir/search.py:247-248)."""
         import torch.distributed as dist
         path = os.fspath(file)
         d = int(self.d or 0)
+        head = index_file_header(self.ntotal, d, self.metric_type, self.do_l2norm, index_file_format(path, format))
         if self.rank == 0:
             with open(path, "wb") as f:
-                f.write(_MAGIC)
-                f.write(struct.pack("<qiiii", self.ntotal, d, self.metric_type, int(self.do_l2norm), 0))
-                f.truncate(32 + self.ntotal * d * 4)
+                f.write(head)
+                f.truncate(len(head) + self.ntotal * d * 4)
         if self.world > 1:
             dist.barrier(group=self.group)
         if getattr(self.local, "ntotal", 0):
             rows = self.local.reconstruct_n()
             with open(path, "r+b") as f:
-                f.seek(32 + int(self.local.id_offset) * d * 4)
+                f.seek(len(head) + int(self.local.id_offset) * d * 4)
                 f.write(np.ascontiguousarray(rows, dtype=np.float32).tobytes())
         if self.world > 1:
             dist.barrier(group=self.group)
@@ -444,12 +444,11 @@ class LocalShardsFlatIndex(_ShardedBase):
                 gathered[r * rec_bytes:(r + 1) * rec_bytes].copy_(record, non_blocking=True)  # peer-to-peer over xGMI
         return _hip_merge_records(gathered, self.world, nq, k, self.metric_type, self.tie_order)
 
-    def save(self, file, storage_options=None):
+    def save(self, file, storage_options=None, format=None):
         path = os.fspath(file)
         d = int(self.d or 0)
         with open(path, "wb") as f:
-            f.write(_MAGIC)
-            f.write(struct.pack("<qiiii", self.ntotal, d, self.metric_type, int(self.do_l2norm), 0))
+            f.write(index_file_header(self.ntotal, d, self.metric_type, self.do_l2norm, index_file_format(path, format)))
             for sh in self.shards:
                 if sh.ntotal:
                     f.write(np.ascontiguousarray(sh.reconstruct_n(), dtype=np.float32).tobytes())
