@@ -127,3 +127,78 @@ def test_arrow_query_transport_changes_the_transport_not_the_runs(tmp_path):
     assert s_fast.runs == s_py.runs and len(s_fast.runs["dense"]["5"]) == 10 and s_fast.runs["face"]["0"] == {}
     assert not S.ArrowQueryColumns(qs.with_format("numpy"), s_py)                   # the user's format stands
     assert not S.ArrowQueryColumns(qs.select([3, 1, 2]), s_py)                      # indices mapping: ordinary path
+
+
+def _reference_loop(k, mapping, many2one, batches):
+    """meerqat/ir/search.py:413-440 restated: runs[q][str(doc)] = score, fan-out, penalty, cut at k after each hit."""
+    run = {}
+    for q_ids, scores_batch, indices_batch in batches:
+        for q_id, scores, indices in zip(q_ids, scores_batch, indices_batch):
+            r = run.setdefault(q_id, {})
+            for score, i in zip(scores, indices):
+                penalty = np.float32(0.0)
+                if mapping is not None:
+                    for n, j in enumerate(mapping[int(i)]):
+                        j = str(j)
+                        if many2one is None:
+                            r[j] = float(np.float32(score) - np.float32(1e-8 * n))
+                        elif j not in r or r[j] < score:
+                            r[j] = float(score)
+                else:
+                    r[str(int(i))] = float(score)
+                if len(r) >= k:
+                    break
+    return run
+
+
+@pytest.mark.parametrize("mapping,many2one", [(None, None), ("csr", None), ("csr", "max")])
+def test_runs_kept_as_arrays_equal_the_reference_loop(mapping, many2one):
+    """Round 3: without on-the-fly relevance the searcher keeps each batch's [nq, k] arrays and builds
+    the dicts once, when `runs` is read.  Same dicts, same insertion order, as the reference's per-hit loop -- with repeated
+    question ids across batches (inserted into the existing run), duplicate ids inside a batch, -1 fillers (k > ntotal),
+    a cut k smaller than what the index returns, and index_mapping fan-out in both many2one modes."""
+    import datasets
+    from datasets.search import BaseIndex, BatchedSearchResults
+    from viquae_amd.ir.search import Index, KnowledgeBase, register_index
+    from viquae_amd.ir.searcher import Searcher
+    rng = np.random.default_rng(1)
+    n_art = 40
+
+    class Canned(BaseIndex):
+        def __init__(self):
+            self.calls = []
+
+        def search_batch(self, queries, k=10, **kw):
+            nq = len(queries)
+            I = np.stack([rng.permutation(n_art)[:k] for _ in range(nq)]).astype(int)
+            D = np.sort(rng.standard_normal((nq, k)).astype(np.float32), axis=1)[:, ::-1].copy()
+            if len(self.calls) == 1:          # second batch: the index ran out of rows for some queries
+                I[0, 5:] = -1
+                D[0, 5:] = -np.finfo(np.float32).max
+            self.calls.append((D, I))
+            return BatchedSearchResults(D, I)
+
+    kb = KnowledgeBase(dataset=datasets.Dataset.from_dict({"vec": [[0.0]] * n_art}))
+    idx = Canned()
+    register_index(kb.dataset, "dense", idx)
+    kb.indexes["dense"] = Index(key="q")
+    if mapping is not None:
+        kb.index_mapping = {a: [int(x) for x in rng.integers(0, 200, rng.integers(0, 4))] for a in range(n_art)}
+        kb.index_mapping[-1] = []
+        kb.many2one = many2one
+    import tempfile
+    qrels = os.path.join(tempfile.mkdtemp(), "qrels.json")
+    open(qrels, "wt").write("{}")
+    with pytest.warns(UserWarning):
+        s = Searcher(kb_kwargs={"kb": {}}, k=8, kbs={"kb": kb}, qrels=qrels)
+    batches_ids = [["a", "b", "c"], ["d", "e"], ["a", "f"], ["g", "g", "h"]]   # "a" comes back; "g" twice in one batch
+    for ids in batches_ids:
+        s({"id": ids, "q": [np.zeros(1, np.float32)] * len(ids)})
+    assert s._pending and not any(s._runs["dense"].values())                     # nothing was turned into dicts yet
+    want = _reference_loop(8, kb.index_mapping, many2one, [(ids, D, I) for ids, (D, I) in zip(batches_ids, idx.calls)])
+    got = s.runs["dense"]
+    assert not s._pending
+    assert list(got) == list(want)
+    for q in want:
+        assert list(got[q]) == list(want[q]), q
+        assert np.allclose(list(got[q].values()), list(want[q].values()), rtol=0, atol=1e-9), q

@@ -12,9 +12,12 @@ optional -- without it ``dataset_search`` returns plain dicts and skips the metr
 (InfoSeek) question types are not judged here.  With several indexes the runs are fused like the reference
 does (:514-524) through ``viquae_amd.ir.fuse.Fusion`` (HIP kernels); the fused run is ``searcher.fusion``.
 
-The reference builds the run with a Python triple loop per batch (256 x 100 dict inserts); here the
-[nq, k] arrays of one batch are expanded with numpy (CSR gather over ``index_mapping``) before the single
-pass that fills the dicts.
+The reference builds the run with a Python triple loop per batch (256 x 100 dict inserts).  Here a batch's [nq, k]
+result arrays are KEPT AS ARRAYS while the dataset is mapped and the ``{q_id: {str(doc): score}}`` dicts are built once,
+when somebody reads ``searcher.runs`` (``dataset_search`` does, before ranx / JSON): per-batch bookkeeping is then an
+append, and the one conversion is vectorised per block.  Only the on-the-fly relevance judgement (a reference KB is given:
+it needs each query's run at once) fills the dicts batch by batch as before.  With an ``index_mapping`` the hits are
+expanded with numpy (CSR gather) before the pass that applies the reference's insertion rules.
 """
 import json
 import re
@@ -95,7 +98,8 @@ class Searcher:
         if qnonrels is not None:
             with open(qnonrels, "rt") as file:
                 self.qnonrels = json.load(file)
-        self.runs = {}
+        self._runs = {}
+        self._pending = []  # (kb, index_name, q_ids, scores [nq, k], indices [nq, k]) blocks not yet turned into dicts
         resolved = {}
         for kb_path, kb_kwarg in kb_kwargs.items():
             real = Path(kb_path).expanduser().resolve()
@@ -104,13 +108,13 @@ class Searcher:
             resolved[real] = kb_path
             kb = kbs[kb_path] if kbs and kb_path in kbs else KnowledgeBase(kb_path, **kb_kwarg)
             self.kbs[kb_path] = kb
-            assert not (kb.indexes.keys() & self.runs.keys()), "All KBs should have unique index names"
+            assert not (kb.indexes.keys() & self._runs.keys()), "All KBs should have unique index names"
             for index_name in kb.indexes:
-                self.runs[index_name] = {}
-        assert not ({"search", "fusion"} & self.runs.keys()), "'search', 'fusion' are reserved names"
-        self.do_fusion = True if (do_fusion is None and len(self.runs) > 1) else do_fusion
+                self._runs[index_name] = {}
+        assert not ({"search", "fusion"} & self._runs.keys()), "'search', 'fusion' are reserved names"
+        self.do_fusion = True if (do_fusion is None and len(self._runs) > 1) else do_fusion
         if self.do_fusion:
-            assert len(self.runs) > 1
+            assert len(self._runs) > 1
         if reference_kb is not None:
             self.reference_kb = reference_kb
         elif reference_kb_path is None:
@@ -128,6 +132,41 @@ class Searcher:
         self.metrics_kwargs.update(metrics_kwargs)
         self._csr = {}
 
+    @property
+    def runs(self):
+        """``runs[index_name][q_id][doc_id] = score`` (meerqat/ir/search.py:386,413-440): reading it turns the result
+        blocks kept as arrays since the last read into dicts, in arrival order."""
+        self._flush()
+        return self._runs
+
+    @runs.setter
+    def runs(self, value):
+        self._pending = []
+        self._runs = value
+
+    def _flush(self):
+        pending, self._pending = self._pending, []
+        for kb, index_name, q_ids, scores, indices in pending:
+            run = self._runs[index_name]
+            indices = np.asarray(indices)
+            scores = np.asarray(scores, dtype=np.float32)
+            nq, kk = indices.shape
+            cut = min(self.k, kk)
+            plain = kb.index_mapping is None and cut > 0
+            if plain:
+                srt = np.sort(indices[:, :cut], axis=1)
+                plain = bool((srt[:, 0] >= 0).all() and (srt[:, 1:] != srt[:, :-1]).all())
+            if plain and len(set(q_ids)) == nq and not any(run.get(q) for q in q_ids):
+                # distinct hits into empty runs: the reference's loop keeps exactly the first k of them, in order.  ONE
+                # str() pass and ONE float pass over the block, then a dict per query from two list slices.
+                keys = list(map(str, indices[:, :cut].ravel().tolist()))
+                vals = scores[:, :cut].ravel().tolist()
+                for n, q_id in enumerate(q_ids):
+                    run[q_id] = dict(zip(keys[n * cut:(n + 1) * cut], vals[n * cut:(n + 1) * cut]))
+                continue
+            for q_id, sc, idx in zip(q_ids, scores.tolist(), indices.tolist()):
+                self._fill_run(kb, run.setdefault(q_id, {}), sc, idx)
+
     def _fill_run(self, kb, run_q, scores, indices):
         """One query's hits -> run dict, cut at k entries (reference: search.py:413-440)."""
         if kb.index_mapping is None:
@@ -142,27 +181,31 @@ class Searcher:
             return
         csr = self._csr.setdefault(id(kb), _Mapping(kb.index_mapping))
         ids, sc, ends = csr.expand(indices, scores, kb.many2one)
-        hit = 0
-        for n, (j, s) in enumerate(zip(ids.tolist(), sc.tolist())):
-            j = str(j)
+        if kb.many2one not in (None, "max"):
+            raise ValueError(f"Invalid value for many2one: '{kb.many2one}'. Choose from {{None, 'max'}}")
+        keys, vals = list(map(str, ids.tolist())), sc.tolist()
+        start = 0
+        for end in ends.tolist():  # one hit = its passages [start, end), possibly none (an empty index_mapping entry)
             if kb.many2one is None:
-                run_q[j] = s
-            elif kb.many2one == "max":
-                if j not in run_q or run_q[j] < s:
-                    run_q[j] = s
+                for n in range(start, end):
+                    run_q[keys[n]] = vals[n]
             else:
-                raise ValueError(f"Invalid value for many2one: '{kb.many2one}'. Choose from {{None, 'max'}}")
-            # the reference tests the cut after each HIT (all passages of an article are inserted first); `<=` also steps
-            # over hits that map to no passage at all (an empty index_mapping entry, ends[hit] == ends[hit - 1])
-            while hit < len(ends) and ends[hit] <= n + 1:
-                hit += 1
-                if len(run_q) >= self.k:
-                    return
+                for n in range(start, end):
+                    j = keys[n]
+                    if j not in run_q or run_q[j] < vals[n]:
+                        run_q[j] = vals[n]
+            start = end
+            # the reference tests the cut after each HIT, all passages of the article inserted first -- also after a hit
+            # that maps to no passage at all, and also when the run was already full on entry (a repeated question id)
+            if len(run_q) >= self.k:
+                return
 
     arrow_queries = None  # set by dataset_search: query vectors come from the Arrow table, not from `batch`
 
     def __call__(self, batch, row_indices=None):
         question_types = batch.get("question_type", ["String"] * len(batch["id"]))
+        # the answers are only read when relevance is judged on the fly (dataset_search does not even decode them otherwise)
+        outputs = batch["output"] if self.reference_kb is not None else [None] * len(batch["id"])
         for kb in self.kbs.values():
             for index_name, index in kb.indexes.items():
                 if self.arrow_queries is not None and row_indices is not None and index.key in self.arrow_queries.columns:
@@ -173,9 +216,14 @@ class Searcher:
                     scores_batch, indices_batch = kb.search_batch_if_not_None(index_name, queries, k=self.k)
                 else:
                     scores_batch, indices_batch = kb.search_batch(index_name, queries, k=self.k)
-                for q_id, scores, indices, gt, question_type in zip(batch["id"], scores_batch, indices_batch, batch["output"],
+                if self.reference_kb is None and isinstance(scores_batch, np.ndarray) and isinstance(indices_batch, np.ndarray):
+                    # nothing reads this batch's run before the end of the job: keep the arrays (see `runs`)
+                    self._pending.append((kb, index_name, list(batch["id"]), scores_batch, indices_batch))
+                    continue
+                self._flush()
+                for q_id, scores, indices, gt, question_type in zip(batch["id"], scores_batch, indices_batch, outputs,
                                                                     question_types):
-                    run_q = self.runs[index_name].setdefault(q_id, {})
+                    run_q = self._runs[index_name].setdefault(q_id, {})
                     scores = np.asarray(scores).tolist()
                     indices = np.asarray(indices).tolist()
                     self._fill_run(kb, run_q, scores, indices)
@@ -248,12 +296,26 @@ def dataset_search(dataset, k=100, metric_save_path=None, map_kwargs={}, **kwarg
     if "new_fingerprint" not in map_kwargs:
         from datasets.fingerprint import generate_random_fingerprint
         map_kwargs["new_fingerprint"] = generate_random_fingerprint()
+    # Only what Searcher.__call__ reads is decoded by `map` (ids; answers and question types when relevance is judged on the
+    # fly; query columns the Arrow transport does not serve), and nothing is written back: the reference discards the mapped
+    # dataset too (meerqat/ir/search.py:482), so the searcher is wrapped to return None ("no update" for Dataset.map).
+    needed = {"id"} | {index.key for kb in searcher.kbs.values() for index in kb.indexes.values()} - set(queries.columns)
+    if searcher.reference_kb is not None:
+        needed |= {"output", "question_type"}
+    dataset = dataset.remove_columns([c for c in dataset.column_names if c not in needed])
     if queries:
         searcher.arrow_queries = queries
-        dataset = dataset.remove_columns(list(queries.columns)).map(searcher, batched=True, with_indices=True, **map_kwargs)
+
+        def run_batch(batch, row_indices):
+            searcher(batch, row_indices)
+
+        dataset.map(run_batch, batched=True, with_indices=True, **map_kwargs)
         searcher.arrow_queries = None
     else:
-        dataset = dataset.map(searcher, batched=True, **map_kwargs)
+        def run_batch(batch):
+            searcher(batch)
+
+        dataset.map(run_batch, batched=True, **map_kwargs)
     from .embedding import process_rank_and_world
     if process_rank_and_world()[0] != 0:
         metric_save_path = None  # sharded search: every rank holds the same runs, rank 0 writes them
