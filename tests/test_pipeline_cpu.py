@@ -1,0 +1,149 @@
+"""CPU: the host logic of the encode pipeline (viquae_amd/pipeline.py) -- the tokenizer fast path against the tokenizer's own
+output, and the lookahead scheduler (order, back-pressure, worker failures).  No GPU work."""
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+
+def _tokenizer(tmp_path, n_words=600):
+    from transformers import BertTokenizer
+    rng = np.random.default_rng(0)
+    words = sorted({"".join(rng.choice(list("abcdefghijklmnopqrstuvwxyz"), rng.integers(2, 8))) for _ in range(n_words)})
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words + ["##" + w for w in words[:50]] + [",", ".", "é", "##s"]
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab) + "\n")
+    return BertTokenizer(str(tmp_path / "vocab.txt")), words
+
+
+def _texts(words, n, rng):
+    out = []
+    for i in range(n):
+        k = int(rng.integers(0, 60))
+        t = " ".join(rng.choice(words, k)) if k else ""
+        if i % 7 == 0:
+            t += " Unknownword, with PUNCTUATION. and accents é"
+        out.append(t)
+    return out
+
+
+@pytest.mark.parametrize("kwargs", [
+    dict(return_tensors="pt", padding="max_length", truncation=True, max_length=32),    # the shipped DPR config's shape
+    dict(return_tensors="pt", padding="max_length", truncation=True, max_length=256),
+    dict(return_tensors="pt", padding=True, truncation=True, max_length=40),            # pad to the longest of the batch
+    dict(return_tensors="pt", padding="longest"),
+])
+def test_fast_batch_tokenizer_equals_the_tokenizer(tmp_path, kwargs):
+    from viquae_amd.pipeline import FastBatchTokenizer
+    tok, words = _tokenizer(tmp_path)
+    rng = np.random.default_rng(1)
+    fast = FastBatchTokenizer(tok, kwargs)
+    assert fast.ok
+    for n in (1, 5, 64):
+        texts = _texts(words, n, rng)
+        want = tok(texts, **kwargs)
+        got, lens = fast(texts)
+        assert list(got.keys()) == list(want.keys())
+        for k in want:
+            assert got[k].dtype == want[k].dtype == torch.int64 and torch.equal(got[k], want[k]), (k, n)
+        assert np.array_equal(lens, want["attention_mask"].sum(1).numpy())
+    assert fast.check(_texts(words, 16, rng))
+
+
+def test_fast_batch_tokenizer_left_padding_and_refusals(tmp_path):
+    from viquae_amd.pipeline import FastBatchTokenizer
+    tok, words = _tokenizer(tmp_path)
+    rng = np.random.default_rng(2)
+    texts = _texts(words, 9, rng)
+    tok.padding_side = "left"
+    kw = dict(return_tensors="pt", padding="max_length", truncation=True, max_length=48)
+    fast = FastBatchTokenizer(tok, kw)
+    want = tok(texts, **kw)
+    got, _ = fast(texts)
+    assert all(torch.equal(got[k], want[k]) for k in want)
+    tok.padding_side = "right"
+    # anything the fast path does not understand is left to the tokenizer itself
+    assert not FastBatchTokenizer(tok, dict(return_tensors="np", padding="max_length", max_length=8)).ok
+    assert not FastBatchTokenizer(tok, dict(return_tensors="pt", padding="max_length", max_length=8, return_offsets_mapping=True)).ok
+    assert not FastBatchTokenizer(tok, dict(return_tensors="pt")).ok            # no padding: ragged, tensors impossible
+    assert not FastBatchTokenizer(object(), dict(return_tensors="pt", padding=True)).ok
+    # a fast path that disagrees with the tokenizer disables itself
+    bad = FastBatchTokenizer(tok, kw)
+    bad.pad_id = 3
+    assert not bad.check(texts) and not bad.ok
+
+
+def test_lookahead_runs_one_batch_ahead_in_order():
+    from viquae_amd.pipeline import Lookahead
+    log, lock = [], threading.Lock()
+
+    class H:
+        def __init__(self, j):
+            self.j = j
+
+        def result(self):
+            with lock:
+                log.append(("result", self.j))
+            return self.j * 10, None
+
+    def prepare(j):
+        time.sleep(0.01)
+        with lock:
+            log.append(("prepare", j))
+        return j
+
+    def launch(j):
+        with lock:
+            log.append(("launch", j))
+        return H(j)
+
+    look = Lookahead(5, prepare, launch, depth=2)
+    outs = [look.step(i)[0] for i in range(5)]
+    look.close()
+    assert outs == [0, 10, 20, 30, 40]
+    order = [e for e in log if e[0] != "prepare"]
+    # batch i + 1 is launched BEFORE batch i's result is awaited; the last batch has nothing to run ahead of
+    assert order == [("launch", 0), ("launch", 1), ("result", 0), ("launch", 2), ("result", 1), ("launch", 3), ("result", 2),
+                     ("launch", 4), ("result", 3), ("result", 4)]
+    with pytest.raises(RuntimeError):
+        look.step(2)
+
+
+def test_lookahead_back_pressure_and_worker_failure():
+    from viquae_amd.pipeline import Lookahead
+    prepared = []
+
+    def prepare(j):
+        prepared.append(j)
+        if j == 3:
+            raise ValueError("decoding batch 3 failed")
+        return j
+
+    class H:
+        def __init__(self, j):
+            self.j = j
+
+        def result(self):
+            return self.j, None
+
+    look = Lookahead(6, prepare, H, depth=1)
+    time.sleep(0.3)
+    assert len(prepared) <= 2            # queue of one + the item the worker holds: it does not run away from the consumer
+    assert look.step(0)[0] == 0 and look.step(1)[0] == 1
+    with pytest.raises(ValueError, match="batch 3"):
+        look.step(2)                     # launching batch 3 ahead surfaces the worker's exception in the caller
+    look.close()
+
+
+def test_pipelines_decline_what_they_cannot_prefetch(tmp_path):
+    import datasets
+    from viquae_amd import pipeline as P
+    ds = datasets.Dataset.from_dict({"passage": ["a b", "c"], "n": [1, 2]})
+    tok, _ = _tokenizer(tmp_path)
+    lin = torch.nn.Linear(2, 2)          # a CPU model: there is no GPU here, and no CPU path either
+    assert P.text_pipeline_or_none(ds, {}, model=lin, tokenizer=tok, key="passage") is None
+    assert P.text_pipeline_or_none(ds, {}, model=lin, tokenizer=tok, key="passage", run=object()) is None
+    assert P.image_pipeline_or_none(ds, {}, model=lin, transform=object(), image_key="passage") is None
+    assert not P._plain_dataset(ds.select([1, 0]), {}) and not P._plain_dataset(ds, {"num_proc": 2}) and P._plain_dataset(ds, {"batch_size": 7})
+    assert P._arrow_strings(ds, "n") is None and P._arrow_strings(ds, "passage") is not None

@@ -470,21 +470,37 @@ def _pack_plan(attention_mask):
     right_padded = bool((m[:, 1:] <= m[:, :-1]).all()) and bool(((attention_mask == 0) | (attention_mask == 1)).all())
     if not right_padded:
         return None
-    lens_dev = m.sum(dim=1)
-    lens = lens_dev.cpu().numpy()
-    if lens.min() < 1 or int(lens.sum()) > 0.9 * B * L:
+    lens = m.sum(dim=1).cpu().numpy()
+    return pack_plan_from_lengths(lens, L, attention_mask.device)
+
+
+def pack_plan_from_lengths(lens, L, device):
+    """The plan of :func:`_pack_plan` from the sequence lengths alone (HOST int array [B]; the mask is right-padded 0/1 by
+    construction, e.g. lengths the tokenizer reported): every array is built on the host and copied to ``device`` on the
+    CURRENT stream -- no device -> host synchronisation, so an input pipeline can prepare the plan of batch i + 1 on a side
+    stream while batch i runs (viquae_amd/pipeline.py).  None when packing does not pay (see _pack_plan)."""
+    if os.environ.get("MQ_ENC_PACKED", "1") == "0" or os.environ.get("MQ_ENC_PAD_SKIP", "1") == "0":
         return None
-    dev = attention_mask.device
-    keep = m.reshape(-1).nonzero(as_tuple=False).reshape(-1)                      # flat indices b * L + t of the real tokens
-    pos = (keep % L).to(torch.int32)
-    cu_host = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    cu = torch.from_numpy(cu_host).to(dev)
+    lens = np.asarray(lens, dtype=np.int64)
+    B = lens.shape[0]
+    if B == 0 or L < 2 or lens.min() < 1 or lens.max() > L or int(lens.sum()) > 0.9 * B * L:
+        return None
+    cu_host = np.concatenate([[0], np.cumsum(lens)])
+    T = int(cu_host[-1])
+    # flat indices b * L + t of the real tokens, in row-major order (= nonzero() of the flattened mask)
+    pos_host = np.arange(T, dtype=np.int64) - np.repeat(cu_host[:-1], lens)
+    keep_host = pos_host + np.repeat(np.arange(B, dtype=np.int64) * L, lens)
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)
+
+    keep, pos, cu = dev(keep_host), dev(pos_host.astype(np.int32)), dev(cu_host.astype(np.int32))
     classes = []
     for lo, hi in ((0, 64), (64, 128), (128, 256), (256, 1 << 30)):               # the attention kernel's key-tile counts
         sel = np.nonzero((lens > lo) & (lens <= hi))[0].astype(np.int32)
         if sel.size:
-            classes.append((torch.from_numpy(sel).to(dev), int(lens[sel].max())))
-    cls_rows = torch.from_numpy(cu_host[:-1].astype(np.int64)).to(dev)
+            classes.append((dev(sel), int(lens[sel].max())))
+    cls_rows = dev(cu_host[:-1].astype(np.int64))
     return keep, pos, cu, classes, cls_rows
 
 
@@ -532,9 +548,15 @@ class _DPREncoder(_HipEncoder):
     def from_state_dict(cls, config, state):
         return cls(config, state)
 
+    supports_pack_plan = True  # forward(..., pack_plan=pack_plan_from_lengths(...)): see viquae_amd/pipeline.py
+
     @torch.no_grad()
-    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, output_hidden_states=False, **unused):
-        pack = None if output_hidden_states else _pack_plan(attention_mask)
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, output_hidden_states=False, pack_plan=None,
+                **unused):
+        """``pack_plan`` (optional): the packed-forward plan of THIS batch prepared ahead of time from the tokenizer's
+        lengths (:func:`pack_plan_from_lengths`) -- the caller vouches that ``attention_mask`` is the right-padded mask of
+        those lengths; the forward then needs no device -> host copy at all."""
+        pack = None if output_hidden_states else (pack_plan if pack_plan is not None else _pack_plan(attention_mask))
         if pack is not None:
             return ModelOutput(pooler_output=self.bert_model.forward_packed(input_ids, token_type_ids, pack))
         plan = None if output_hidden_states else _length_buckets(attention_mask)

@@ -69,7 +69,18 @@ def dataset_embed(dataset_path, map_kwargs={}, model_kwargs={}, transform_kwargs
     rank, world = process_rank_and_world()
     if world > 1:  # one process per GPU: every rank embeds its contiguous block of rows (see viquae_amd/ir/embedding.py)
         dataset = _rank_shard(dataset, rank, world)
-    dataset = dataset.map(embed, batched=True, fn_kwargs=fn_kwargs, **map_kwargs)
+    # decode / pack / H2D / device-side resize of batch i + 1 behind the CLIP forward of batch i (viquae_amd/pipeline.py)
+    from ..pipeline import image_pipeline_or_none
+    pipe = image_pipeline_or_none(dataset, map_kwargs, **fn_kwargs)
+    if pipe is not None:
+        try:
+            dataset = dataset.map(pipe.embed, batched=True, with_indices=True, **map_kwargs)
+        finally:
+            pipe.close()
+            dataset_embed.last_pipeline_stats = dict(pipe.stats)
+    else:
+        dataset_embed.last_pipeline_stats = None
+        dataset = dataset.map(embed, batched=True, fn_kwargs=fn_kwargs, **map_kwargs)
     if world > 1:
         return _save_rank_shards(dataset, dataset_path, output_path, rank, world)
     return _save(dataset, dataset_path, output_path)

@@ -169,7 +169,20 @@ def dataset_embed(dataset_path, map_kwargs={}, output_path=None, keep_columns=No
     rank, world = process_rank_and_world()
     if world > 1:
         dataset = _rank_shard(dataset, rank, world)
-    dataset = dataset.map(embed, batched=True, fn_kwargs=fn_kwargs, **map_kwargs)
+    # Dataset.map stays the driver.  For the plain job (texts = batch[key] as they are, a CUDA model) the function it calls is
+    # a software-pipelined embed: tokenisation / pinned staging / H2D of batch i + 1 and the Arrow write of batch i - 1 overlap
+    # the forward of batch i (viquae_amd/pipeline.py); everything else maps the serial `embed` below
+    from ..pipeline import text_pipeline_or_none
+    pipe = text_pipeline_or_none(dataset, map_kwargs, **fn_kwargs)
+    if pipe is not None:
+        try:
+            dataset = dataset.map(pipe.embed, batched=True, with_indices=True, **map_kwargs)
+        finally:
+            pipe.close()
+            dataset_embed.last_pipeline_stats = dict(pipe.stats)
+    else:
+        dataset_embed.last_pipeline_stats = None
+        dataset = dataset.map(embed, batched=True, fn_kwargs=fn_kwargs, **map_kwargs)
     if world > 1:
         return _save_rank_shards(dataset, dataset_path, output_path, rank, world)
     return _save(dataset, dataset_path, output_path)

@@ -1,0 +1,487 @@
+"""Software pipeline behind ``Dataset.map`` for the encode jobs (VERDICT r2 "What's missing" 1).
+
+The reference's ``embed`` (meerqat/ir/embedding.py:197-246, meerqat/image/embedding.py:125-166) is strictly serial per batch:
+tokenise / decode on the CPU -> pageable synchronous ``.to(device)`` -> forward -> ``.cpu().numpy()`` -> Arrow write, so the
+GPU idles during every host stage.  ``Dataset.map`` stays the driver here (same call, same batches, same output dataset), but
+the function it calls is a :class:`Lookahead` step:
+
+* a WORKER THREAD prepares batch j + 1 while the GPU runs batch j: it reads the batch's rows straight from the Arrow table,
+  does the host work (tokenisation into PINNED buffers / image decoding and packing), issues the host -> device copies with
+  ``non_blocking=True`` on a SIDE STREAM, builds whatever the forward would otherwise have to read back from the device (the
+  packed-forward plan from the tokenizer's lengths) and records an event;
+* the map function for batch i first LAUNCHES batch i + 1 on the compute stream (which waits for the worker's event on the
+  device, not on the host), then waits for ONE event -- batch i's result landing in pinned memory -- and returns it.  The
+  Arrow write of batch i (done by ``Dataset.map`` after the function returns) therefore overlaps the forward of batch i + 1.
+
+Results are identical to the serial path: the same tokenizer backend (validated against ``tokenizer(texts, **kwargs)`` on the
+first batch, else the tokenizer itself is called in the worker), the same forward.  Anything the prefetcher cannot know ahead
+of ``Dataset.map`` (query expansion, KB features, shuffled / filtered datasets, ``num_proc``) keeps the serial path.
+"""
+import itertools
+import os
+import queue
+import threading
+import time
+
+import numpy as np
+import torch
+
+
+class _Failure:
+    def __init__(self, exc):
+        self.exc = exc
+
+
+class Lookahead:
+    """``prepare(j)`` (worker thread) -> prepared inputs of batch j; ``launch(prepared)`` (caller's thread) enqueues the
+    device work and returns a handle whose ``result()`` blocks until batch j's output is on the host.  ``step(i)`` returns
+    batch i's result after making sure batch i + 1 is already running."""
+
+    def __init__(self, n_batches, prepare, launch, depth=2):
+        self.n, self._prepare, self._launch = int(n_batches), prepare, launch
+        self._q = queue.Queue(maxsize=max(1, int(depth)))
+        self._handles = {}
+        self._launched = 0
+        self._stop = False
+        self.wait_prepared_s = 0.0   # time the caller spent waiting for the worker (host-bound when this grows)
+        self._thread = threading.Thread(target=self._work, name="viquae-amd-prefetch", daemon=True)
+        self._thread.start()
+
+    def _work(self):
+        try:
+            for j in range(self.n):
+                if self._stop:
+                    return
+                item = self._prepare(j)
+                while not self._stop:
+                    try:
+                        self._q.put(item, timeout=0.2)
+                        break
+                    except queue.Full:
+                        continue
+        except BaseException as e:  # noqa: BLE001 - handed to the caller's thread
+            self._q.put(_Failure(e))
+
+    def _launch_next(self):
+        t0 = time.perf_counter()
+        item = self._q.get()
+        self.wait_prepared_s += time.perf_counter() - t0
+        if isinstance(item, _Failure):
+            self._stop = True
+            raise item.exc
+        self._handles[self._launched] = self._launch(item)
+        self._launched += 1
+
+    def step(self, i):
+        if i < self._launched - len(self._handles) or i >= self.n:
+            raise RuntimeError(f"batch {i} was requested out of order (batches must be taken in sequence)")
+        while self._launched <= min(i + 1, self.n - 1):
+            self._launch_next()
+        return self._handles.pop(i).result()
+
+    def close(self):
+        self._stop = True
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=5.0)
+        self._handles.clear()
+
+
+class _Handle:
+    def __init__(self, event, pinned, rows, extra=None):
+        self.event, self.pinned, self.rows, self.extra = event, pinned, rows, extra
+
+    def result(self):
+        if self.event is not None:
+            self.event.synchronize()
+        return np.array(self.pinned[: self.rows].numpy()), self.extra  # a copy: the pinned slot is reused two batches later
+
+
+class _PinnedRing:
+    """Page-locked staging slots, reused round-robin; a slot is handed out again only after the copy that read it is done."""
+
+    def __init__(self, slots):
+        self.bufs = [None] * slots
+        self.events = [None] * slots
+        self.next = 0
+
+    def take(self, nbytes):
+        s = self.next
+        self.next = (s + 1) % len(self.bufs)
+        if self.events[s] is not None:
+            self.events[s].synchronize()
+            self.events[s] = None
+        if self.bufs[s] is None or self.bufs[s].numel() < nbytes:
+            self.bufs[s] = torch.empty(int(nbytes * 5 // 4) + 64, dtype=torch.uint8, pin_memory=True)
+        return s, self.bufs[s]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# text
+# ----------------------------------------------------------------------------------------------------------------------
+class FastBatchTokenizer:
+    """``tokenizer(texts, **tokenization_kwargs)`` for the plain case -- a list of single texts, ``return_tensors="pt"``,
+    ``padding`` "max_length" / True / "longest", optional truncation -- computed from the tokenizer's own Rust backend
+    (``tokenizer.backend_tokenizer``: same normaliser, pre-tokeniser, model and post-processor) without the per-element Python
+    passes of ``BatchEncoding.convert_to_tensors`` (transformers 5: 0.86 s of a 0.95 s call for 2048 passages padded to 256).
+    The backend releases the GIL and encodes in parallel; the padded int64 matrices are then built with numpy.  ``check()``
+    compares with the tokenizer's own output and must pass before the fast path is trusted."""
+
+    SUPPORTED = {"return_tensors", "padding", "truncation", "max_length"}
+
+    def __init__(self, tokenizer, tokenization_kwargs):
+        self.tokenizer, self.kwargs = tokenizer, dict(tokenization_kwargs)
+        self.ok = False
+        backend = getattr(tokenizer, "backend_tokenizer", None) or getattr(tokenizer, "_tokenizer", None)
+        kw = self.kwargs
+        if backend is None or set(kw) - self.SUPPORTED or kw.get("return_tensors") != "pt":
+            return
+        padding = kw.get("padding", False)
+        if padding not in ("max_length", True, "longest"):
+            return
+        truncation = kw.get("truncation", False)
+        if truncation not in (True, False, "longest_first"):
+            return
+        max_length = kw.get("max_length")
+        if max_length is None and (truncation or padding == "max_length"):
+            mml = getattr(tokenizer, "model_max_length", None)
+            max_length = int(mml) if mml is not None and mml < 1_000_000 else None
+        if padding == "max_length" and max_length is None:
+            return
+        try:
+            import tokenizers
+            self.backend = tokenizers.Tokenizer.from_str(backend.to_str())  # a private copy: truncation / padding are state
+        except Exception:
+            return
+        self.backend.no_padding()
+        if truncation and max_length is not None:
+            self.backend.enable_truncation(int(max_length))
+        else:
+            self.backend.no_truncation()
+        self.pad_to = int(max_length) if padding == "max_length" else None
+        self.pad_id = int(tokenizer.pad_token_id if tokenizer.pad_token_id is not None else 0)
+        self.left = getattr(tokenizer, "padding_side", "right") == "left"
+        self.names = list(getattr(tokenizer, "model_input_names", ["input_ids", "attention_mask"]))
+        if not set(self.names) <= {"input_ids", "token_type_ids", "attention_mask"}:
+            return
+        self.ok = True
+
+    def encode(self, texts):
+        """-> (lengths int64 [B], flat ids int64 [sum lengths])"""
+        enc = self.backend.encode_batch_fast(texts, add_special_tokens=True) if hasattr(self.backend, "encode_batch_fast") \
+            else self.backend.encode_batch(texts, add_special_tokens=True)
+        ids = [e.ids for e in enc]
+        lens = np.fromiter(map(len, ids), dtype=np.int64, count=len(ids))
+        flat = np.fromiter(itertools.chain.from_iterable(ids), dtype=np.int64, count=int(lens.sum()))
+        return lens, flat
+
+    def fill(self, lens, flat, out):
+        """out: dict name -> int64 numpy [B, L] views to fill (the tokenizer's padded matrices)."""
+        B, L = out["input_ids"].shape
+        cols = np.arange(L, dtype=np.int64)[None, :]
+        mask = (cols >= L - lens[:, None]) if self.left else (cols < lens[:, None])
+        ids = out["input_ids"]
+        ids.fill(self.pad_id)
+        ids[mask] = flat
+        if "attention_mask" in out:
+            np.copyto(out["attention_mask"], mask, casting="unsafe")
+        if "token_type_ids" in out:
+            out["token_type_ids"].fill(0)  # single texts: every token belongs to segment 0 (pad_token_type_id is 0 too)
+
+    def width(self, lens):
+        return self.pad_to if self.pad_to is not None else int(lens.max()) if lens.size else 0
+
+    def __call__(self, texts):
+        lens, flat = self.encode(texts)
+        L = self.width(lens)
+        out = {n: np.empty((len(texts), L), dtype=np.int64) for n in self.names}
+        self.fill(lens, flat, out)
+        return {n: torch.from_numpy(a) for n, a in out.items()}, lens
+
+    def check(self, texts):
+        """True when the fast path reproduces ``tokenizer(texts, **kwargs)`` exactly (keys, order, dtypes, values)."""
+        if not self.ok:
+            return False
+        try:
+            want = self.tokenizer(texts, **self.kwargs)
+            got, _ = self(texts)
+            same = list(want.keys()) == list(got.keys()) and all(
+                want[k].dtype == got[k].dtype and want[k].shape == got[k].shape and bool(torch.equal(want[k], got[k])) for k in got)
+        except Exception:
+            same = False
+        self.ok = bool(same)
+        return self.ok
+
+
+def _arrow_strings(dataset, key):
+    """The Arrow column ``key`` of a dataset without an indices mapping, or None."""
+    import pyarrow as pa
+    if getattr(dataset, "_indices", None) is not None or key not in dataset.column_names:
+        return None
+    col = dataset.data.column(key)
+    if not (pa.types.is_string(col.type) or pa.types.is_large_string(col.type)):
+        return None
+    return col
+
+
+class TextEmbedPipeline:
+    """``embed`` for ``Dataset.map(..., batched=True, with_indices=True)`` with the host stages of batch i + 1 (Arrow ->
+    str, tokenisation, pinned staging, H2D, packed-forward plan) hidden behind the forward of batch i.  Plain passages /
+    questions only (no query expansion, no KB features, no per-layer dump): see :func:`text_pipeline_or_none`."""
+
+    def __init__(self, dataset, model, tokenizer, tokenization_kwargs, key, save_as, output_key, forward_kwargs, call, batch_size,
+                 depth=2):
+        self.model, self.key, self.save_as, self.output_key = model, key, save_as, output_key
+        self.forward_kwargs, self.call = dict(forward_kwargs or {}), call
+        self.tokenizer, self.tokenization_kwargs = tokenizer, dict(tokenization_kwargs or {})
+        self.column = _arrow_strings(dataset, key)
+        n = len(dataset)
+        self.bounds = [(s, min(s + batch_size, n)) for s in range(0, n, batch_size)]
+        self.device = next(iter(model.parameters()), None)
+        self.device = (self.device if self.device is not None else next(iter(model.buffers()))).device
+        self.main = torch.cuda.current_stream(self.device)
+        self.side = torch.cuda.Stream(device=self.device)
+        self.fast = FastBatchTokenizer(tokenizer, self.tokenization_kwargs)
+        self._checked = False
+        self.use_plan = bool(getattr(model, "supports_pack_plan", False)) and call is None and not self.fast.left
+        self.in_ring = _PinnedRing(depth + 2)
+        self.out_ring = _PinnedRing(3)
+        self.stats = {"batches": 0, "tokenize_s": 0.0, "prepare_s": 0.0, "launch_s": 0.0, "wait_result_s": 0.0,
+                      "fast_tokenizer": None, "pack_plan": self.use_plan}
+        self.look = Lookahead(len(self.bounds), self._prepare, self._launch, depth=depth)
+
+    # ---- worker thread ---------------------------------------------------------------------------------------------
+    def _prepare(self, j):
+        t0 = time.perf_counter()
+        s, e = self.bounds[j]
+        texts = self.column.slice(s, e - s).to_pylist()
+        if not self._checked:
+            self._checked = True
+            self.stats["fast_tokenizer"] = self.fast.check(texts[: min(len(texts), 256)])
+        lens = None
+        tt = time.perf_counter()
+        if self.fast.ok:
+            lens, flat = self.fast.encode(texts)
+            L = self.fast.width(lens)
+            names = self.fast.names
+            nbytes = len(names) * len(texts) * L * 8
+            slot, buf = self.in_ring.take(nbytes)
+            host = {}
+            for n_, name in enumerate(names):
+                host[name] = buf[n_ * len(texts) * L * 8:(n_ + 1) * len(texts) * L * 8].view(torch.int64).view(len(texts), L)
+            self.fast.fill(lens, flat, {k: v.numpy() for k, v in host.items()})
+        else:  # the tokenizer itself (whatever its kwargs mean), staged through pinned memory all the same
+            enc = self.tokenizer(texts, **self.tokenization_kwargs)
+            tensors = {k: v for k, v in enc.items()}
+            nbytes = sum(v.numel() * v.element_size() + 64 for v in tensors.values())
+            slot, buf = self.in_ring.take(nbytes)
+            host, off = {}, 0
+            for k, v in tensors.items():
+                v = v.contiguous()
+                nb = v.numel() * v.element_size()
+                dst = buf[off:off + nb].view(v.dtype).view(v.shape)
+                dst.copy_(v)
+                host[k] = dst
+                off += (nb + 63) // 64 * 64
+        self.stats["tokenize_s"] += time.perf_counter() - tt
+        with torch.cuda.device(self.device), torch.cuda.stream(self.side):
+            inputs = {k: torch.empty(v.shape, dtype=v.dtype, device=self.device).copy_(v, non_blocking=True) for k, v in host.items()}
+            plan = None
+            if self.use_plan and lens is not None and "attention_mask" in inputs:
+                from .encoders import pack_plan_from_lengths
+                plan = pack_plan_from_lengths(lens, inputs["input_ids"].shape[1], self.device)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self.in_ring.events[slot] = ev
+        self.stats["prepare_s"] += time.perf_counter() - t0
+        return {"texts": texts, "inputs": inputs, "plan": plan, "event": ev, "rows": len(texts)}
+
+    # ---- caller's thread -------------------------------------------------------------------------------------------
+    def _launch(self, p):
+        t0 = time.perf_counter()
+        with torch.cuda.device(self.device):
+            self.main.wait_event(p["event"])
+            for t in p["inputs"].values():
+                t.record_stream(self.main)
+            if p["plan"] is not None:
+                keep, pos, cu, classes, cls_rows = p["plan"]
+                for t in [keep, pos, cu, cls_rows] + [c[0] for c in classes]:
+                    t.record_stream(self.main)
+            method = self.model if self.call is None else getattr(self.model, self.call)
+            kw = dict(self.forward_kwargs)
+            if p["plan"] is not None:
+                kw["pack_plan"] = p["plan"]
+            with torch.no_grad():
+                outputs = method(**p["inputs"], **kw)
+            output = select_output(outputs, self.output_key)
+            output = output.to(torch.float32) if output.dtype != torch.float32 else output
+            output = output.contiguous()
+            slot, buf = self.out_ring.take(output.numel() * 4)
+            pinned = buf[: output.numel() * 4].view(torch.float32).view(output.shape)
+            pinned.copy_(output, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            self.out_ring.events[slot] = ev
+        self.stats["launch_s"] += time.perf_counter() - t0
+        return _Handle(ev, pinned, p["rows"], extra=p["texts"])
+
+    def embed(self, batch, indices):
+        """The function ``Dataset.map`` calls (batched, with_indices): ``batch[save_as]`` = float32 [B, H] of THIS batch."""
+        i = self.stats["batches"]
+        s, e = self.bounds[i] if i < len(self.bounds) else (-1, -1)
+        if len(indices) != e - s or int(indices[0]) != s or int(indices[-1]) != e - 1:
+            raise RuntimeError("Dataset.map handed over batches in another order than the prefetcher prepared them "
+                               f"(batch {i}: rows {indices[0]}..{indices[-1]}, expected {s}..{e - 1}); set MQ_EMBED_PIPELINE=0")
+        t0 = time.perf_counter()
+        out, texts = self.look.step(i)
+        self.stats["wait_result_s"] += time.perf_counter() - t0
+        if texts != batch[self.key]:
+            raise RuntimeError(f"the prefetched texts of batch {i} differ from what Dataset.map decoded; set MQ_EMBED_PIPELINE=0")
+        self.stats["batches"] = i + 1
+        batch[self.save_as] = out
+        return batch
+
+    def close(self):
+        self.stats["wait_prepared_s"] = self.look.wait_prepared_s
+        self.look.close()
+
+
+def select_output(outputs, output_key):
+    """meerqat/ir/embedding.py:227-236: a tensor, or ``outputs[output_key]`` of a dict / list / tuple."""
+    if isinstance(outputs, torch.Tensor):
+        return outputs
+    if isinstance(outputs, (dict, list, tuple)):
+        if output_key is None:
+            raise ValueError(f"You should set output_key to choose from the model's outputs (got {output_key})")
+        return outputs[output_key]
+    raise TypeError(f"Invalid type '{type(outputs)}' for model's outputs:\\n{outputs}")
+
+
+def pipeline_enabled():
+    return os.environ.get("MQ_EMBED_PIPELINE", "1") != "0"
+
+
+def _plain_dataset(dataset, map_kwargs):
+    from datasets import Dataset
+    return (isinstance(dataset, Dataset) and getattr(dataset, "_indices", None) is None and len(dataset) > 0
+            and not map_kwargs.get("num_proc") and map_kwargs.get("batched", True) and not map_kwargs.get("drop_last_batch")
+            and not map_kwargs.get("with_rank") and not map_kwargs.get("input_columns") and not map_kwargs.get("with_indices"))
+
+
+def text_pipeline_or_none(dataset, map_kwargs, model=None, tokenizer=None, tokenization_kwargs={}, key="passage",
+                          save_as="text_embedding", output_key=None, forward_kwargs={}, layers=None, kb=None, call=None, run=None,
+                          qe_predictions_key=None, **other):
+    """A :class:`TextEmbedPipeline` when the job is the plain one the prefetcher can reproduce ahead of ``Dataset.map`` --
+    a CUDA model, a plain ``datasets.Dataset`` walked in order, texts = ``batch[key]`` as they are -- else None (the caller
+    then maps the serial ``embed``)."""
+    if not pipeline_enabled() or other or layers is not None or kb is not None or run is not None or qe_predictions_key is not None:
+        return None
+    if model is None or tokenizer is None or not torch.cuda.is_available() or not _plain_dataset(dataset, map_kwargs):
+        return None
+    from .ir.embedding import is_multimodal
+    if is_multimodal(model) or not isinstance(model, torch.nn.Module):
+        return None
+    first = next(iter(model.parameters()), None)
+    first = first if first is not None else next(iter(model.buffers()), None)
+    if first is None or not first.is_cuda or _arrow_strings(dataset, key) is None:
+        return None
+    return TextEmbedPipeline(dataset, model, tokenizer, tokenization_kwargs, key, save_as, output_key, forward_kwargs, call,
+                             int(map_kwargs.get("batch_size", 1000)))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# images
+# ----------------------------------------------------------------------------------------------------------------------
+class ImageEmbedPipeline:
+    """The image job (meerqat/image/embedding.py:125-166) with the host stages of batch i + 1 -- file decoding, packing the
+    decoded RGB images into one pinned buffer, H2D and the Pillow-exact resize / crop / normalise kernels on a side stream --
+    hidden behind the CLIP forward of batch i.  Needs the device-side transform (``transform.on_device``)."""
+
+    def __init__(self, dataset, model, transform, save_as, image_key, call, pool, batch_size, depth=2):
+        self.model, self.transform, self.save_as, self.image_key, self.call, self.pool = model, transform, save_as, image_key, call, pool
+        self.column = _arrow_strings(dataset, image_key)
+        n = len(dataset)
+        self.bounds = [(s, min(s + batch_size, n)) for s in range(0, n, batch_size)]
+        first = next(iter(model.parameters()), None)
+        self.device = (first if first is not None else next(iter(model.buffers()))).device
+        self.main = torch.cuda.current_stream(self.device)
+        self.side = torch.cuda.Stream(device=self.device)
+        self.out_ring = _PinnedRing(3)
+        self.stats = {"batches": 0, "decode_s": 0.0, "prepare_s": 0.0, "launch_s": 0.0, "wait_result_s": 0.0}
+        self.look = Lookahead(len(self.bounds), self._prepare, self._launch, depth=depth)
+
+    def _prepare(self, j):
+        from .data.loading import load_image_batch
+        t0 = time.perf_counter()
+        s, e = self.bounds[j]
+        names = self.column.slice(s, e - s).to_pylist()
+        images = load_image_batch(names, pool=self.pool, as_arrays=True)
+        kept = [i for i, im in enumerate(images) if im is not None]
+        self.stats["decode_s"] += time.perf_counter() - t0
+        inputs = ev = None
+        if kept:
+            with torch.cuda.device(self.device), torch.cuda.stream(self.side):
+                inputs = dict(self.transform([images[i] for i in kept], return_tensors="pt"))  # packs, copies, runs its kernels HERE
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+        self.stats["prepare_s"] += time.perf_counter() - t0
+        return {"names": names, "kept": kept, "inputs": inputs, "event": ev, "rows": len(names)}
+
+    def _launch(self, p):
+        t0 = time.perf_counter()
+        if not p["kept"]:
+            return _Handle(None, torch.empty((0, 1)), 0, extra=(p["names"], p["kept"], p["rows"]))
+        with torch.cuda.device(self.device):
+            self.main.wait_event(p["event"])
+            for t in p["inputs"].values():
+                t.record_stream(self.main)
+            method = self.model if self.call is None else getattr(self.model, self.call)
+            with torch.no_grad():
+                out = method(**p["inputs"])
+            if not isinstance(out, torch.Tensor):  # transformers >= 5 returns a ModelOutput
+                out = out.pooler_output
+            out = out.reshape(len(p["kept"]), -1).to(torch.float32).contiguous()
+            slot, buf = self.out_ring.take(out.numel() * 4)
+            pinned = buf[: out.numel() * 4].view(torch.float32).view(out.shape)
+            pinned.copy_(out, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            self.out_ring.events[slot] = ev
+        self.stats["launch_s"] += time.perf_counter() - t0
+        return _Handle(ev, pinned, len(p["kept"]), extra=(p["names"], p["kept"], p["rows"]))
+
+    def embed(self, batch, indices):
+        i = self.stats["batches"]
+        s, e = self.bounds[i] if i < len(self.bounds) else (-1, -1)
+        if len(indices) != e - s or int(indices[0]) != s or int(indices[-1]) != e - 1:
+            raise RuntimeError("Dataset.map handed over batches in another order than the prefetcher prepared them; "
+                               "set MQ_EMBED_PIPELINE=0")
+        t0 = time.perf_counter()
+        found, (names, kept, rows) = self.look.step(i)
+        self.stats["wait_result_s"] += time.perf_counter() - t0
+        if names != batch[self.image_key]:
+            raise RuntimeError(f"the prefetched file names of batch {i} differ from what Dataset.map decoded; set MQ_EMBED_PIPELINE=0")
+        self.stats["batches"] = i + 1
+        output = [None] * rows
+        if not kept:
+            return output  # (sic) the reference returns the bare list here: meerqat/image/embedding.py:134-135
+        for row, k in enumerate(kept):
+            output[k] = found[row]
+        batch[self.save_as] = output
+        return batch
+
+    def close(self):
+        self.stats["wait_prepared_s"] = self.look.wait_prepared_s
+        self.look.close()
+
+
+def image_pipeline_or_none(dataset, map_kwargs, model=None, transform=None, save_as="image_embedding", image_key="image", call=None,
+                           pool=None, **other):
+    if not pipeline_enabled() or other or model is None or transform is None or not getattr(transform, "on_device", False):
+        return None
+    if not torch.cuda.is_available() or not _plain_dataset(dataset, map_kwargs) or _arrow_strings(dataset, image_key) is None:
+        return None
+    return ImageEmbedPipeline(dataset, model, transform, save_as, image_key, call, pool, int(map_kwargs.get("batch_size", 1000)))
