@@ -474,11 +474,13 @@ def _pack_plan(attention_mask):
     return pack_plan_from_lengths(lens, L, attention_mask.device)
 
 
-def pack_plan_from_lengths(lens, L, device):
+def pack_plan_from_lengths(lens, L, device, stage=None):
     """The plan of :func:`_pack_plan` from the sequence lengths alone (HOST int array [B]; the mask is right-padded 0/1 by
     construction, e.g. lengths the tokenizer reported): every array is built on the host and copied to ``device`` on the
     CURRENT stream -- no device -> host synchronisation, so an input pipeline can prepare the plan of batch i + 1 on a side
-    stream while batch i runs (viquae_amd/pipeline.py).  None when packing does not pay (see _pack_plan)."""
+    stream while batch i runs (viquae_amd/pipeline.py).  ``stage`` (optional): numpy array -> page-locked CPU tensor holding a
+    copy of it; the copies to the device are then truly asynchronous (a copy from pageable memory blocks the calling thread,
+    on this runtime until the device has drained).  None when packing does not pay (see _pack_plan)."""
     if os.environ.get("MQ_ENC_PACKED", "1") == "0" or os.environ.get("MQ_ENC_PAD_SKIP", "1") == "0":
         return None
     lens = np.asarray(lens, dtype=np.int64)
@@ -492,7 +494,8 @@ def pack_plan_from_lengths(lens, L, device):
     keep_host = pos_host + np.repeat(np.arange(B, dtype=np.int64) * L, lens)
 
     def dev(a):
-        return torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)
+        a = np.ascontiguousarray(a)
+        return (stage(a) if stage is not None else torch.from_numpy(a)).to(device, non_blocking=True)
 
     keep, pos, cu = dev(keep_host), dev(pos_host.astype(np.int32)), dev(cu_host.astype(np.int32))
     classes = []

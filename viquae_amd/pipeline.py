@@ -135,6 +135,7 @@ class FastBatchTokenizer:
     def __init__(self, tokenizer, tokenization_kwargs):
         self.tokenizer, self.kwargs = tokenizer, dict(tokenization_kwargs)
         self.ok = False
+        self.left = getattr(tokenizer, "padding_side", "right") == "left"
         backend = getattr(tokenizer, "backend_tokenizer", None) or getattr(tokenizer, "_tokenizer", None)
         kw = self.kwargs
         if backend is None or set(kw) - self.SUPPORTED or kw.get("return_tensors") != "pt":
@@ -268,7 +269,8 @@ class TextEmbedPipeline:
             L = self.fast.width(lens)
             names = self.fast.names
             nbytes = len(names) * len(texts) * L * 8
-            slot, buf = self.in_ring.take(nbytes)
+            plan_bytes = int(lens.sum()) * 12 + len(texts) * 24 + 1024   # keep i64 + pos i32 per token; cu, classes, cls rows
+            slot, buf = self.in_ring.take(nbytes + plan_bytes)
             host = {}
             for n_, name in enumerate(names):
                 host[name] = buf[n_ * len(texts) * L * 8:(n_ + 1) * len(texts) * L * 8].view(torch.int64).view(len(texts), L)
@@ -292,7 +294,16 @@ class TextEmbedPipeline:
             plan = None
             if self.use_plan and lens is not None and "attention_mask" in inputs:
                 from .encoders import pack_plan_from_lengths
-                plan = pack_plan_from_lengths(lens, inputs["input_ids"].shape[1], self.device)
+                cursor = [(nbytes + 63) // 64 * 64]
+
+                def stage(a):  # the plan's host arrays go through the same pinned slot as the token ids
+                    nb = a.nbytes
+                    dst = buf[cursor[0]:cursor[0] + nb].view(torch.from_numpy(a).dtype).view(a.shape)
+                    cursor[0] += (nb + 63) // 64 * 64
+                    dst.numpy()[...] = a
+                    return dst
+
+                plan = pack_plan_from_lengths(lens, inputs["input_ids"].shape[1], self.device, stage=stage)
             ev = torch.cuda.Event()
             ev.record(self.side)
         self.in_ring.events[slot] = ev
@@ -411,14 +422,23 @@ class ImageEmbedPipeline:
         self.side = torch.cuda.Stream(device=self.device)
         self.out_ring = _PinnedRing(3)
         self.stats = {"batches": 0, "decode_s": 0.0, "prepare_s": 0.0, "launch_s": 0.0, "wait_result_s": 0.0}
+        # Without the caller's process pool (`processes` of the reference's config) the files are decoded by a pool of
+        # THREADS: Pillow releases the GIL inside its decoders and converters, and an array crosses no pipe.
+        self.threads = None
+        if pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self.threads = ThreadPoolExecutor(max(1, min(32, (os.cpu_count() or 2) - 1)))
         self.look = Lookahead(len(self.bounds), self._prepare, self._launch, depth=depth)
 
     def _prepare(self, j):
-        from .data.loading import load_image_batch
+        from .data.loading import load_image_array, load_image_batch
         t0 = time.perf_counter()
         s, e = self.bounds[j]
         names = self.column.slice(s, e - s).to_pylist()
-        images = load_image_batch(names, pool=self.pool, as_arrays=True)
+        if self.threads is not None:
+            images = list(self.threads.map(load_image_array, names))
+        else:
+            images = load_image_batch(names, pool=self.pool, as_arrays=True)
         kept = [i for i, im in enumerate(images) if im is not None]
         self.stats["decode_s"] += time.perf_counter() - t0
         inputs = ev = None
@@ -476,6 +496,8 @@ class ImageEmbedPipeline:
     def close(self):
         self.stats["wait_prepared_s"] = self.look.wait_prepared_s
         self.look.close()
+        if self.threads is not None:
+            self.threads.shutdown(wait=False)
 
 
 def image_pipeline_or_none(dataset, map_kwargs, model=None, transform=None, save_as="image_embedding", image_key="image", call=None,
