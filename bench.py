@@ -104,16 +104,46 @@ def mfma_ceiling(device, stream, achieved_tflops):
     return res
 
 
+def host_cpus():
+    """Physical cores, hardware threads and the threads this process may use -- stated ONCE for every CPU leg."""
+    logical = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = logical
+    physical = None
+    try:
+        cores = set()
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+        physical = len(cores) or None
+    except OSError:
+        pass
+    return {"physical_cores": physical or logical, "hardware_threads": logical, "usable_threads": usable}
+
+
 def cpu_baseline(idx, Q, seconds):
     """CPU legs on the GPU box's host cores, each on a BOUNDED sample of the same workload (ALL queries of the step, so
     every core has work, against the first `rows` KB rows sized by a calibration run), scaled by rows to the metric's
     unit (queries/s over the full 1.5M x 768 KB):
-      * fmaf_chain_oracle: oracle/knn_oracle.c, the bit-exact checker (OpenMP over 32-query blocks);
-      * blas_sgemm_topk:   oracle.knn.knn_blas, FAISS's own organisation for >= 20 queries (sgemm blocks + k best per
-                           query) on torch's CPU BLAS, all cores -- the faster leg, and the one `value` reports.
-    Neither is FAISS itself (not installable here): kind = "port"."""
+      * fmaf_chain_oracle:    oracle/knn_oracle.c, the bit-exact checker (OpenMP over 32-query blocks);
+      * faiss_organisation:   oracle.knn.knn_blas = FAISS's own organisation for >= 20 queries: blocks of 4096 queries x
+                              1024 database rows through the host BLAS's sgemm (torch.mm = MKL, all cores), then FAISS's
+                              strict-'>' heap rule per query in C / OpenMP (oracle_heap_add_block) -- the faster leg, and
+                              the one `value` reports.
+    Neither is FAISS itself (not installable here): kind = "port (FAISS organisation)"."""
     from oracle import knn as ok
     import torch
+    cpus = host_cpus()
     threads = ok.num_threads()
     Qh = Q.cpu().numpy()
     nq = Qh.shape[0]
@@ -134,17 +164,21 @@ def cpu_baseline(idx, Q, seconds):
         return {"value": round(value, 2), "seconds": round(tc, 2), "kb_rows_sampled": rows_s,
                 "gflops": round(2.0 * nq * rows_s * DIM / tc / 1e9, 1), "what": name}
 
-    legs = {"fmaf_chain_oracle": leg(lambda X, Qq: ok.knn(X, Qq, TOPK, metric=0), 4096, seconds * 0.6,
+    legs = {"fmaf_chain_oracle": leg(lambda X, Qq: ok.knn(X, Qq, TOPK, metric=0), 4096, seconds * 0.5,
                                      f"oracle/knn_oracle.c (k-ordered fmaf chain = the bit-exact checker), OpenMP x{threads}")}
     try:
+        torch.set_num_threads(cpus["physical_cores"])  # one sgemm thread per physical core (SMT siblings only add contention)
         tt = torch.get_num_threads()
-        legs["blas_sgemm_topk"] = leg(lambda X, Qq: ok.knn_blas(X, Qq, TOPK, metric=0), 1 << 16, seconds * 0.6,
-                                      f"oracle.knn.knn_blas (torch CPU sgemm blocks + topk, FAISS's >= 20-query organisation), {tt} threads")
+        legs["faiss_organisation"] = leg(lambda X, Qq: ok.knn_blas(X, Qq, TOPK, metric=0), 1 << 16, seconds * 0.7,
+                                         f"oracle.knn.knn_blas: 4096 x 1024 sgemm blocks on the host BLAS (torch.mm, {tt} threads) + FAISS's "
+                                         f"strict-'>' heap per query in C / OpenMP x{threads}")
     except Exception as e:
-        legs["blas_sgemm_topk"] = {"value": 0.0, "what": f"failed: {e!r}"}
+        legs["faiss_organisation"] = {"value": 0.0, "what": f"failed: {e!r}"}
     best = max(legs, key=lambda n: legs[n]["value"])
     rec = {
-        "value": legs[best]["value"], "unit": "queries/s", "cores": threads, "kind": "port",
+        "value": legs[best]["value"], "unit": "queries/s", "cores": cpus["physical_cores"], "threads": threads,
+        "kind": "port (FAISS organisation)" if best == "faiss_organisation" else "port",
+        "host": cpus,
         "sample": f"{best}: {legs[best]['what']}; {nq} queries x the first {legs[best]['kb_rows_sampled']} KB rows, top-{TOPK}: "
                   f"{legs[best]['seconds']} s ({legs[best]['gflops']} GFLOP/s); scaled by rows to {idx.ntotal} x {DIM}",
         "legs": legs,
@@ -153,20 +187,54 @@ def cpu_baseline(idx, Q, seconds):
 
 
 def cpu_encoder_baseline(n=64):
-    """the CPU restatement of the encoders (oracle/encoders.py: numpy fp32, op order of
-    meerqat/models/bert.py) on `n` passages of 100 tokens (BERT-base) and `n` 224x224 images (CLIP ViT-B/32), seeded weights."""
-    from oracle import encoders as oe
+    """the reference's OWN CPU encode path -- Hugging Face `DPRContextEncoder` /
+    `CLIPModel.get_image_features` (what meerqat/ir/embedding.py:226 and meerqat/image/embedding.py:156-161 call) on torch-CPU
+    fp32, all cores, `n` passages of 100 tokens / `n` 224 x 224 images, default-config random weights -- when `transformers`
+    is importable on the box (it is in this image); otherwise the numpy restatement oracle/encoders.py (`kind: "port"`)."""
+    import torch
+    cpus = host_cpus()
     rng = np.random.default_rng(0)
-    out = {"cores": os.cpu_count(), "kind": "port", "sample": f"oracle/encoders.py (numpy fp32 on the host BLAS), {n} passages x 100 tokens / {n} images"}
-    state = oe.seeded_state(oe.bert_param_shapes(oe.BERT_BASE), 1)
     ids = rng.integers(1000, 30000, (n, 100)).astype(np.int64)
+    px = rng.standard_normal((n, 3, 224, 224)).astype(np.float32)
+    try:
+        import transformers
+        torch.set_num_threads(cpus["physical_cores"])
+        out = {"cores": cpus["physical_cores"], "threads": torch.get_num_threads(), "kind": "hf-transformers torch-cpu",
+               "sample": f"transformers {transformers.__version__} DPRContextEncoder / CLIPModel.get_image_features, default configs "
+                         f"(bert-base / ViT-B/32), random weights, fp32, {n} passages x 100 tokens / {n} images, one batch"}
+        with torch.no_grad():
+            dpr = transformers.DPRContextEncoder(transformers.DPRConfig()).eval()
+            t_ids = torch.from_numpy(ids)
+            dpr(input_ids=t_ids[:4], attention_mask=torch.ones_like(t_ids[:4]))
+            best = 1e9
+            for _ in range(2):
+                t0 = time.perf_counter()
+                dpr(input_ids=t_ids, attention_mask=torch.ones_like(t_ids))
+                best = min(best, time.perf_counter() - t0)
+            out["dpr_passages_per_s"] = round(n / best, 2)
+            del dpr
+            clip = transformers.CLIPModel(transformers.CLIPConfig()).eval()
+            t_px = torch.from_numpy(px)
+            clip.get_image_features(pixel_values=t_px[:4])
+            best = 1e9
+            for _ in range(2):
+                t0 = time.perf_counter()
+                clip.get_image_features(pixel_values=t_px)
+                best = min(best, time.perf_counter() - t0)
+            out["clip_images_per_s"] = round(n / best, 2)
+        return out
+    except Exception as e:  # noqa: BLE001 - fall back to the port
+        why = repr(e)
+    from oracle import encoders as oe
+    out = {"cores": cpus["physical_cores"], "threads": cpus["usable_threads"], "kind": "port",
+           "sample": f"oracle/encoders.py (numpy fp32 on the host BLAS), {n} passages x 100 tokens / {n} images; transformers unusable: {why}"}
+    state = oe.seeded_state(oe.bert_param_shapes(oe.BERT_BASE), 1)
     oe.bert_forward(state, oe.BERT_BASE, ids[:4], None, np.ones_like(ids[:4]))
     t0 = time.perf_counter()
     oe.bert_forward(state, oe.BERT_BASE, ids, None, np.ones_like(ids))
     out["dpr_passages_per_s"] = round(n / (time.perf_counter() - t0), 2)
     del state
     state = oe.seeded_state(oe.clip_vision_param_shapes(oe.CLIP_VITB32), 2)
-    px = rng.standard_normal((n, 3, 224, 224)).astype(np.float32)
     oe.clip_vision_forward(state, oe.CLIP_VITB32, px[:4])
     t0 = time.perf_counter()
     oe.clip_vision_forward(state, oe.CLIP_VITB32, px)
@@ -502,7 +570,7 @@ def main():
             try:
                 rec["cpu_baseline"] = cpu_baseline(local, Q, args.cpu_seconds)
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
-                rec["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port",
+                rec["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port (FAISS organisation)",
                                        "sample": f"failed: {e!r}"}
             if not args.no_encoders:
                 try:
@@ -544,13 +612,47 @@ def main():
                 torch.cuda.synchronize()
                 t3 = (time.perf_counter() - t3) / 5
                 del clip_idx
+                # the headline's workload on DPR-LIKE data (zero-mean Gaussians flatter the screen): every
+                # vector = a shared direction of norm 9 + isotropic noise of sd 0.25 (scores ~81 +- a few units, like real DPR
+                # inner products); same index class, same search call, exact results
+                try:
+                    gd = torch.Generator(device=device)
+                    gd.manual_seed(7)
+                    mu = torch.randn((1, DIM), generator=gd, device=device)
+                    mu = 9.0 * mu / mu.norm()
+                    dpr_idx = MI355XFlatIndex(device=local_rank, string_factory="Flat", metric_type=0, screen=True)
+                    for s0 in range(0, rows, 1 << 16):
+                        dpr_idx.add(mu + 0.25 * torch.randn((min(1 << 16, rows - s0), DIM), generator=gd, device=device), total_hint=rows)
+                    Qd = mu + 0.25 * torch.randn((nq, DIM), generator=gd, device=device)
+                    dpr_idx.search_device(Qd, k)
+                    torch.cuda.synchronize()
+                    td = time.perf_counter()
+                    for _ in range(5):
+                        dpr_idx.search_device(Qd, k)
+                    torch.cuda.synchronize()
+                    td = (time.perf_counter() - td) / 5
+                    std = dpr_idx.screen_stats(nq, k)
+                    dpr_like = {"workload": f"{rows}x{DIM} KB of shared-direction (norm 9) + N(0, 0.25^2) noise vectors, {nq} such queries, exact IP "
+                                            f"top-{k} (screened path, bf16 copy centred on the KB mean)",
+                                "queries_per_s": round(nq / td, 1), "ms_per_step": round(td * 1e3, 3),
+                                "candidates_rescored_per_query": round(std[1] / nq, 1), "query_tiles_recomputed_exactly": std[0]}
+                    del dpr_idx, Qd
+                except Exception as e:
+                    dpr_like = {"error": repr(e)}
                 try:
                     import bench_host_path
                     surface = bench_host_path.main(rows=rows)
                 except Exception as e:
                     surface = {"error": repr(e)}
+                try:
+                    import bench_encode_surface
+                    encode_surface = bench_encode_surface.main()
+                except Exception as e:
+                    encode_surface = {"error": repr(e)}
                 rec["secondary"] = {
                     "reference_call_surface": surface,
+                    "encode_call_surface": encode_surface,
+                    "dpr_like_data": dpr_like,
                     "clip_kb_search": {"workload": f"{rows}x512 'L2norm,Flat' inner-product KB, {nq} queries, exact top-{k} (screened path)",
                                        "queries_per_s": round(nq / t3, 1), "ms_per_step": round(t3 * 1e3, 3)},
                     "kb_passages_encoded_per_s": round(d["passages_per_s"], 1),
