@@ -914,18 +914,32 @@ __global__ __launch_bounds__(WIDE ? 512 : 256) void attention_x3_kernel(const fl
     // K / V staging, one item = 4 consecutive keys x 4 consecutive d: K rows leave as 8-byte (hi, lo) pieces as before; V^T
     // gets, for each of the 4 d, the 4 keys as ONE 8-byte piece per (hi, lo) instead of four 2-byte stores (keys 4 kq .. + 3
     // share a 16-byte chunk), and the conversions run on packed pairs
-    for (int e = tid; e < nt_live * 8 * (DH / 4); e += nthr) {
-        const int kq = e / (DH / 4), c4 = (e % (DH / 4)) * 4, j0 = 4 * kq;
-        float4 kf[4], vf[4];
+    for (int e0 = tid; e0 < nt_live * 8 * (DH / 4); e0 += 2 * nthr) {
+        // two items per round, all sixteen 16-byte loads issued before the first conversion: ONE round trip to HBM / L2 for
+        // the K / V of a 100-key sequence instead of two (the kernel is bound by these round trips, not by its arithmetic:
+        // a variant that read q / k / v as ready-made bf16 pairs -- no conversion at all -- measured 3 % SLOWER, round 3)
+        float4 kf2[2][4], vf2[2][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            kf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            vf[u] = kf[u];
-            if (kb0 + j0 + u < L) {
-                kf[u] = *reinterpret_cast<const float4*>(base + (size_t)(kb0 + j0 + u) * ld + H + c4);
-                vf[u] = *reinterpret_cast<const float4*>(base + (size_t)(kb0 + j0 + u) * ld + 2 * H + c4);
+        for (int it = 0; it < 2; ++it) {
+            const int e = e0 + it * nthr;
+            const int kq = e / (DH / 4), c4 = (e % (DH / 4)) * 4, j0 = 4 * kq;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                kf2[it][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                vf2[it][u] = kf2[it][u];
+                if (e < nt_live * 8 * (DH / 4) && kb0 + j0 + u < L) {
+                    kf2[it][u] = *reinterpret_cast<const float4*>(base + (size_t)(kb0 + j0 + u) * ld + H + c4);
+                    vf2[it][u] = *reinterpret_cast<const float4*>(base + (size_t)(kb0 + j0 + u) * ld + 2 * H + c4);
+                }
             }
         }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+        const int e = e0 + it * nthr;
+        if (e >= nt_live * 8 * (DH / 4)) break;
+        const int kq = e / (DH / 4), c4 = (e % (DH / 4)) * 4, j0 = 4 * kq;
+        const float4* kf = kf2[it];
+        const float4* vf = vf2[it];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // K row j0 + u: four consecutive d -> 8 bytes inside chunk c4 / 8
             const int j = j0 + u;
@@ -946,6 +960,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256) void attention_x3_kernel(const fl
             *reinterpret_cast<uint2*>(Vth + voff) = h2;
             *reinterpret_cast<uint2*>(Vtl + voff) = l2;
         }
+        }
     }
     for (int j = tid; j < NK; j += nthr)
         addm[j] = (kb0 + j < L && (!mask || mask[row0 + kb0 + j] != 0)) ? 0.f : -INFINITY;
@@ -956,17 +971,32 @@ __global__ __launch_bounds__(WIDE ? 512 : 256) void attention_x3_kernel(const fl
 #pragma unroll
     for (int t = 0; t < NKT; ++t) sacc[t] = (f32x16){0};
     const int ksw = (i >> 1) & 7;
+    // Tiles in PAIRS: the two accumulators of a pair alternate, so no MFMA waits for the one issued just before it (a
+    // dependent 32x32x16 MFMA cannot issue back to back); every accumulator still sees lo.hi, hi.lo, hi.hi for m = 0 .. 3 in
+    // that order, so the sums keep their bits.
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) {
+    for (int t = 0; t < NKT; t += 2) {
         if (t >= nt_live) break;
+        const bool two = t + 1 < nt_live;  // block-uniform
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int ko = (32 * t + i) * 128 + (((2 * m + kg) ^ ksw) * 16);
-            const bf16x8_t kh_ = *reinterpret_cast<const bf16x8_t*>(Kh + ko);
-            const bf16x8_t kl_ = *reinterpret_cast<const bf16x8_t*>(Kl + ko);
-            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl_, qh[m], sacc[t], 0, 0, 0);
-            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh_, ql[m], sacc[t], 0, 0, 0);
-            sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh_, qh[m], sacc[t], 0, 0, 0);
+            const bf16x8_t kh0 = *reinterpret_cast<const bf16x8_t*>(Kh + ko);
+            const bf16x8_t kl0 = *reinterpret_cast<const bf16x8_t*>(Kl + ko);
+            if (two) {
+                const bf16x8_t kh1 = *reinterpret_cast<const bf16x8_t*>(Kh + ko + 32 * 128);
+                const bf16x8_t kl1 = *reinterpret_cast<const bf16x8_t*>(Kl + ko + 32 * 128);
+                sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl0, qh[m], sacc[t], 0, 0, 0);
+                sacc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl1, qh[m], sacc[t + 1], 0, 0, 0);
+                sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh0, ql[m], sacc[t], 0, 0, 0);
+                sacc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh1, ql[m], sacc[t + 1], 0, 0, 0);
+                sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh0, qh[m], sacc[t], 0, 0, 0);
+                sacc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh1, qh[m], sacc[t + 1], 0, 0, 0);
+            } else {
+                sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl0, qh[m], sacc[t], 0, 0, 0);
+                sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh0, ql[m], sacc[t], 0, 0, 0);
+                sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh0, qh[m], sacc[t], 0, 0, 0);
+            }
         }
     }
     // sacc[t][reg] = <k_key, q_query>, key = 32 t + (reg&3) + 8 (reg>>2) + 4 kg, query = this lane's column
@@ -975,22 +1005,32 @@ __global__ __launch_bounds__(WIDE ? 512 : 256) void attention_x3_kernel(const fl
     for (int t = 0; t < NKT; ++t) {
         if (t >= nt_live) break;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int key = 32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
-            float sv = sacc[t][reg] * scale2 + addm[key];   // scores in units of log2 e: the exponentials below are v_exp_f32
-            if (causal && kb0 + key > qrow) sv = -INFINITY;
-            sacc[t][reg] = sv;
-            mx = fmaxf(mx, sv);
+        for (int a4 = 0; a4 < 4; ++a4) {
+            // registers 4 a4 .. 4 a4 + 3 hold four CONSECUTIVE keys: their additive mask entries are one 16-byte LDS read
+            const int key0 = 32 * t + 8 * a4 + 4 * kg;
+            const float4 am = *reinterpret_cast<const float4*>(addm + key0);
+            const float amv[4] = {am.x, am.y, am.z, am.w};
+#pragma unroll
+            for (int b4 = 0; b4 < 4; ++b4) {
+                const int reg = 4 * a4 + b4;
+                float sv = sacc[t][reg] * scale2 + amv[b4];   // scores in units of log2 e: the exponentials below are v_exp_f32
+                if (causal && kb0 + key0 + b4 > qrow) sv = -INFINITY;
+                sacc[t][reg] = sv;
+                mx = fmaxf(mx, sv);
+            }
         }
     }
     mx = fmaxf(fmaxf(mx, __shfl_xor(mx, 32)), m_run);
+    // a masked score is -inf and 2^(-inf - max) is exactly 0; only a row with NO live key so far (max = -inf) needs a guard,
+    // taken once per lane instead of once per score: subtracting 0 keeps every -inf, hence every probability 0 as before
+    const float mxs = (mx == -INFINITY) ? 0.f : mx;
     float bsum = 0.f;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
         if (t >= nt_live) break;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const float p = (sacc[t][reg] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(sacc[t][reg] - mx);
+            const float p = __builtin_amdgcn_exp2f(sacc[t][reg] - mxs);
             sacc[t][reg] = p;
             bsum += p;
         }
@@ -1026,20 +1066,18 @@ __global__ __launch_bounds__(WIDE ? 512 : 256) void attention_x3_kernel(const fl
             bf16x8_t ph, pl;
             split8(make_float4(p8[0], p8[1], p8[2], p8[3]), make_float4(p8[4], p8[5], p8[6], p8[7]), ph, pl);
             const int ck = 4 * t + 2 * g + kg;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const int vo = (32 * dt + i) * (NK * 2) + ((ck ^ vsw0) * 16);
-                const bf16x8_t vh_ = *reinterpret_cast<const bf16x8_t*>(Vth + vo);
-                const bf16x8_t vl_ = *reinterpret_cast<const bf16x8_t*>(Vtl + vo);
-                if (dt == 0) {
-                    oacc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl_, ph, oacc0, 0, 0, 0);
-                    oacc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh_, pl, oacc0, 0, 0, 0);
-                    oacc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh_, ph, oacc0, 0, 0, 0);
-                } else {
-                    oacc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl_, ph, oacc1, 0, 0, 0);
-                    oacc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh_, pl, oacc1, 0, 0, 0);
-                    oacc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh_, ph, oacc1, 0, 0, 0);
-                }
+            {   // both 32-row halves of d, their accumulators alternating (see the note at the S products)
+                const int vo0 = i * (NK * 2) + ((ck ^ vsw0) * 16), vo1 = vo0 + 32 * (NK * 2);
+                const bf16x8_t vh0 = *reinterpret_cast<const bf16x8_t*>(Vth + vo0);
+                const bf16x8_t vl0 = *reinterpret_cast<const bf16x8_t*>(Vtl + vo0);
+                const bf16x8_t vh1 = *reinterpret_cast<const bf16x8_t*>(Vth + vo1);
+                const bf16x8_t vl1 = *reinterpret_cast<const bf16x8_t*>(Vtl + vo1);
+                oacc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl0, ph, oacc0, 0, 0, 0);
+                oacc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl1, ph, oacc1, 0, 0, 0);
+                oacc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh0, pl, oacc0, 0, 0, 0);
+                oacc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh1, pl, oacc1, 0, 0, 0);
+                oacc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh0, ph, oacc0, 0, 0, 0);
+                oacc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh1, ph, oacc1, 0, 0, 0);
             }
         }
     }
