@@ -1,5 +1,6 @@
 #!/bin/bash
 # Builds a variant of libmeerqat_hip.so for same-box A/B runs:  tools/ab_build.sh <name> "<-D flags>"  -> ab/lib_<name>.so
+# The -DMQ_ABL_* / MQ_PROBE* switches live in tools/ablate/lab_switches.patch (see tools/ablate/README.md): apply it first.
 # (ab/ is git-ignored; it travels to the GPU box with gpurun.  Use with MEERQAT_HIP_LIB=ab/lib_<name>.so.)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)

@@ -219,12 +219,6 @@ constexpr int X_STAGE = X_A_BYTES + 2 * X_W_BYTES;
 constexpr int X_LDS_BYTES = 2 * X_STAGE;  // 128 KiB
 
 __device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8_t& hi, bf16x8_t& lo) {
-#ifdef MQ_ABL_NOSPLIT  // timing ablation only (wrong results): what the in-loop conversions cost
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    hi = __builtin_bit_cast(bf16x8_t, (u32x4){__float_as_uint(u.x), __float_as_uint(u.y), __float_as_uint(u.z), __float_as_uint(u.w)});
-    lo = __builtin_bit_cast(bf16x8_t, (u32x4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)});
-    return;
-#endif
     const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -359,10 +353,8 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-#ifndef MQ_GEMM_ABL_NODMA  // timing ablations (tools/ab_build.sh + tools/ab_gemm.sh): not part of the product build
         if (kb + 1 < nk) issue(cur, kb + 1, stage ^ 1);
         else
-#endif
         if (next < ntiles) {  // last step: the other stage is free -> the next tile's first K stage
             nxt = make_tile(next);
             issue(nxt, 0, stage ^ 1);
@@ -397,13 +389,6 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
         stage ^= 1;
     }
 
-#ifdef MQ_GEMM_ABL_NOEPI
-    asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11));
-    if (next >= ntiles) break;
-    tile = next;
-    cur = nxt;
-    continue;
-#endif
     const int m0 = cur.m0, n0 = cur.n0;
     // the C-store epilogue, instantiated twice: a tile that lies wholly inside C (every tile of the encoder shapes) carries no
     // bound tests and no exec-mask juggling around its 64 stores per lane

@@ -616,11 +616,6 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
 #undef MQ_M4
 #undef MQ_LD2
 
-#ifdef MQ_ABLATE_NO_EPILOGUE
-        // timing ablation only (tools/): keeps the accumulators live, skips the selection
-        asm volatile("" ::"v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11));
-        continue;
-#endif
         // ---------------- selection epilogue ----------------
         // C/D map of 32x32x2: column j = lane&31 (query 2j+b of the wave's panel),
         // row i' = (reg&3) + 8*(reg>>2) + 4*(lane>>5)  (KB row 2i'+a of the wave's panel)
@@ -689,10 +684,6 @@ __global__ __launch_bounds__(1024) void knn_scan_kernel(const ScanArgs a) {
         MQ_T(1)
         __syncthreads();  // appended keys are in L2 (vmcnt(0) precedes the barrier), counters final
         MQ_T(2)
-#ifdef MQ_ABLATE_NO_FLUSH
-        if (tid < TQ) gcnt[tid] = 0;  // timing ablation only: drop the candidates
-        continue;
-#endif
         const bool last = (c + 1 == c1);
         for (int j = 0; j < TQ / NWAVES; ++j) {
             const int q = w + NWAVES * j;
@@ -867,12 +858,6 @@ __global__ __launch_bounds__(256) void shard_merge_big_kernel(const float* __res
 
 #include "knn_screen.inc"
 #include "knn_direct.inc"
-#ifdef MQ_PROBE8
-#include "knn_probe8.inc"
-#endif
-#if defined(MQ_PROBE2X8) || defined(MQ_ABL_SYNTHEPI)
-#include "knn_probe2x8.inc"
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1378,16 +1363,8 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         a.dbg = dbg_ptr();
         a.N = N; a.dp = dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx_screen; a.nchunks = g.nchunks;
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
-#if defined(MQ_PROBE2X8)
-        MQ_DYNAMIC_LDS(P2_LDS, screen_probe2x8_kernel);
-        hipLaunchKernelGGL(screen_probe2x8_kernel, dim3((unsigned)(g.nqt * g.S * 2)), dim3(512), P2_LDS, st, a);
-#elif defined(MQ_PROBE8)
-        MQ_DYNAMIC_LDS(S_LDS_TOTAL, screen_probe8_kernel);
-        hipLaunchKernelGGL(screen_probe8_kernel, dim3((unsigned)(g.nqt * g.S)), dim3(512), S_LDS_TOTAL, st, a);
-#else
         MQ_DYNAMIC_LDS(S_LDS_TOTAL, screen_scan_kernel);
         hipLaunchKernelGGL(screen_scan_kernel, dim3((unsigned)(g.nqt * g.S)), dim3(1024), S_LDS_TOTAL, st, a);
-#endif
         MQ_HIP(hipGetLastError());
         if (ev_scan_end) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_end, st));
     }
