@@ -172,7 +172,8 @@ def test_config3_search_half_1p5M_x_512_l2norm_flat():
 def test_config1_integer_lattice_variants_against_torch_mm(amp):
     """SURVEY 8(d) config 1, second variant: a 1.5M x 768 KB of integers.  Every fp32 summation order is exact on such data
     (|score| <= 768 * 128^2 < 2^24), so a plain torch matmul is an INDEPENDENT oracle at full size: the scores must equal its
-    top-100 values bit for bit and the ids must follow FAISS's rule (every row above the k-th score, then the LOWEST ids among
+    top-100 values bit for bit and the ids must follow this library's documented tie policy, id_asc -- NOT a claim about FAISS,
+    whose tie sets depend on its version and on k (oracle/knn_oracle.c) -- (every row above the k-th score, then the LOWEST ids among
     the rows that tie with it).  amp = 128: few ties, the bf16 screen is exact on these integers and does all the work;
     amp = 2 with queries that have 3 non-zero components (|score| <= 12): ~12,000 rows share the best score of a query,
     every query tile overflows and is recomputed by the exact scan from the row-major rows (this index keeps no panel copy)."""

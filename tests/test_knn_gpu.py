@@ -60,7 +60,8 @@ def test_integer_lattice(metric):
 
 @pytest.mark.parametrize("metric", [0, 1])
 def test_tie_heavy(metric):
-    # many exactly equal scores: membership at the k-th boundary must go to the lower id
+    # many exactly equal scores: membership at the k-th boundary must go to the lower id (this library's default tie policy,
+    # id_asc; the other order and what is known about FAISS's own: tests/test_tie_order_bigk_gpu.py, oracle/knn_oracle.c)
     X, Q = _mk(3000, 16, 21, seed=11, kind="ties")
     _check(X, Q, 100, metric)
 

@@ -6,8 +6,10 @@ searched through the reference's own ``meerqat.ir.search.KnowledgeBase`` (``sear
 ``search_batch_if_not_None``, meerqat/ir/search.py:135-171), whose FAISS dependency is served by the
 stand-in of tools/ref_import.py (the CPU oracle).  Integer-lattice and tie-heavy cases are
 additionally asserted against an independent float64 computation at generation time: on such data
-every summation order gives the same fp32 scores, so these fixtures are also what FAISS itself
-would return (lower id first on ties, see oracle/knn_oracle.c).
+every summation order gives the same fp32 SCORES, so the score arrays are also what any correct
+IndexFlat returns; which of several exactly tied rows is listed (and in which order) is THIS
+LIBRARY'S documented policy -- lower id first, "id_asc" -- not a statement about FAISS, whose
+tie behaviour depends on its version and on k (oracle/knn_oracle.c header).
 
 Encoder fixtures (``dpr_*.npz``, ``clip_*.npz``): Hugging Face ``DPRContextEncoder`` /
 ``CLIPModel.get_image_features`` (the code the reference calls, meerqat/ir/embedding.py:226,

@@ -422,12 +422,14 @@ class ImageEmbedPipeline:
         self.side = torch.cuda.Stream(device=self.device)
         self.out_ring = _PinnedRing(3)
         self.stats = {"batches": 0, "decode_s": 0.0, "prepare_s": 0.0, "launch_s": 0.0, "wait_result_s": 0.0}
-        # Without the caller's process pool (`processes` of the reference's config) the files are decoded by a pool of
-        # THREADS: Pillow releases the GIL inside its decoders and converters, and an array crosses no pipe.
+        # Without the caller's process pool (`processes` of the reference's config) the files are decoded by a small pool of
+        # THREADS: Pillow releases the GIL inside its codecs (JPEG: 0.71 -> 0.40 ms per image on the GPU box) but not in the
+        # per-file Python around them, so more than a handful of threads only fight for the GIL (measured: 32 threads decode
+        # BMP files SLOWER than one).  MQ_IMAGE_DECODE_THREADS overrides.
         self.threads = None
         if pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            self.threads = ThreadPoolExecutor(max(1, min(32, (os.cpu_count() or 2) - 1)))
+            self.threads = ThreadPoolExecutor(max(1, int(os.environ.get("MQ_IMAGE_DECODE_THREADS", min(8, os.cpu_count() or 1)))))
         self.look = Lookahead(len(self.bounds), self._prepare, self._launch, depth=depth)
 
     def _prepare(self, j):
