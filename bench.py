@@ -167,11 +167,29 @@ def cpu_baseline(idx, Q, seconds):
     legs = {"fmaf_chain_oracle": leg(lambda X, Qq: ok.knn(X, Qq, TOPK, metric=0), 4096, seconds * 0.5,
                                      f"oracle/knn_oracle.c (k-ordered fmaf chain = the bit-exact checker), OpenMP x{threads}")}
     try:
-        torch.set_num_threads(cpus["physical_cores"])  # one sgemm thread per physical core (SMT siblings only add contention)
-        tt = torch.get_num_threads()
-        legs["faiss_organisation"] = leg(lambda X, Qq: ok.knn_blas(X, Qq, TOPK, metric=0), 1 << 16, seconds * 0.7,
-                                         f"oracle.knn.knn_blas: 4096 x 1024 sgemm blocks on the host BLAS (torch.mm, {tt} threads) + FAISS's "
-                                         f"strict-'>' heap per query in C / OpenMP x{threads}")
+        # which host BLAS, how many threads, which database block: a 1-second calibration on the box (MKL takes a slow code
+        # path on AMD hosts; numpy's OpenBLAS is capped at 64 threads; FAISS's own 1024-row blocks starve 128 threads)
+        Xc = idx.reconstruct_n(0, min(idx.ntotal, 1 << 15))
+        trials = []
+        for backend, nthreads, block in (("torch", cpus["physical_cores"], 1024), ("torch", cpus["physical_cores"], 16384),
+                                         ("torch", max(1, cpus["physical_cores"] // 2), 16384), ("numpy", None, 1024), ("numpy", None, 16384)):
+            try:
+                if nthreads:
+                    torch.set_num_threads(nthreads)
+                ok.knn_blas(Xc[:2048], Qh, TOPK, metric=0, block=block, backend=backend)
+                t0 = time.perf_counter()
+                ok.knn_blas(Xc, Qh, TOPK, metric=0, block=block, backend=backend)
+                trials.append((time.perf_counter() - t0, backend, nthreads, block))
+            except Exception:
+                pass
+        _, backend, nthreads, block = min(trials)
+        if nthreads:
+            torch.set_num_threads(nthreads)
+        legs["faiss_organisation"] = leg(lambda X, Qq: ok.knn_blas(X, Qq, TOPK, metric=0, block=block, backend=backend), 1 << 16, seconds * 0.7,
+                                         f"oracle.knn.knn_blas: 4096 x {block} sgemm blocks on the host BLAS ({backend}"
+                                         f"{', %d threads' % nthreads if nthreads else ' / OpenBLAS'}; the fastest of "
+                                         f"{[(b, n, bl, round(2.0 * nq * Xc.shape[0] * DIM / t / 1e9)) for t, b, n, bl in trials]} (backend, threads, block, "
+                                         f"GFLOP/s)) + FAISS's strict-'>' heap per query in C / OpenMP x{threads}")
     except Exception as e:
         legs["faiss_organisation"] = {"value": 0.0, "what": f"failed: {e!r}"}
     best = max(legs, key=lambda n: legs[n]["value"])

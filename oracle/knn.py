@@ -124,17 +124,20 @@ def topk_merge(Ds, Is, metric=0, tie_order="id_asc"):
     return D, I
 
 
-def knn_blas(X, Q, k, metric=0, block=1024, threads=None, query_block=4096):
+def knn_blas(X, Q, k, metric=0, block=1024, threads=None, query_block=4096, backend="torch"):
     """The same search ORGANISED the way FAISS's IndexFlat runs it for 20 or more queries
     (faiss/utils/distances.cpp, exhaustive_inner_product_blas / exhaustive_L2sqr_blas): blocks of ``query_block`` (4096 =
     distance_compute_blas_query_bs) queries x ``block`` (1024 = distance_compute_blas_database_bs) database rows go through
     the host BLAS's sgemm (torch.mm = MKL here, all cores, into one reused buffer), then FAISS's result-handler rule in
     C / OpenMP over the queries (knn_oracle.c::oracle_heap_add_block): a score enters a query's heap only if it beats the
     heap's current k-th best strictly.  Scores carry the BLAS library's summation order, not the fmaf chain of knn(): this
-    is bench.py's fast CPU leg, compared with knn() only up to float64 near-ties (tests/test_oracle_cpu.py)."""
+    is bench.py's fast CPU leg, compared with knn() only up to float64 near-ties (tests/test_oracle_cpu.py).
+    ``backend``: which host BLAS runs the sgemm -- "torch" (MKL in this image) or "numpy" (its bundled OpenBLAS; MKL takes a
+    slow code path on AMD hosts, so bench.py calibrates both and keeps the faster)."""
     import torch
     if threads:
         torch.set_num_threads(int(threads))
+    use_numpy = backend == "numpy"
     X, Q = _f32(X), _f32(Q)
     Xt, Qt = torch.from_numpy(X), torch.from_numpy(Q)
     nq, N = Qt.shape[0], Xt.shape[0]
@@ -153,7 +156,10 @@ def knn_blas(X, Q, k, metric=0, block=1024, threads=None, query_block=4096):
             xb = Xt[s:s + block]
             nb = xb.shape[0]
             Sb = S[:n, :nb] if nb == block else torch.empty((n, nb), dtype=torch.float32)
-            torch.mm(qb, xb.T, out=Sb)
+            if use_numpy:
+                np.matmul(qb.numpy(), xb.numpy().T, out=Sb.numpy())
+            else:
+                torch.mm(qb, xb.T, out=Sb)
             if metric == 1:  # FAISS: ||q||^2 + ||x||^2 - 2 <q, x>, clamped at 0; the heap keeps the goodness -distance
                 Sb.mul_(-2.0).add_(qn[:, None]).add_((xb * xb).sum(1)[None, :]).clamp_min_(0.0).neg_()
             L.oracle_heap_add_block(Sb.data_ptr(), n, Sb.stride(0), s, nb, k, hv.ctypes.data, hi.ctypes.data)

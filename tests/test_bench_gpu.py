@@ -32,8 +32,8 @@ def test_single_gpu_line_with_both_exact_paths_and_cpu_baseline():
     assert rec["n_gpus"] == 1 and rec["config"]["queries_per_step"] == 4096
     assert rec["other_exact_path"]["results_identical_to_headline_path"] is True
     cpu = rec["cpu_baseline"]
-    assert {"value", "unit", "cores", "kind", "sample"} <= cpu.keys() and cpu["kind"] == "port" and cpu["value"] > 0
-    assert set(cpu["legs"]) == {"fmaf_chain_oracle", "blas_sgemm_topk"}
+    assert {"value", "unit", "cores", "kind", "sample"} <= cpu.keys() and cpu["kind"].startswith("port") and cpu["value"] > 0
+    assert set(cpu["legs"]) == {"fmaf_chain_oracle", "faiss_organisation"} and cpu["host"]["physical_cores"] >= 1
     ceil = rec["roofline"]["sustained_mfma_ceiling"]          # the register-only MFMA loop timed on the same box
     assert 1000 < ceil["random_operands_tflops"] <= ceil["zero_operands_tflops"] * 1.02 < 2700
     assert 0 < ceil["frac_of_random_operand_ceiling"] < 1
