@@ -172,7 +172,8 @@ def cpu_baseline(idx, Q, seconds):
         Xc = idx.reconstruct_n(0, min(idx.ntotal, 1 << 15))
         trials = []
         for backend, nthreads, block in (("torch", cpus["physical_cores"], 1024), ("torch", cpus["physical_cores"], 16384),
-                                         ("torch", max(1, cpus["physical_cores"] // 2), 16384), ("numpy", None, 1024), ("numpy", None, 16384)):
+                                         ("torch", max(1, cpus["physical_cores"] // 2), 16384), ("numpy", None, 1024), ("numpy", None, 16384),
+                                         ("c", None, 1024), ("c", None, 16384)):
             try:
                 if nthreads:
                     torch.set_num_threads(nthreads)
@@ -187,7 +188,7 @@ def cpu_baseline(idx, Q, seconds):
             torch.set_num_threads(nthreads)
         legs["faiss_organisation"] = leg(lambda X, Qq: ok.knn_blas(X, Qq, TOPK, metric=0, block=block, backend=backend), 1 << 16, seconds * 0.7,
                                          f"oracle.knn.knn_blas: 4096 x {block} sgemm blocks on the host BLAS ({backend}"
-                                         f"{', %d threads' % nthreads if nthreads else ' / OpenBLAS'}; the fastest of "
+                                         f"{', %d threads' % nthreads if nthreads else {'numpy': ' / OpenBLAS', 'c': ': oracle_sgemm_nt, OpenMP x%d' % threads}.get(backend, '')}; the fastest of "
                                          f"{[(b, n, bl, round(2.0 * nq * Xc.shape[0] * DIM / t / 1e9)) for t, b, n, bl in trials]} (backend, threads, block, "
                                          f"GFLOP/s)) + FAISS's strict-'>' heap per query in C / OpenMP x{threads}")
     except Exception as e:

@@ -47,6 +47,11 @@ def lib():
         L.oracle_heap_add_block.restype = None
         L.oracle_heap_finish.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp]
         L.oracle_heap_finish.restype = None
+        L.oracle_sgemm_mr.restype = ctypes.c_int
+        L.oracle_pack_queries.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp]
+        L.oracle_pack_queries.restype = None
+        L.oracle_sgemm_nt.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, fp, ctypes.c_int64]
+        L.oracle_sgemm_nt.restype = None
         L.oracle_l2norm_rows_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int]
         L.oracle_l2norm_rows_f32.restype = None
         L.oracle_sqnorm_rows_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int, fp]
@@ -132,12 +137,14 @@ def knn_blas(X, Q, k, metric=0, block=1024, threads=None, query_block=4096, back
     C / OpenMP over the queries (knn_oracle.c::oracle_heap_add_block): a score enters a query's heap only if it beats the
     heap's current k-th best strictly.  Scores carry the BLAS library's summation order, not the fmaf chain of knn(): this
     is bench.py's fast CPU leg, compared with knn() only up to float64 near-ties (tests/test_oracle_cpu.py).
-    ``backend``: which host BLAS runs the sgemm -- "torch" (MKL in this image) or "numpy" (its bundled OpenBLAS; MKL takes a
-    slow code path on AMD hosts, so bench.py calibrates both and keeps the faster)."""
+    ``backend``: what runs the sgemm -- "torch" (MKL in this image), "numpy" (its bundled OpenBLAS) or "c" (the register-blocked
+    AVX-512 / AVX2 kernel of knn_oracle.c, oracle_sgemm_nt: MKL takes a slow code path on AMD hosts and OpenBLAS stops at 64
+    threads, so bench.py calibrates the three and keeps the fastest)."""
     import torch
     if threads:
         torch.set_num_threads(int(threads))
     use_numpy = backend == "numpy"
+    use_c = backend == "c"
     X, Q = _f32(X), _f32(Q)
     Xt, Qt = torch.from_numpy(X), torch.from_numpy(Q)
     nq, N = Qt.shape[0], Xt.shape[0]
@@ -152,11 +159,19 @@ def knn_blas(X, Q, k, metric=0, block=1024, threads=None, query_block=4096, back
         hi = np.empty((n, k), dtype=np.int64)
         L.oracle_heap_init(n, k, hv.ctypes.data, hi.ctypes.data)
         qn = (qb * qb).sum(1) if metric == 1 else None
+        if use_c:
+            MR = int(L.oracle_sgemm_mr())
+            Qp = np.empty(((n + MR - 1) // MR) * Qt.shape[1] * MR, dtype=np.float32)
+            qc = np.ascontiguousarray(qb.numpy())
+            L.oracle_pack_queries(qc.ctypes.data, n, Qt.shape[1], Qp.ctypes.data)
         for s in range(0, N, block):
             xb = Xt[s:s + block]
             nb = xb.shape[0]
             Sb = S[:n, :nb] if nb == block else torch.empty((n, nb), dtype=torch.float32)
-            if use_numpy:
+            if use_c:
+                xc = np.ascontiguousarray(xb.numpy())
+                L.oracle_sgemm_nt(Qp.ctypes.data, n, Qt.shape[1], xc.ctypes.data, nb, Sb.data_ptr(), Sb.stride(0))
+            elif use_numpy:
                 np.matmul(qb.numpy(), xb.numpy().T, out=Sb.numpy())
             else:
                 torch.mm(qb, xb.T, out=Sb)

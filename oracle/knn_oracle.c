@@ -369,6 +369,116 @@ void oracle_heap_finish(int nq, int k, int metric, const float *hv, const int64_
     }
 }
 
+/*
+ * A host sgemm for the FAISS-organised leg: S[nq][nb] = Q[nq][d] . X[nb][d]^T (+ FAISS's L2 epilogue in the caller).
+ * The two BLAS libraries this image ships reach 0.5-0.9 TFLOP/s on the GPU box's 128 EPYC cores (MKL takes its non-Intel
+ * code path, numpy's OpenBLAS stops at 64 threads), which would understate what FAISS + a tuned BLAS does there; this is a
+ * plain register-blocked kernel -- 14 x 32 accumulators in AVX-512 registers (6 x 16 in AVX2), operands packed per panel,
+ * one OpenMP thread per 32-column panel of X -- good for a few TFLOP/s.  Same role as the BLAS call: scores carry ITS
+ * summation order (k ascending per accumulator, fused multiply-add), not the fmaf chain's bits... they are in fact the same
+ * chain per output, but nothing relies on it.
+ *   Qp: queries packed by oracle_pack_queries ([ceil(nq / MR)][d][MR], zero padded); S row stride ld.
+ */
+#include <immintrin.h>
+
+static int have_avx512(void) { return __builtin_cpu_supports("avx512f"); }
+int oracle_sgemm_mr(void) { return have_avx512() ? 14 : 6; }
+
+void oracle_pack_queries(const float *Q, int nq, int d, float *Qp) {
+    const int MR = oracle_sgemm_mr();
+    const int np = (nq + MR - 1) / MR;
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < np; ++p) {
+        float *dst = Qp + (size_t)p * d * MR;
+        for (int k = 0; k < d; ++k)
+            for (int i = 0; i < MR; ++i) {
+                const int q = p * MR + i;
+                dst[(size_t)k * MR + i] = q < nq ? Q[(size_t)q * d + k] : 0.0f;
+            }
+    }
+}
+
+__attribute__((target("avx512f"))) static void panel_avx512(const float *Qp, int nq, int d, const float *Bp, float *S, int64_t ld,
+                                                            int j0, int ncols) {
+    const int MR = 14;
+    const int np = (nq + MR - 1) / MR;
+    for (int p = 0; p < np; ++p) {
+        const float *a = Qp + (size_t)p * d * MR;
+        __m512 c0[14], c1[14];
+        for (int i = 0; i < 14; ++i) { c0[i] = _mm512_setzero_ps(); c1[i] = _mm512_setzero_ps(); }
+        for (int k = 0; k < d; ++k) {
+            const __m512 b0 = _mm512_loadu_ps(Bp + (size_t)k * 32), b1 = _mm512_loadu_ps(Bp + (size_t)k * 32 + 16);
+            const float *ak = a + (size_t)k * MR;
+#pragma GCC unroll 14
+            for (int i = 0; i < 14; ++i) {
+                const __m512 av = _mm512_set1_ps(ak[i]);
+                c0[i] = _mm512_fmadd_ps(av, b0, c0[i]);
+                c1[i] = _mm512_fmadd_ps(av, b1, c1[i]);
+            }
+        }
+        for (int i = 0; i < 14; ++i) {
+            const int q = p * MR + i;
+            if (q >= nq) break;
+            float tmp[32];
+            _mm512_storeu_ps(tmp, c0[i]);
+            _mm512_storeu_ps(tmp + 16, c1[i]);
+            memcpy(S + (size_t)q * ld + j0, tmp, sizeof(float) * (size_t)ncols);
+        }
+    }
+}
+
+__attribute__((target("avx2,fma"))) static void panel_avx2(const float *Qp, int nq, int d, const float *Bp, float *S, int64_t ld,
+                                                           int j0, int ncols) {
+    const int MR = 6;
+    const int np = (nq + MR - 1) / MR;
+    for (int p = 0; p < np; ++p) {
+        const float *a = Qp + (size_t)p * d * MR;
+        for (int h = 0; h < 2; ++h) { /* the 32-column panel as two 16-column halves */
+            __m256 c0[6], c1[6];
+            for (int i = 0; i < 6; ++i) { c0[i] = _mm256_setzero_ps(); c1[i] = _mm256_setzero_ps(); }
+            for (int k = 0; k < d; ++k) {
+                const __m256 b0 = _mm256_loadu_ps(Bp + (size_t)k * 32 + 16 * h), b1 = _mm256_loadu_ps(Bp + (size_t)k * 32 + 16 * h + 8);
+                const float *ak = a + (size_t)k * MR;
+#pragma GCC unroll 6
+                for (int i = 0; i < 6; ++i) {
+                    const __m256 av = _mm256_set1_ps(ak[i]);
+                    c0[i] = _mm256_fmadd_ps(av, b0, c0[i]);
+                    c1[i] = _mm256_fmadd_ps(av, b1, c1[i]);
+                }
+            }
+            for (int i = 0; i < 6; ++i) {
+                const int q = p * MR + i;
+                if (q >= nq) break;
+                float tmp[16];
+                _mm256_storeu_ps(tmp, c0[i]);
+                _mm256_storeu_ps(tmp + 8, c1[i]);
+                const int n = ncols - 16 * h;
+                if (n > 0) memcpy(S + (size_t)q * ld + j0 + 16 * h, tmp, sizeof(float) * (size_t)(n < 16 ? n : 16));
+            }
+        }
+    }
+}
+
+void oracle_sgemm_nt(const float *Qp, int nq, int d, const float *X, int nb, float *S, int64_t ld) {
+    const int npan = (nb + 31) / 32;
+    const int wide = have_avx512();
+#pragma omp parallel
+    {
+        float *Bp = (float *)aligned_alloc(64, sizeof(float) * (size_t)d * 32);
+#pragma omp for schedule(dynamic, 1)
+        for (int pn = 0; pn < npan; ++pn) {
+            const int j0 = pn * 32, ncols = nb - j0 < 32 ? nb - j0 : 32;
+            for (int k = 0; k < d; ++k)
+                for (int j = 0; j < 32; ++j) Bp[(size_t)k * 32 + j] = j < ncols ? X[(size_t)(j0 + j) * d + k] : 0.0f;
+            if (wide)
+                panel_avx512(Qp, nq, d, Bp, S, ld, j0, ncols);
+            else
+                panel_avx2(Qp, nq, d, Bp, S, ld, j0, ncols);
+        }
+        free(Bp);
+    }
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

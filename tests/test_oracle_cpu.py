@@ -229,8 +229,9 @@ def test_blas_leg_equals_the_chain_oracle_on_lattice_data(metric):
     Q = rng.integers(-3, 4, (70, 32)).astype(np.float32)
     for k, block, qb in ((100, 1024, 4096), (10, 700, 32), (1200, 1024, 64)):
         D, I = ok.knn(X, Q, k, metric=metric, l2_form="expanded")
-        Db, Ib = ok.knn_blas(X, Q, k, metric=metric, block=block, query_block=qb)
-        assert np.array_equal(D, Db) and np.array_equal(I, Ib), (k, block, qb)
+        for backend in ("torch", "numpy", "c"):   # MKL, OpenBLAS, the register-blocked kernel of knn_oracle.c
+            Db, Ib = ok.knn_blas(X, Q, k, metric=metric, block=block, query_block=qb, backend=backend)
+            assert np.array_equal(D, Db) and np.array_equal(I, Ib), (k, block, qb, backend)
     Db, Ib = ok.knn_blas(X[:40], Q, 64, metric=metric)  # k > ntotal: neutral values and -1
     D, I = ok.knn(X[:40], Q, 64, metric=metric, l2_form="expanded")
     assert np.array_equal(D, Db) and np.array_equal(I, Ib)
