@@ -45,7 +45,7 @@ json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 
 
 def traffic(kernel):
-    c = pmc.get(kernel, {})
+    c = pmc.get(kernel) or next((v for k, v in pmc.items() if k.startswith(kernel)), {})
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         return None
     fetch_kb, write_kb = c["FETCH_SIZE"]["max_per_launch"], c["WRITE_SIZE"]["max_per_launch"]
@@ -57,7 +57,7 @@ def traffic(kernel):
 out = {"_profile": f"profiles/{tag}_pmc.json", "_note": "L2<->fabric bytes per full-size launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH "
                 "doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streams; Infinity-Cache hits are included, so this is "
                 f"an upper bound of HBM bytes.  Raw counters: profiles/{tag}_pmc.json."}
-for key, kernel in (("screened_1500000x768_nq4096_k100", "screen_scan_kernel"), ("exact_f32_1500000x768_nq4096_k100", "knn_scan_kernel<0>")):
+for key, kernel in (("screened_1500000x768_nq4096_k100", "screen_scan_kernel"), ("exact_f32_1500000x768_nq4096_k100", "knn_scan_kernel<0, false, false>")):
     t = traffic(kernel)
     if t:
         out[key] = t
@@ -68,4 +68,4 @@ for a, b in (("bench.json", f"{tag}_bench_screened.json"), ("bench_exact.json", 
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, b))
 print(json.dumps({k: {n: round(c["max_per_launch"], 1) for n, c in v.items()} for k, v in pmc.items()
-                  if k in ("screen_scan_kernel", "knn_scan_kernel<0>", "rescore_kernel", "cand_select_kernel")}, indent=1))
+                  if k.startswith(("screen_scan_kernel", "knn_scan_kernel<0", "rescore_kernel", "cand_select_kernel"))}, indent=1))
