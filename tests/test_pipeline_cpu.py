@@ -147,3 +147,55 @@ def test_pipelines_decline_what_they_cannot_prefetch(tmp_path):
     assert P.image_pipeline_or_none(ds, {}, model=lin, transform=object(), image_key="passage") is None
     assert not P._plain_dataset(ds.select([1, 0]), {}) and not P._plain_dataset(ds, {"num_proc": 2}) and P._plain_dataset(ds, {"batch_size": 7})
     assert P._arrow_strings(ds, "n") is None and P._arrow_strings(ds, "passage") is not None
+
+
+def test_decode_pool_writes_rgb_bytes_into_the_shared_slots(tmp_path):
+    """The image pipeline's decode workers (forked processes, two phases): sizes with load_image's error handling, then the
+    RGB bytes of every readable file at the byte offsets the parent planned -- equal to np.asarray(Image.open().convert('RGB')),
+    for RGB / greyscale / palette / RGBA files, a missing file, a file that opens but cannot be decoded, and across both slots."""
+    from PIL import Image
+    from viquae_amd.image.decode_pool import DecodePool
+    rng = np.random.default_rng(0)
+    paths, want = [], []
+    for i, (mode, ext) in enumerate([("RGB", "png"), ("L", "png"), ("RGB", "jpg"), ("P", "png"), ("RGBA", "png"), ("RGB", "bmp")] * 3):
+        h, w = int(rng.integers(5, 60)), int(rng.integers(5, 60))
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        im = Image.fromarray(a).convert(mode) if mode != "RGBA" else Image.fromarray(np.dstack([a, a[..., :1]]))
+        p = str(tmp_path / f"{i}.{ext}")
+        im.save(p)
+        paths.append(p)
+        want.append(np.asarray(Image.open(p).convert("RGB")))
+    paths.insert(4, str(tmp_path / "missing.png"))
+    want.insert(4, None)
+    trunc = tmp_path / "trunc.jpg"
+    big = tmp_path / "big.jpg"
+    Image.fromarray(rng.integers(0, 256, (200, 200, 3), dtype=np.uint8)).save(str(big), quality=95)
+    data = open(str(big), "rb").read()
+    trunc.write_bytes(data[: len(data) // 2])                    # the header parses, the data does not
+    paths.insert(9, str(trunc))
+    want.insert(9, "fails")
+    pool = DecodePool(3, 1 << 20, n_slots=2)
+    try:
+        for rep in range(3):                                      # slots are reused round-robin
+            with pytest.warns(UserWarning, match="missing.png"):
+                sizes = pool.sizes(paths)
+            assert [s is None for s in sizes] == [w is None for w in want]
+            kept = [i for i, s in enumerate(sizes) if s is not None]
+            offs, o = {}, 64 * rep
+            for i in kept:
+                offs[i] = o
+                o += -(-(sizes[i][0] * sizes[i][1] * 3) // 16) * 16
+            slot = pool.take_slot()
+            assert slot == rep % 2
+            with pytest.warns(UserWarning, match="trunc.jpg"):
+                failed = pool.decode(slot, offs)
+            assert failed == {9}
+            buf = pool.tensors[slot].numpy()
+            for i in kept:
+                if i == 9:
+                    continue
+                h, w = sizes[i]
+                assert want[i].shape == (h, w, 3)
+                assert np.array_equal(buf[offs[i]:offs[i] + h * w * 3].reshape(h, w, 3), want[i]), i
+    finally:
+        pool.close()

@@ -109,18 +109,33 @@ def test_pipelined_image_embed_is_identical_to_the_serial_embed(tmp_path, monkey
         names.append(f"im{i}.png")
     names[7] = "missing.png"                      # unreadable image: None in the output, the rest of its batch unaffected
     names[20] = names[21] = "gone.png"
+    big = tmp_path / "big.jpg"                    # a file whose header parses but whose data is cut: fails at DECODE time
+    Image.fromarray(rng.integers(0, 256, (300, 300, 3), dtype=np.uint8)).save(str(big), quality=95)
+    data = open(str(big), "rb").read()
+    (tmp_path / "cut.jpg").write_bytes(data[: len(data) // 2])
+    names[30] = "cut.jpg"
     datasets.Dataset.from_dict({"image": names, "id": list(range(45))}).save_to_disk(str(tmp_path / "ds"))
     kw = dict(map_kwargs={"batch_size": 8}, save_as="clip", call="get_image_features",
               model_kwargs={"type": "transformers", "class_name": "CLIPModel", "pretrained_model_name_or_path": str(mdir)},
               transform_kwargs={"class_name": "CLIPFeatureExtractor", "pretrained_model_name_or_path": str(mdir)})
     outs = []
-    for flag in ("0", "1"):
+    # serial embed | pipeline with forked decode processes writing into the shared pinned slots (the default; `processes`
+    # sets their number) | pipeline with decode threads
+    for flag, procs, processes in (("0", None, None), ("1", None, 3), ("1", "0", None)):
         monkeypatch.setenv("MQ_EMBED_PIPELINE", flag)
+        if procs is None:
+            monkeypatch.delenv("MQ_IMAGE_DECODE_PROCS", raising=False)
+        else:
+            monkeypatch.setenv("MQ_IMAGE_DECODE_PROCS", procs)
         with pytest.warns(UserWarning):
-            ds = IE.dataset_embed(str(tmp_path / "ds"), output_path=str(tmp_path / f"out{flag}"), **kw)
+            ds = IE.dataset_embed(str(tmp_path / "ds"), output_path=str(tmp_path / f"out{len(outs)}"), processes=processes, **kw)
         outs.append(ds["clip"])
-        assert (IE.dataset_embed.last_pipeline_stats is not None) == (flag == "1")
-    assert [v is None for v in outs[0]] == [v is None for v in outs[1]] and outs[0][7] is None
-    a = np.asarray([v for v in outs[0] if v is not None], dtype=np.float32)
-    b = np.asarray([v for v in outs[1] if v is not None], dtype=np.float32)
-    assert a.shape == (42, cfg["projection_dim"]) and np.array_equal(a, b)
+        st = IE.dataset_embed.last_pipeline_stats
+        assert (st is not None) == (flag == "1")
+        if st is not None:
+            assert st["decode"].startswith("3 processes" if processes else "8 threads" if procs == "0" else "x") or procs is None
+    for o in outs[1:]:
+        assert [v is None for v in outs[0]] == [v is None for v in o] and o[7] is None and o[30] is None
+        a = np.asarray([v for v in outs[0] if v is not None], dtype=np.float32)
+        b = np.asarray([v for v in o if v is not None], dtype=np.float32)
+        assert a.shape == (41, cfg["projection_dim"]) and np.array_equal(a, b)

@@ -1,0 +1,188 @@
+"""Decode workers of the image-embedding pipeline: PROCESSES that turn image files into RGB bytes inside a shared, page-locked
+staging buffer (viquae_amd/pipeline.py; the reference's own answer to slow decoding is a process pool too, `processes` in
+meerqat/image/embedding.py:169-183 -- but its workers pickle every decoded image back through a pipe).
+
+Pillow's per-file Python (open, plugin probing, convert, export) holds the GIL, so decode THREADS stop scaling at ~2x; here W
+forked workers each own a contiguous chunk of a batch's files and work in two phases:
+
+  sizes    open every file (lazy: header only), report (height, width) or the error; the opened images stay with the worker
+  decode   given each image's byte offset in staging slot s (from mq_image_plan, computed by the parent between the phases),
+           decode + convert to RGB and write the H x W x 3 bytes straight into the slot -- nothing crosses a pipe but offsets
+
+The slots are anonymous shared mappings created BEFORE the fork (so every worker has them) and registered with the HIP
+runtime as page-locked, which makes the host -> device copy of a packed batch a plain asynchronous DMA.  Workers never touch the
+GPU.  A worker reproduces `meerqat.data.loading.load_image` (:108-119): unreadable or empty images are reported and become
+`None` in the output, with the same warning text issued by the parent."""
+import mmap
+import multiprocessing as mp
+import os
+import warnings
+
+import numpy as np
+
+_SLOTS = []   # the staging mappings; inherited by the forked workers
+
+
+def _worker(conn, slots):
+    from PIL import Image
+    opened = {}
+    while True:
+        try:
+            msg = conn.recv()
+        except EOFError:
+            return
+        kind = msg[0]
+        if kind == "quit":
+            return
+        if kind == "sizes":
+            _, base, paths = msg
+            opened.clear()
+            out = []
+            for n, path in enumerate(paths):
+                try:
+                    im = Image.open(path)
+                    w, h = im.size
+                    if w < 1 or h < 1:
+                        out.append((None, f"Empty image '{path}'"))
+                        continue
+                    opened[base + n] = (im, path)
+                    out.append(((h, w), None))
+                except Exception as e:  # noqa: BLE001 - load_image catches everything too
+                    out.append((None, f"Caught exception '{e}' with image '{path}'"))
+            conn.send(out)
+        elif kind == "decode":
+            _, slot, items = msg   # items: (index in the batch, byte offset in the slot)
+            buf = np.frombuffer(slots[slot], dtype=np.uint8)
+            failed = []
+            for idx, off in items:
+                im, path = opened.pop(idx)
+                try:
+                    a = np.asarray(im.convert("RGB"))
+                    n = a.shape[0] * a.shape[1] * 3
+                    buf[off:off + n] = a.reshape(-1)
+                except Exception as e:  # noqa: BLE001
+                    failed.append((idx, f"Caught exception '{e}' with image '{path}'"))
+            opened.clear()
+            conn.send(failed)
+
+
+class DecodePool:
+    def __init__(self, n_procs, slot_bytes, n_slots=2):
+        import torch
+        self.slot_bytes = int(slot_bytes)
+        self.maps = [mmap.mmap(-1, self.slot_bytes) for _ in range(n_slots)]
+        self.tensors = [torch.frombuffer(m, dtype=torch.uint8) for m in self.maps]
+        ctx = mp.get_context("fork")
+        self.conns, self.procs = [], []
+        for _ in range(max(1, int(n_procs))):
+            parent, child = ctx.Pipe()
+            p = ctx.Process(target=_worker, args=(child, self.maps), daemon=True)
+            p.start()
+            child.close()
+            self.conns.append(parent)
+            self.procs.append(p)
+        # page-lock the slots AFTER the fork (MQ_IMAGE_PIN=0: leave them pageable): the children only ever see plain shared
+        # memory, and the fork never meets a registered range of THIS mapping
+        self.pinned = []
+        for t in self.tensors:
+            ok = False
+            if torch.cuda.is_available() and os.environ.get("MQ_IMAGE_PIN", "1") != "0":
+                try:
+                    ok = int(torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel(), 0)) == 0
+                except Exception:  # noqa: BLE001 - unpinned staging still works (a blocking copy in the prefetch thread)
+                    ok = False
+            self.pinned.append(ok)
+        self.next_slot = 0
+        self._chunks = None
+
+    def _recv(self, conn, what):
+        if not conn.poll(600):
+            raise RuntimeError(f"image decode worker did not answer ({what})")
+        return conn.recv()
+
+    def sizes(self, paths):
+        """-> [(h, w) or None] per file; warnings for the unreadable ones (load_image's wording)."""
+        n, w = len(paths), len(self.conns)
+        per = -(-n // w)
+        self._chunks = [(c, c * per, min(n, (c + 1) * per)) for c in range(w) if c * per < n]
+        for c, lo, hi in self._chunks:
+            self.conns[c].send(("sizes", lo, paths[lo:hi]))
+        out = []
+        for c, lo, hi in self._chunks:
+            for size, err in self._recv(self.conns[c], "sizes"):
+                if err:
+                    warnings.warn(err)
+                out.append(size)
+        return out
+
+    def take_slot(self):
+        s = self.next_slot
+        self.next_slot = (s + 1) % len(self.maps)
+        return s
+
+    def decode(self, slot, offsets):
+        """offsets: {index in the batch: byte offset in `slot`} for the images to decode -> set of indices that failed."""
+        for c, lo, hi in self._chunks:
+            self.conns[c].send(("decode", slot, [(i, int(offsets[i])) for i in range(lo, hi) if i in offsets]))
+        failed = set()
+        for c, lo, hi in self._chunks:
+            for idx, err in self._recv(self.conns[c], "decode"):
+                warnings.warn(err)
+                failed.add(idx)
+        return failed
+
+    def close(self):
+        import torch
+        for conn in self.conns:
+            try:
+                conn.send(("quit",))
+                conn.close()
+            except Exception:  # noqa: BLE001
+                pass
+        for p in self.procs:
+            p.join(timeout=2)
+            if p.is_alive():
+                p.terminate()
+        for t, ok in zip(self.tensors, self.pinned):
+            if ok:
+                try:
+                    torch.cuda.cudart().cudaHostUnregister(t.data_ptr())
+                except Exception:  # noqa: BLE001
+                    pass
+        self.tensors = []
+        for m in self.maps:
+            try:
+                m.close()
+            except Exception:  # noqa: BLE001 - exported buffers may still be referenced
+                pass
+
+
+def slot_bytes(batch_size):
+    """Bytes of one staging slot for batches of ``batch_size`` images: MQ_IMAGE_SLOT_KB (default 768 KB = a 512 x 512 RGB image)
+    per image; a batch that needs more takes the thread path."""
+    return max(64 << 20, int(batch_size) * int(os.environ.get("MQ_IMAGE_SLOT_KB", "768")) * 1024)
+
+
+def early_pool(processes, batch_size):
+    """The decode workers, forked BEFORE the caller loads the model or allocates page-locked memory (see
+    ImageEmbedPipeline: the first device operation after a fork pays for what the process has pinned) -- or None when the
+    pipeline / the processes are switched off or there is no GPU."""
+    import torch
+    if os.environ.get("MQ_EMBED_PIPELINE", "1") == "0" or not hasattr(os, "fork") or not torch.cuda.is_available():
+        return None
+    procs = int(processes) if processes else default_procs()
+    if procs <= 0:
+        return None
+    try:
+        return DecodePool(procs, slot_bytes(batch_size), n_slots=2)
+    except Exception as e:  # noqa: BLE001
+        warnings.warn(f"image decode processes unavailable ({e!r}): decoding in threads")
+        return None
+
+
+def default_procs():
+    """MQ_IMAGE_DECODE_PROCS, else a quarter of the hardware threads (at most 32); 0 = decode in threads."""
+    env = os.environ.get("MQ_IMAGE_DECODE_PROCS")
+    if env is not None:
+        return max(0, int(env))
+    return max(0, min(32, (os.cpu_count() or 1) // 4))

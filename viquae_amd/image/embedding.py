@@ -63,15 +63,21 @@ def dataset_embed(dataset_path, map_kwargs={}, model_kwargs={}, transform_kwargs
     elif keep_columns is not None:
         keep_columns = set(keep_columns)
         dataset = dataset.remove_columns([c for c in dataset.column_names if c not in keep_columns])
+    # the decode workers of the pipeline are forked FIRST, while this process owns no page-locked memory (decode_pool.py)
+    from .decode_pool import early_pool
+    workers = early_pool(processes, int(map_kwargs.get("batch_size", 1000)))
     fn_kwargs.update(get_model_and_transform(model_kwargs=model_kwargs, transform_kwargs=transform_kwargs))
-    fn_kwargs["pool"] = None if processes is None else Pool(processes=processes)
     from ..ir.embedding import _rank_shard, _save_rank_shards, process_rank_and_world
     rank, world = process_rank_and_world()
     if world > 1:  # one process per GPU: every rank embeds its contiguous block of rows (see viquae_amd/ir/embedding.py)
         dataset = _rank_shard(dataset, rank, world)
-    # decode / pack / H2D / device-side resize of batch i + 1 behind the CLIP forward of batch i (viquae_amd/pipeline.py)
+    # decode / pack / H2D / device-side resize of batch i + 1 behind the CLIP forward of batch i (viquae_amd/pipeline.py).
+    # `processes` (the reference's pool size) then sets the number of DECODE processes, which write the RGB bytes straight
+    # into a shared page-locked staging buffer instead of pickling arrays back (viquae_amd/image/decode_pool.py).
     from ..pipeline import image_pipeline_or_none
-    pipe = image_pipeline_or_none(dataset, map_kwargs, **fn_kwargs)
+    pipe = image_pipeline_or_none(dataset, map_kwargs, decode_procs=processes, decode_pool=workers, **fn_kwargs)
+    if pipe is None and workers is not None:
+        workers.close()
     if pipe is not None:
         try:
             dataset = dataset.map(pipe.embed, batched=True, with_indices=True, **map_kwargs)
@@ -80,6 +86,7 @@ def dataset_embed(dataset_path, map_kwargs={}, model_kwargs={}, transform_kwargs
             dataset_embed.last_pipeline_stats = dict(pipe.stats)
     else:
         dataset_embed.last_pipeline_stats = None
+        fn_kwargs["pool"] = None if processes is None else Pool(processes=processes)
         dataset = dataset.map(embed, batched=True, fn_kwargs=fn_kwargs, **map_kwargs)
     if world > 1:
         return _save_rank_shards(dataset, dataset_path, output_path, rank, world)

@@ -130,6 +130,16 @@ class CLIPImageProcessorHIP:
             list(self._pool().map(lambda lo: pack(lo, min(B, lo + step)), range(0, B, step)))
         else:
             pack(0, B)
+        return self.run_packed(packed, geom, totals, B, out=out)
+
+    def run_packed(self, packed, geom, totals, B, out=None):
+        """The device half of :meth:`preprocess`: ``packed`` = a (page-locked) uint8 CPU tensor that already holds the B decoded
+        images at the byte offsets ``geom[:, 0]`` of :meth:`plan` (the image pipeline's decode workers write them there
+        directly, viquae_amd/image/decode_pool.py) -> {"pixel_values": float32 [B, 3, crop_h, crop_w] on the device}."""
+        lib = _lib.load()
+        dev = torch.device(self.device if self.device is not None else "cuda")
+        if out is None:
+            out = torch.empty((B, 3, self.crop_h, self.crop_w), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             src = packed[:int(totals[0])].to(dev, non_blocking=True)
             gdev = torch.from_numpy(geom).to(dev, non_blocking=True)

@@ -411,7 +411,8 @@ class ImageEmbedPipeline:
     decoded RGB images into one pinned buffer, H2D and the Pillow-exact resize / crop / normalise kernels on a side stream --
     hidden behind the CLIP forward of batch i.  Needs the device-side transform (``transform.on_device``)."""
 
-    def __init__(self, dataset, model, transform, save_as, image_key, call, pool, batch_size, depth=2):
+    def __init__(self, dataset, model, transform, save_as, image_key, call, pool, batch_size, depth=2, decode_procs=None,
+                 decode_pool=None):
         self.model, self.transform, self.save_as, self.image_key, self.call, self.pool = model, transform, save_as, image_key, call, pool
         self.column = _arrow_strings(dataset, image_key)
         n = len(dataset)
@@ -422,21 +423,63 @@ class ImageEmbedPipeline:
         self.side = torch.cuda.Stream(device=self.device)
         self.out_ring = _PinnedRing(3)
         self.stats = {"batches": 0, "decode_s": 0.0, "prepare_s": 0.0, "launch_s": 0.0, "wait_result_s": 0.0}
-        # Without the caller's process pool (`processes` of the reference's config) the files are decoded by a small pool of
-        # THREADS: Pillow releases the GIL inside its codecs (JPEG: 0.71 -> 0.40 ms per image on the GPU box) but not in the
-        # per-file Python around them, so more than a handful of threads only fight for the GIL (measured: 32 threads decode
-        # BMP files SLOWER than one).  MQ_IMAGE_DECODE_THREADS overrides.
-        self.threads = None
-        if pool is None:
+        # Decoding.  Default: forked decode PROCESSES that write the RGB bytes straight into a shared page-locked staging slot
+        # (viquae_amd/image/decode_pool.py: Pillow's per-file Python holds the GIL, threads stop scaling at ~2x; `processes`
+        # of the reference's config sets their number, MQ_IMAGE_DECODE_PROCS the default, 0 disables).  Otherwise the caller's
+        # multiprocessing pool (arrays pickled back), or a few threads.
+        from .image import decode_pool as dp
+        self.decode, self.threads = decode_pool, None
+        if self.decode is not None and not hasattr(transform, "run_packed"):
+            self.decode.close()
+            self.decode = None
+        procs = decode_procs if decode_procs is not None else (dp.default_procs() if pool is None else 0)
+        if self.decode is None and procs and hasattr(transform, "run_packed") and hasattr(os, "fork"):
+            # (created here, the workers are forked from a process that already holds the model: the FIRST device operation
+            # after a fork pays for the page-locked memory the process owns -- 4 s with the CLIP weights loaded, 22 s with 2 GB
+            # of pinned buffers, measured; image.embedding.dataset_embed therefore forks them before it loads anything)
+            try:
+                self.decode = dp.DecodePool(procs, dp.slot_bytes(batch_size), n_slots=2)
+            except Exception as e:  # noqa: BLE001 - e.g. not enough lockable memory: decode in threads instead
+                import warnings
+                warnings.warn(f"image decode processes unavailable ({e!r}): decoding in threads")
+        if self.decode is None and pool is None:
             from concurrent.futures import ThreadPoolExecutor
             self.threads = ThreadPoolExecutor(max(1, int(os.environ.get("MQ_IMAGE_DECODE_THREADS", min(8, os.cpu_count() or 1)))))
+        self.stats["decode"] = (f"{len(self.decode.procs)} processes -> shared pinned staging" if self.decode is not None else
+                                "caller's process pool" if pool is not None else f"{self.threads._max_workers} threads")
         self.look = Lookahead(len(self.bounds), self._prepare, self._launch, depth=depth)
+
+    def _prepare_shared(self, names, t0):
+        """Decode workers: sizes -> plan -> decode into the planned offsets of a shared slot -> device-side transform."""
+        from .data import loading
+        paths = [str(loading.IMAGE_PATH / n) for n in names]
+        sizes = self.decode.sizes(paths)
+        kept = [i for i, sz in enumerate(sizes) if sz is not None]
+        if not kept:
+            return kept, set(), None, None
+        geom, totals = self.transform.plan(np.array([sizes[i] for i in kept], dtype=np.int64))
+        if int(totals[0]) > self.decode.slot_bytes:
+            return None  # larger images than the slots were sized for: this batch takes the thread path
+        slot = self.decode.take_slot()
+        failed = self.decode.decode(slot, {k: int(g[0]) for k, g in zip(kept, geom)})
+        self.stats["decode_s"] += time.perf_counter() - t0
+        with torch.cuda.device(self.device), torch.cuda.stream(self.side):
+            inputs = dict(self.transform.run_packed(self.decode.tensors[slot], geom, totals, len(kept)))  # synchronises: the slot is free again
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        return kept, failed, inputs, ev
 
     def _prepare(self, j):
         from .data.loading import load_image_array, load_image_batch
         t0 = time.perf_counter()
         s, e = self.bounds[j]
         names = self.column.slice(s, e - s).to_pylist()
+        if self.decode is not None:
+            got = self._prepare_shared(names, t0)
+            if got is not None:
+                kept, failed, inputs, ev = got
+                self.stats["prepare_s"] += time.perf_counter() - t0
+                return {"names": names, "kept": kept, "failed": failed, "inputs": inputs, "event": ev, "rows": len(names)}
         if self.threads is not None:
             images = list(self.threads.map(load_image_array, names))
         else:
@@ -450,12 +493,12 @@ class ImageEmbedPipeline:
                 ev = torch.cuda.Event()
                 ev.record(self.side)
         self.stats["prepare_s"] += time.perf_counter() - t0
-        return {"names": names, "kept": kept, "inputs": inputs, "event": ev, "rows": len(names)}
+        return {"names": names, "kept": kept, "failed": set(), "inputs": inputs, "event": ev, "rows": len(names)}
 
     def _launch(self, p):
         t0 = time.perf_counter()
         if not p["kept"]:
-            return _Handle(None, torch.empty((0, 1)), 0, extra=(p["names"], p["kept"], p["rows"]))
+            return _Handle(None, torch.empty((0, 1)), 0, extra=(p["names"], p["kept"], p["failed"], p["rows"]))
         with torch.cuda.device(self.device):
             self.main.wait_event(p["event"])
             for t in p["inputs"].values():
@@ -473,7 +516,7 @@ class ImageEmbedPipeline:
             ev.record(self.main)
             self.out_ring.events[slot] = ev
         self.stats["launch_s"] += time.perf_counter() - t0
-        return _Handle(ev, pinned, len(p["kept"]), extra=(p["names"], p["kept"], p["rows"]))
+        return _Handle(ev, pinned, len(p["kept"]), extra=(p["names"], p["kept"], p["failed"], p["rows"]))
 
     def embed(self, batch, indices):
         i = self.stats["batches"]
@@ -482,16 +525,20 @@ class ImageEmbedPipeline:
             raise RuntimeError("Dataset.map handed over batches in another order than the prefetcher prepared them; "
                                "set MQ_EMBED_PIPELINE=0")
         t0 = time.perf_counter()
-        found, (names, kept, rows) = self.look.step(i)
+        found, (names, kept, failed, rows) = self.look.step(i)
         self.stats["wait_result_s"] += time.perf_counter() - t0
         if names != batch[self.image_key]:
             raise RuntimeError(f"the prefetched file names of batch {i} differ from what Dataset.map decoded; set MQ_EMBED_PIPELINE=0")
         self.stats["batches"] = i + 1
+        if len(kept) == rows and not failed:
+            batch[self.save_as] = found   # every image was readable: ONE [B, H] array (Arrow ingests it without a per-row pass)
+            return batch
         output = [None] * rows
-        if not kept:
+        if len(failed) == len(kept):
             return output  # (sic) the reference returns the bare list here: meerqat/image/embedding.py:134-135
         for row, k in enumerate(kept):
-            output[k] = found[row]
+            if k not in failed:   # a file that opened but did not decode: None, like an unreadable one
+                output[k] = found[row]
         batch[self.save_as] = output
         return batch
 
@@ -500,12 +547,15 @@ class ImageEmbedPipeline:
         self.look.close()
         if self.threads is not None:
             self.threads.shutdown(wait=False)
+        if self.decode is not None:
+            self.decode.close()
 
 
 def image_pipeline_or_none(dataset, map_kwargs, model=None, transform=None, save_as="image_embedding", image_key="image", call=None,
-                           pool=None, **other):
+                           pool=None, decode_procs=None, decode_pool=None, **other):
     if not pipeline_enabled() or other or model is None or transform is None or not getattr(transform, "on_device", False):
         return None
     if not torch.cuda.is_available() or not _plain_dataset(dataset, map_kwargs) or _arrow_strings(dataset, image_key) is None:
         return None
-    return ImageEmbedPipeline(dataset, model, transform, save_as, image_key, call, pool, int(map_kwargs.get("batch_size", 1000)))
+    return ImageEmbedPipeline(dataset, model, transform, save_as, image_key, call, pool, int(map_kwargs.get("batch_size", 1000)),
+                              decode_procs=decode_procs, decode_pool=decode_pool)
