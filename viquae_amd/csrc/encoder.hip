@@ -1080,13 +1080,28 @@ __global__ __launch_bounds__(WIDE ? 512 : 256) void attention_x3_kernel(const fl
         Ot[i * 65 + 32 + d] = oacc1[reg] * inv;
     }
     __syncthreads();
-    for (int e = lane; e < 32 * 64; e += 64) {
-        const int r = e >> 6, c = e & 63;
+    // a lane takes EIGHT consecutive d of one query row: two 16-byte stores for the fp32 output, one 16-byte store each for
+    // the hi and the lo halves of the split output (round 2 stored 4 bytes per lane and instruction: 32 stores and 32 DPP /
+    // pack sequences per lane instead of 4 + 4)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = 8 * it + (lane >> 3), c0 = 8 * (lane & 7);
         const int qr = blockIdx.y * qpb + 32 * w + r;
-        const size_t at = (row0 + qr) * H + h * DH;
-        const float val = Ot[r * 65 + c];
-        if (out && qr < L) out[at + c] = val;
-        if (out_h) store_split_pair(val, qr < L, out_h, out_l, at + (c & ~1), lane);
+        const size_t at = (row0 + qr) * H + h * DH + c0;
+        const float* src = Ot + r * 65 + c0;
+        const float4 u = make_float4(src[0], src[1], src[2], src[3]), v = make_float4(src[4], src[5], src[6], src[7]);
+        if (qr < L) {
+            if (out) {
+                *reinterpret_cast<float4*>(out + at) = u;
+                *reinterpret_cast<float4*>(out + at + 4) = v;
+            }
+            if (out_h) {
+                bf16x8_t hi8, lo8;
+                split8(u, v, hi8, lo8);
+                *reinterpret_cast<uint4*>(out_h + at) = __builtin_bit_cast(uint4, hi8);
+                *reinterpret_cast<uint4*>(out_l + at) = __builtin_bit_cast(uint4, lo8);
+            }
+        }
     }
 }
 
