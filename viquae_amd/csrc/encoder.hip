@@ -443,7 +443,56 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
             }
         }
     };
-    if (m0 + GT <= M && n0 + GT <= N) epilogue(std::true_type{}); else epilogue(std::false_type{});
+    if (SPLIT_OUT && m0 + GT <= M && n0 + GT <= N && (N & 7) == 0) {
+        // Round 3, SPLIT outputs only (measured: FFN1 + GELU 2.90 -> 2.83 ms; with fp32 outputs, whose direct stores are already
+        // 128-byte runs per half-wave, the detour through LDS costs 2-6 %): the C store of a tile that lies wholly inside C goes through LDS, one 32 x 32 accumulator at a time, so that
+        // a lane ends up with EIGHT consecutive columns of one row: 16-byte stores (two for fp32, one each for the hi and the
+        // lo halves of a split output) and 16-byte residual loads, instead of 4-byte ones -- a quarter of the memory
+        // instructions, and the split pair needs no DPP exchange.  Bias and activation are applied in the accumulator layout
+        // (one column per lane), the residual after the transposition: per element the operations and their order are those
+        // of the direct epilogue, so the results keep their bits.  Scratch: the LDS stage the K loop has just finished with
+        // (the other one may be receiving the next tile's first K step), 4 KiB per wave, 16-byte groups XOR-swizzled by the row.
+        __syncthreads();  // every wave has read its last operands from that stage
+        float* Ot = reinterpret_cast<float*>(smem + (stage ^ 1) * XS_STAGE) + w * 1024;
+        const int nb0 = n0 + 64 * wc + i, nb1 = nb0 + 32;
+        const float bias0 = EPI != EPI_NONE ? bias[nb0] : 0.f, bias1 = EPI != EPI_NONE ? bias[nb1] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x16& acc = a == 0 ? acc00 : a == 1 ? acc01 : a == 2 ? acc10 : acc11;
+            const float bs = (a & 1) ? bias1 : bias0;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+                float v = acc[reg] + bs;
+                if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                if (EPI == EPI_BIAS_QUICKGELU) v = quick_gelu(v);
+                Ot[row * 32 + ((((i >> 3) ^ (row & 3)) << 3) | (i & 7))] = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave reads what it has just written (LDS is in order per wave)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = 16 * it + (lane >> 2), g = lane & 3;
+                const float* src = Ot + row * 32 + ((g ^ (row & 3)) << 3);
+                float4 u = *reinterpret_cast<const float4*>(src), v = *reinterpret_cast<const float4*>(src + 4);
+                const size_t at = (size_t)(m0 + 64 * wr + 32 * (a >> 1) + row) * N + (n0 + 64 * wc + 32 * (a & 1) + 8 * g);
+                if (EPI == EPI_BIAS_RESIDUAL) {
+                    const float4 ru = *reinterpret_cast<const float4*>(R + at), rv = *reinterpret_cast<const float4*>(R + at + 4);
+                    u.x += ru.x; u.y += ru.y; u.z += ru.z; u.w += ru.w;
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                if (SPLIT_OUT) {
+                    bf16x8_t hi8, lo8;
+                    split8(u, v, hi8, lo8);
+                    *reinterpret_cast<uint4*>(Ch + at) = __builtin_bit_cast(uint4, hi8);
+                    *reinterpret_cast<uint4*>(Cl + at) = __builtin_bit_cast(uint4, lo8);
+                } else {
+                    *reinterpret_cast<float4*>(C + at) = u;
+                    *reinterpret_cast<float4*>(C + at + 4) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next accumulator overwrites the scratch
+        }
+    } else if (m0 + GT <= M && n0 + GT <= N) epilogue(std::true_type{}); else epilogue(std::false_type{});
     if (next >= ntiles) break;
     tile = next;
     cur = nxt;
