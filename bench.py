@@ -173,7 +173,7 @@ def cpu_baseline(idx, Q, seconds):
         trials = []
         for backend, nthreads, block in (("torch", cpus["physical_cores"], 1024), ("torch", cpus["physical_cores"], 16384),
                                          ("torch", max(1, cpus["physical_cores"] // 2), 16384), ("numpy", None, 1024), ("numpy", None, 16384),
-                                         ("c", None, 1024), ("c", None, 16384)):
+                                         ("c", None, 1024), ("c", None, 4096)):
             try:
                 if nthreads:
                     torch.set_num_threads(nthreads)

@@ -52,6 +52,8 @@ def lib():
         L.oracle_pack_queries.restype = None
         L.oracle_sgemm_nt.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, fp, ctypes.c_int64]
         L.oracle_sgemm_nt.restype = None
+        L.oracle_heap_add_block_panels.argtypes = [fp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, fp, fp]
+        L.oracle_heap_add_block_panels.restype = None
         L.oracle_l2norm_rows_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int]
         L.oracle_l2norm_rows_f32.restype = None
         L.oracle_sqnorm_rows_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int, fp]
@@ -159,6 +161,7 @@ def knn_blas(X, Q, k, metric=0, block=1024, threads=None, query_block=4096, back
         hi = np.empty((n, k), dtype=np.int64)
         L.oracle_heap_init(n, k, hv.ctypes.data, hi.ctypes.data)
         qn = (qb * qb).sum(1) if metric == 1 else None
+        Sp = None
         if use_c:
             MR = int(L.oracle_sgemm_mr())
             Qp = np.empty(((n + MR - 1) // MR) * Qt.shape[1] * MR, dtype=np.float32)
@@ -168,6 +171,15 @@ def knn_blas(X, Q, k, metric=0, block=1024, threads=None, query_block=4096, back
             xb = Xt[s:s + block]
             nb = xb.shape[0]
             Sb = S[:n, :nb] if nb == block else torch.empty((n, nb), dtype=torch.float32)
+            if use_c and metric == 0:
+                # inner product: panel-major scores (contiguous per thread of the sgemm), read as they are by the heap pass
+                xc = np.ascontiguousarray(xb.numpy())
+                npan = (nb + 31) // 32
+                if Sp is None or Sp.size < npan * n * 32:
+                    Sp = np.empty(npan * n * 32, dtype=np.float32)
+                L.oracle_sgemm_nt(Qp.ctypes.data, n, Qt.shape[1], xc.ctypes.data, nb, Sp.ctypes.data, -1)
+                L.oracle_heap_add_block_panels(Sp.ctypes.data, n, s, nb, k, hv.ctypes.data, hi.ctypes.data)
+                continue
             if use_c:
                 xc = np.ascontiguousarray(xb.numpy())
                 L.oracle_sgemm_nt(Qp.ctypes.data, n, Qt.shape[1], xc.ctypes.data, nb, Sb.data_ptr(), Sb.stride(0))

@@ -339,6 +339,39 @@ void oracle_heap_add_block(const float *S, int nq, int64_t ld, int64_t j0, int n
     }
 }
 
+/* oracle_heap_add_block over the panel-major score block of oracle_sgemm_nt (S[panel][nq][32]; columns >= nb are padding) */
+void oracle_heap_add_block_panels(const float *S, int nq, int64_t j0, int nb, int k, float *hv, int64_t *hi) {
+    const int npan = (nb + 31) / 32;
+#pragma omp parallel for schedule(static)
+    for (int q = 0; q < nq; ++q) {
+        float *v = hv + (size_t)q * k;
+        int64_t *id = hi + (size_t)q * k;
+        float thr = v[0];
+        for (int pn = 0; pn < npan; ++pn) {
+            const float *s = S + ((size_t)pn * (size_t)nq + (size_t)q) * 32;
+            const int nc = nb - pn * 32 < 32 ? nb - pn * 32 : 32;
+            for (int j = 0; j < nc; ++j) {
+                const float g = s[j];
+                if (!(g > thr)) continue;
+                int p = 0;
+                const int64_t gid = j0 + pn * 32 + j;
+                for (;;) {
+                    int c = 2 * p + 1;
+                    if (c >= k) break;
+                    if (c + 1 < k && heap_worse(v[c + 1], id[c + 1] < 0 ? INT64_MAX : id[c + 1], v[c], id[c] < 0 ? INT64_MAX : id[c])) ++c;
+                    if (!heap_worse(v[c], id[c] < 0 ? INT64_MAX : id[c], g, gid)) break;
+                    v[p] = v[c];
+                    id[p] = id[c];
+                    p = c;
+                }
+                v[p] = g;
+                id[p] = gid;
+                thr = v[0];
+            }
+        }
+    }
+}
+
 static int ent_cmp_best_first(const void *a, const void *b) {
     const ent_t *x = (const ent_t *)a, *y = (const ent_t *)b;
     if (x->id < 0 || y->id < 0) return (x->id < 0) - (y->id < 0);
@@ -377,7 +410,10 @@ void oracle_heap_finish(int nq, int k, int metric, const float *hv, const int64_
  * one OpenMP thread per 32-column panel of X -- good for a few TFLOP/s.  Same role as the BLAS call: scores carry ITS
  * summation order (k ascending per accumulator, fused multiply-add), not the fmaf chain's bits... they are in fact the same
  * chain per output, but nothing relies on it.
- *   Qp: queries packed by oracle_pack_queries ([ceil(nq / MR)][d][MR], zero padded); S row stride ld.
+ *   Qp: queries packed by oracle_pack_queries ([ceil(nq / MR)][d][MR], zero padded); S row stride ld, or ld < 0 for the
+ *   PANEL-MAJOR layout S[ceil(nb / 32)][nq][32] (what a thread computes is then contiguous: row-major S makes every
+ *   14 x 32 micro-tile a set of 128-byte pieces one row stride apart, which thrashes the L1 sets -- measured 67 GFLOP/s at a
+ *   64 KB stride against 669 at 4 KB); oracle_heap_add_block_panels reads that layout.
  */
 #include <immintrin.h>
 
@@ -419,6 +455,12 @@ __attribute__((target("avx512f"))) static void panel_avx512(const float *Qp, int
         for (int i = 0; i < 14; ++i) {
             const int q = p * MR + i;
             if (q >= nq) break;
+            if (ld < 0) { /* panel-major output: S[panel][q][32], contiguous per thread */
+                float *dst = S + ((size_t)(j0 / 32) * (size_t)nq + (size_t)q) * 32;
+                _mm512_storeu_ps(dst, c0[i]);
+                _mm512_storeu_ps(dst + 16, c1[i]);
+                continue;
+            }
             float tmp[32];
             _mm512_storeu_ps(tmp, c0[i]);
             _mm512_storeu_ps(tmp + 16, c1[i]);
@@ -449,6 +491,12 @@ __attribute__((target("avx2,fma"))) static void panel_avx2(const float *Qp, int 
             for (int i = 0; i < 6; ++i) {
                 const int q = p * MR + i;
                 if (q >= nq) break;
+                if (ld < 0) {
+                    float *dst = S + ((size_t)(j0 / 32) * (size_t)nq + (size_t)q) * 32 + 16 * h;
+                    _mm256_storeu_ps(dst, c0[i]);
+                    _mm256_storeu_ps(dst + 8, c1[i]);
+                    continue;
+                }
                 float tmp[16];
                 _mm256_storeu_ps(tmp, c0[i]);
                 _mm256_storeu_ps(tmp + 8, c1[i]);
