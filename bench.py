@@ -34,7 +34,12 @@ import os
 import sys
 import time
 
-import numpy as np
+# the CPU legs (OpenMP in oracle/knn_oracle.c, torch's CPU kernels) keep their threads on consecutive cores: read by the
+# OpenMP runtime when it is first loaded, i.e. with `import torch`
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -169,26 +174,23 @@ def cpu_baseline(idx, Q, seconds):
     try:
         # which host BLAS, how many threads, which database block: a 1-second calibration on the box (MKL takes a slow code
         # path on AMD hosts; numpy's OpenBLAS is capped at 64 threads; FAISS's own 1024-row blocks starve 128 threads)
-        Xc = idx.reconstruct_n(0, min(idx.ntotal, 1 << 15))
+        Xc = idx.reconstruct_n(0, min(idx.ntotal, 1 << 17))
         trials = []
         for backend, nthreads, block in (("torch", cpus["physical_cores"], 1024), ("torch", cpus["physical_cores"], 16384),
                                          ("torch", max(1, cpus["physical_cores"] // 2), 16384), ("numpy", None, 1024), ("numpy", None, 16384),
-                                         ("c", None, 1024), ("c", None, 4096)):
+                                         ("c", cpus["physical_cores"], 16384), ("c", max(1, cpus["physical_cores"] // 2), 16384),
+                                         ("c", max(1, cpus["physical_cores"] // 2), 65536)):
             try:
-                if nthreads:
-                    torch.set_num_threads(nthreads)
-                ok.knn_blas(Xc[:2048], Qh, TOPK, metric=0, block=block, backend=backend)
+                ok.knn_blas(Xc[:2048], Qh, TOPK, metric=0, block=block, backend=backend, threads=nthreads)
                 t0 = time.perf_counter()
-                ok.knn_blas(Xc, Qh, TOPK, metric=0, block=block, backend=backend)
+                ok.knn_blas(Xc, Qh, TOPK, metric=0, block=block, backend=backend, threads=nthreads)
                 trials.append((time.perf_counter() - t0, backend, nthreads, block))
             except Exception:
                 pass
         _, backend, nthreads, block = min(trials)
-        if nthreads:
-            torch.set_num_threads(nthreads)
-        legs["faiss_organisation"] = leg(lambda X, Qq: ok.knn_blas(X, Qq, TOPK, metric=0, block=block, backend=backend), 1 << 16, seconds * 0.7,
+        legs["faiss_organisation"] = leg(lambda X, Qq: ok.knn_blas(X, Qq, TOPK, metric=0, block=block, backend=backend, threads=nthreads), 1 << 16, seconds * 0.7,
                                          f"oracle.knn.knn_blas: 4096 x {block} sgemm blocks on the host BLAS ({backend}"
-                                         f"{', %d threads' % nthreads if nthreads else {'numpy': ' / OpenBLAS', 'c': ': oracle_sgemm_nt, OpenMP x%d' % threads}.get(backend, '')}; the fastest of "
+                                         f"{': oracle_sgemm_nt, OpenMP x%d' % nthreads if backend == 'c' else ', %d threads' % nthreads if nthreads else ' / OpenBLAS'}; the fastest of "
                                          f"{[(b, n, bl, round(2.0 * nq * Xc.shape[0] * DIM / t / 1e9)) for t, b, n, bl in trials]} (backend, threads, block, "
                                          f"GFLOP/s)) + FAISS's strict-'>' heap per query in C / OpenMP x{threads}")
     except Exception as e:

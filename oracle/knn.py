@@ -61,6 +61,8 @@ def lib():
         L.oracle_topk_merge.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp]
         L.oracle_topk_merge.restype = ctypes.c_int
         L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_set_num_threads.argtypes = [ctypes.c_int]
+        L.oracle_set_num_threads.restype = None
         _lib = L
     return _lib
 
@@ -71,6 +73,12 @@ def _f32(a):
 
 def num_threads():
     return int(lib().oracle_num_threads())
+
+
+def set_num_threads(n):
+    """OpenMP threads of the following oracle calls (0 / None: leave as is)."""
+    if n:
+        lib().oracle_set_num_threads(int(n))
 
 
 def l2norm_rows(x):
@@ -143,10 +151,12 @@ def knn_blas(X, Q, k, metric=0, block=1024, threads=None, query_block=4096, back
     AVX-512 / AVX2 kernel of knn_oracle.c, oracle_sgemm_nt: MKL takes a slow code path on AMD hosts and OpenBLAS stops at 64
     threads, so bench.py calibrates the three and keeps the fastest)."""
     import torch
-    if threads:
-        torch.set_num_threads(int(threads))
     use_numpy = backend == "numpy"
     use_c = backend == "c"
+    if threads and use_c:
+        set_num_threads(threads)
+    elif threads:
+        torch.set_num_threads(int(threads))
     X, Q = _f32(X), _f32(Q)
     Xt, Qt = torch.from_numpy(X), torch.from_numpy(Q)
     nq, N = Qt.shape[0], Xt.shape[0]
