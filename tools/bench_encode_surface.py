@@ -50,12 +50,13 @@ def make_vocab(path, rng, n_words=30000):
     return words, suffixes
 
 
-def make_passages(n, words, suffixes, rng):
-    """~100 'words' per passage of which a third carry a second word piece: ~130 tokens, lengths ~ N(130, 30)."""
+def make_passages(n, words, suffixes, rng, mean_words=98, sd_words=23):
+    """~100 'words' per passage of which a third carry a second word piece: ~130 tokens, lengths ~ N(130, 30)
+    (mean_words = 11: question-like texts of ~16 tokens)."""
     words = np.asarray(words)
     tails = np.asarray([s[2:] for s in suffixes])
     out = []
-    for n_words in np.clip(rng.normal(98, 23, n), 8, 190).astype(int):
+    for n_words in np.clip(rng.normal(mean_words, sd_words, n), 3, 190).astype(int):
         w = rng.choice(words, n_words)
         t = rng.choice(tails, n_words)
         glue = rng.random(n_words) < 0.33
@@ -63,7 +64,7 @@ def make_passages(n, words, suffixes, rng):
     return out
 
 
-def text_job(n_passages=65536, batch=2048, max_length=256, serial_batches=3, workdir=None):
+def text_job(n_passages=65536, batch=2048, max_length=256, serial_batches=3, workdir=None, mean_words=98, sd_words=23, what="passages"):
     import datasets
     from transformers import BertTokenizer
     from viquae_amd.encoders import DPRContextEncoder
@@ -75,15 +76,15 @@ def text_job(n_passages=65536, batch=2048, max_length=256, serial_batches=3, wor
     work = workdir or tempfile.mkdtemp(prefix="mq_encode_")
     words, suffixes = make_vocab(os.path.join(work, "tok"), rng)
     tok = BertTokenizer(os.path.join(work, "tok", "vocab.txt"))
-    passages = make_passages(n_passages, words, suffixes, rng)
+    passages = make_passages(n_passages, words, suffixes, rng, mean_words, sd_words)
     datasets.Dataset.from_dict({"passage": passages, "index": list(range(n_passages))}).save_to_disk(os.path.join(work, "kb"))
     dev = torch.device("cuda")
     model = DPRContextEncoder.from_state_dict(BERT_BASE, random_bert_state(BERT_BASE, 1)).to(dev).eval()
     tk = dict(return_tensors="pt", padding="max_length", truncation=True, max_length=max_length)
     kw = dict(model=model, tokenizer=tok, tokenization_kwargs=tk, key="passage", save_as="DPR_few_shot", output_key="pooler_output",
               map_kwargs={"batch_size": batch})
-    out = {"workload": f"{n_passages} synthetic passages, BertTokenizer pad-to-{max_length}, DPR bert-base, batch {batch} "
-                       "(experiments/ir/viquae/dpr/passages/config.json)"}
+    out = {"workload": f"{n_passages} synthetic {what}, BertTokenizer pad-to-{max_length}, DPR bert-base, batch {batch} "
+                       f"(experiments/ir/viquae/dpr/{what}/config.json)"}
     # -- stages, one batch at a time ------------------------------------------------------------------------------
     texts = passages[:batch]
     tok(texts[:64], **tk)
@@ -256,7 +257,9 @@ def image_job_in_a_fresh_process(ext):
 def main(n_passages=65536):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for name, fn in (("text", lambda: text_job(n_passages)), ("image", lambda: image_job_in_a_fresh_process("bmp")),
+    for name, fn in (("text", lambda: text_job(n_passages)),
+                     ("text_questions", lambda: text_job(32768, mean_words=11, sd_words=4, serial_batches=2, what="questions")),
+                     ("image", lambda: image_job_in_a_fresh_process("bmp")),
                      ("image_jpeg", lambda: image_job_in_a_fresh_process("jpg"))):
         try:
             out[name] = fn()
