@@ -34,12 +34,7 @@ import os
 import sys
 import time
 
-# the CPU legs (OpenMP in oracle/knn_oracle.c, torch's CPU kernels) keep their threads on consecutive cores: read by the
-# OpenMP runtime when it is first loaded, i.e. with `import torch`
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")
-
-import numpy as np  # noqa: E402
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
