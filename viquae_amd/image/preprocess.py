@@ -132,10 +132,12 @@ class CLIPImageProcessorHIP:
             pack(0, B)
         return self.run_packed(packed, geom, totals, B, out=out)
 
-    def run_packed(self, packed, geom, totals, B, out=None):
+    def run_packed(self, packed, geom, totals, B, out=None, sync=True):
         """The device half of :meth:`preprocess`: ``packed`` = a (page-locked) uint8 CPU tensor that already holds the B decoded
         images at the byte offsets ``geom[:, 0]`` of :meth:`plan` (the image pipeline's decode workers write them there
-        directly, viquae_amd/image/decode_pool.py) -> {"pixel_values": float32 [B, 3, crop_h, crop_w] on the device}."""
+        directly, viquae_amd/image/decode_pool.py) -> {"pixel_values": float32 [B, 3, crop_h, crop_w] on the device}.
+        ``sync=False``: nothing is waited for -- the copy and the kernels are only enqueued on the current stream; the caller
+        keeps ``packed`` untouched, and the returned ``"_keep"`` tensors alive, until an event recorded after the call fires."""
         lib = _lib.load()
         dev = torch.device(self.device if self.device is not None else "cuda")
         if out is None:
@@ -150,6 +152,8 @@ class CLIPImageProcessorHIP:
                                                   self.image_mean.ctypes.data, self.image_std.ctypes.data, out.data_ptr(),
                                                   ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream),
                        "mq_image_preprocess_u8")
+            if not sync:
+                return {"pixel_values": out, "_keep": (src, gdev, ws)}
             # the pinned staging buffer and the workspace may be recycled as soon as this returns
             torch.cuda.current_stream(dev).synchronize()
         return {"pixel_values": out}

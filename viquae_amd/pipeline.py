@@ -445,6 +445,7 @@ class ImageEmbedPipeline:
         if self.decode is None and pool is None:
             from concurrent.futures import ThreadPoolExecutor
             self.threads = ThreadPoolExecutor(max(1, int(os.environ.get("MQ_IMAGE_DECODE_THREADS", min(8, os.cpu_count() or 1)))))
+        self._slot_busy = {}
         self.stats["decode"] = (f"{len(self.decode.procs)} processes -> shared pinned staging" if self.decode is not None else
                                 "caller's process pool" if pool is not None else f"{self.threads._max_workers} threads")
         self.look = Lookahead(len(self.bounds), self._prepare, self._launch, depth=depth)
@@ -461,13 +462,19 @@ class ImageEmbedPipeline:
         if int(totals[0]) > self.decode.slot_bytes:
             return None  # larger images than the slots were sized for: this batch takes the thread path
         slot = self.decode.take_slot()
+        busy = self._slot_busy.pop(slot, None)
+        if busy is not None:      # the copy that last read this slot (two batches ago) must be over before it is rewritten
+            busy[0].synchronize()
         failed = self.decode.decode(slot, {k: int(g[0]) for k, g in zip(kept, geom)})
         self.stats["decode_s"] += time.perf_counter() - t0
         with torch.cuda.device(self.device), torch.cuda.stream(self.side):
-            inputs = dict(self.transform.run_packed(self.decode.tensors[slot], geom, totals, len(kept)))  # synchronises: the slot is free again
+            # enqueued only: the DMA of this slot and the resize kernels run while the workers decode the NEXT batch into the
+            # other slot
+            got = self.transform.run_packed(self.decode.tensors[slot], geom, totals, len(kept), sync=False)
             ev = torch.cuda.Event()
             ev.record(self.side)
-        return kept, failed, inputs, ev
+        self._slot_busy[slot] = (ev, got.pop("_keep", None))
+        return kept, failed, dict(got), ev
 
     def _prepare(self, j):
         from .data.loading import load_image_array, load_image_batch
