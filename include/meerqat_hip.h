@@ -129,7 +129,9 @@ int mq_knn_search_f32_ev(const float *packed_dev, const float *sqnorm_dev, int64
  * two extra columns, the bf16 pair of -||x||^2/2 (queries get 1, 1), so that the same scan ranks by q.x - ||x||^2/2.
  * The bf16 copy is metric-specific: pass the same `metric` to the three calls.  Extra shard buffers:
  *   rowmajor_dev [N, d] fp32  : the stored rows in row-major order (re-scoring operand)
- *   bf16_dev                  : mq_knn_screen_bytes(N, d, metric) bytes, bf16 copy (rows padded to 256, d (+2) to 64)
+ *   bf16_dev                  : mq_knn_screen_bytes(N, d, metric) bytes, bf16 copy (rows padded to 256, d (+2) to 64); an
+ *                               opaque buffer owned by these three calls -- stored tile by tile ([row / 256][col / 64][256][64]:
+ *                               one K step's operand is one contiguous 32-KiB block), a prefix of the rows is a prefix of it
  *   xstats_dev                : THREE floats kept by mq_knn_screen_prepare (zero them before its first call):
  *                               max ||x||^2, max ||xc - bf16(xc)||^2 and max ||xc||^2 over the shard (xc = x - centre),
  *                               the inputs of the error bound

@@ -1234,11 +1234,10 @@ static int screen_copy_and_stats(const float* sqnorm_dev, int d, int metric, int
     const float* rm = rowmajor_dev + (size_t)row_offset * d;
     const int64_t quads = n * (int64_t)(dp / 4);
     hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, rm, n, d, dp,
-                       (unsigned short*)bf16_dev + (size_t)row_offset * dp, metric == MQ_METRIC_L2 ? 1 : 0, sqnorm_dev + row_offset,
-                       center_dev);
+                       (unsigned short*)bf16_dev, metric == MQ_METRIC_L2 ? 1 : 0, sqnorm_dev + row_offset, center_dev, row_offset);
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(row_err_stats_kernel, dim3((unsigned)((n + 3) / 4 < 2048 ? (n + 3) / 4 : 2048)), dim3(256), 0, st, rm,
-                       (const unsigned short*)bf16_dev + (size_t)row_offset * dp, n, d, dp, (unsigned*)xstats_dev, center_dev);
+                       (const unsigned short*)bf16_dev, n, d, dp, (unsigned*)xstats_dev, center_dev, row_offset);
     MQ_HIP(hipGetLastError());
     return MQ_OK;
 }
@@ -1343,13 +1342,13 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
                            g.dpad, (int64_t)0, 0, Qp, qn, (const int*)nullptr);
         MQ_HIP(hipGetLastError());
     }
-    if (g.nqpad > nq)  // bf16 rows of the padding queries of the last tile
-        MQ_HIP(hipMemsetAsync(Qb + (size_t)nq * dp, 0, (size_t)(g.nqpad - nq) * dp * 2, st));
+    if (g.nqpad > nq)  // bf16 rows of the padding queries: the last tile (tile layout: its real rows are written below)
+        MQ_HIP(hipMemsetAsync(Qb + (size_t)(g.nqpad - TQ) * dp, 0, (size_t)TQ * dp * 2, st));
     MQ_HIP(hipMemsetAsync(ovf, 0, g.off_smax + (size_t)g.nqpad * g.ms * 4 - g.off_ovf, st));  // ovf + gthr + smax
     {
         const int64_t quads = (int64_t)nq * (dp / 4);
         hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, q_rm, (int64_t)nq, d, dp, Qb,
-                           l2 ? 2 : 0, (const float*)nullptr);
+                           l2 ? 2 : 0, (const float*)nullptr, (const float*)nullptr, (int64_t)0);
         MQ_HIP(hipGetLastError());
         hipLaunchKernelGGL(screen_margin_kernel, dim3((unsigned)((g.nqpad + 3) / 4)), dim3(256), 0, st, q_rm, Qb, xstats_dev, nq,
                            (int)g.nqpad, d, dp, margin, l2);
