@@ -210,6 +210,13 @@ int mq_gemm_nt_f32(const float *A_dev, const float *W_dev, const float *bias_dev
  * weight), A stays fp32 and is split in registers; C ~= Ah.Wh + Al.Wh + Ah.Wl with fp32 accumulation --
  * relative error ~1e-5 (fp32-class) at 3/16 of the fp32-MFMA cycles.  K must be a multiple of 32. */
 int mq_split_bf16_f32(const float *src_dev, int64_t n, uint16_t *hi_dev, uint16_t *lo_dev, void *stream);
+/* The same split of a weight matrix W [N, K] (K a multiple of 32), stored in TILE layout [ceil(N / 256)][K / 32][256][32]
+ * (rows beyond N are zeros): the operand of one K step of a GEMM tile is then one contiguous 16-KiB block.  hi / lo hold
+ * mq_split_bf16_tiled_elems(N, K) elements each.  Pass such a pair to mq_gemm_nt_bf16x3_f32 / mq_gemm_nt_bf16x3s_f32 with
+ * MQ_GEMM_W_TILED or-ed into `epilogue`: same products in the same order, bit-identical results, 3.5-6 % faster GEMMs. */
+#define MQ_GEMM_W_TILED 0x100
+int64_t mq_split_bf16_tiled_elems(int N, int K);
+int mq_split_bf16_tiled_f32(const float *W_dev, int N, int K, uint16_t *hi_dev, uint16_t *lo_dev, void *stream);
 int mq_gemm_nt_bf16x3_f32(const float *A_dev, const uint16_t *Wh_dev, const uint16_t *Wl_dev, const float *bias_dev,
                           const float *residual_dev, float *C_dev, int M, int N, int K, int epilogue, void *stream);
 

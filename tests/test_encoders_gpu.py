@@ -691,3 +691,32 @@ def test_dpr_beyond_256_tokens_matches_the_oracle():
     assert np.abs(out["pooler_output"].cpu().numpy() - want).max() < TOL
     real = mask.astype(bool)   # padded positions attend like everybody else but nobody reads them
     assert np.abs(out["hidden_states"][-1].cpu().numpy() - np.asarray(hidden[-1]).reshape(B, L, -1))[real].max() < TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (300, 768, 768), (1000, 2304, 768), (517, 3072, 768), (260, 768, 3072),
+                                   (64, 100, 64), (1, 7, 96), (513, 515, 160)])
+def test_tiled_weight_split_gives_the_same_bits_as_the_row_major_split(M, N, K):
+    """mq_split_bf16_tiled_f32 + MQ_GEMM_W_TILED: the weight's (hi, lo) pair stored tile by tile ([N / 256][K / 32][256][32]) --
+    other addresses, same products in the same order: every epilogue, both activation forms, ragged M and N."""
+    from viquae_amd import encoders as E
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((M, K), generator=g, device="cuda")
+    w = torch.randn((N, K), generator=g, device="cuda") * 0.05
+    bias = torch.randn((N,), generator=g, device="cuda")
+    res = torch.randn((M, N), generator=g, device="cuda")
+    rm, tl = E.split_bf16(w), E.split_bf16_tiled(w)
+    assert tl.tiled and tl[0].numel() == ((N + 255) // 256) * 256 * K
+    # the tile layout holds exactly the row-major pair (and zeros in the padding rows)
+    for t, r in zip(tl, rm):
+        back = t.view((N + 255) // 256, K // 32, 256, 32).permute(0, 2, 1, 3).reshape(-1, K)
+        assert torch.equal(back[:N], r) and not back[N:].any()
+    asp = E.SplitAct(*E.split_bf16(a))
+    for epi, r_ in [(E.EPI_NONE, None), (E.EPI_BIAS, None), (E.EPI_BIAS_GELU, None), (E.EPI_BIAS_QUICKGELU, None),
+                    (E.EPI_BIAS_RESIDUAL, res)]:
+        b_ = None if epi == E.EPI_NONE else bias
+        want = E.gemm_nt(asp, w, b_, r_, epi, wsplit=rm)
+        assert torch.equal(E.gemm_nt(asp, w, b_, r_, epi, wsplit=tl), want)          # split activations (x3s)
+        assert torch.equal(E.gemm_nt(a, w, b_, r_, epi, wsplit=tl), E.gemm_nt(a, w, b_, r_, epi, wsplit=rm))  # fp32 activations (x3)
+        if N % 2 == 0:
+            o1, o2 = E.gemm_nt(asp, w, b_, r_, epi, wsplit=tl, out_split=True), E.gemm_nt(asp, w, b_, r_, epi, wsplit=rm, out_split=True)
+            assert torch.equal(o1.hi, o2.hi) and torch.equal(o1.lo, o2.lo)

@@ -43,6 +43,8 @@ SIGNATURES = {
     "mq_knn_launch_info": (c_int, [c_i64, c_int, c_int, c_int, ctypes.POINTER(c_i64)]),
     "mq_gemm_nt_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "mq_split_bf16_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
+    "mq_split_bf16_tiled_elems": (c_i64, [c_int, c_int]),
+    "mq_split_bf16_tiled_f32": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "mq_gemm_nt_bf16x3_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "mq_layernorm_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, ctypes.c_float, c_ptr]),
     "mq_bert_embed_ln_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int,

@@ -254,6 +254,33 @@ __global__ void split_bf16_kernel(const float* __restrict__ src, long long n, un
     lo[e] = __builtin_bit_cast(unsigned short, l);
 }
 
+// Weights in TILE layout [N / 256][K / 32][256][32] (rows padded to 256 with zeros): the W operand of one K step of a GEMM
+// tile is one contiguous 16-KiB block instead of 256 pieces of 64 bytes K x 2 bytes apart (same arithmetic, other addresses:
+// -3 ... -12 % per GEMM, tools/bench_gemm_shapes.py).  One thread per 4 consecutive k of one (padded) row.
+__global__ void split_bf16_tiled_kernel(const float* __restrict__ src, int N, int K, unsigned short* __restrict__ hi,
+                                        unsigned short* __restrict__ lo) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_row = K / 4;
+    const long long npad = (long long)((N + GT - 1) / GT) * GT;
+    if (e >= npad * per_row) return;
+    const long long n = e / per_row;
+    const int k = (int)(e - n * per_row) * 4;
+    unsigned short h[4] = {0, 0, 0, 0}, l[4] = {0, 0, 0, 0};
+    if (n < N) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = src[n * K + k + j];
+            const __bf16 hb = (__bf16)x;
+            const __bf16 lb = (__bf16)(x - (float)hb);
+            h[j] = __builtin_bit_cast(unsigned short, hb);
+            l[j] = __builtin_bit_cast(unsigned short, lb);
+        }
+    }
+    const size_t at = (((size_t)(n / GT) * (size_t)(K / XBK) + (size_t)(k / XBK)) * GT + (size_t)(n % GT)) * XBK + (size_t)(k % XBK);
+    *reinterpret_cast<uint2*>(hi + at) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2*>(lo + at) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+}
+
 // Split activations.  An activation tensor that only feeds GEMMs is kept as its (hi, lo) bf16 pair, written by the
 // kernel that PRODUCES it (LayerNorm, attention, the GELU epilogue): the consuming GEMM then streams bf16 operands
 // only and carries no conversions in its MFMA loop (measured: the in-loop split cost 18-22 % of encoder time).
@@ -284,7 +311,9 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
                                                            const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
                                                            const float* __restrict__ bias, const float* __restrict__ R,
                                                            float* __restrict__ C, unsigned short* __restrict__ Ch,
-                                                           unsigned short* __restrict__ Cl, int M, int N, int K, int ntm, int ntn) {
+                                                           unsigned short* __restrict__ Cl, int M, int N, int K, int ntm, int ntn,
+                                                           int wt) {
+    // wt != 0: Wh, Wl are in tile layout (split_bf16_tiled_kernel).
     // Each workgroup walks the output tiles blockIdx.x, + gridDim.x, ... (one tile per workgroup by default; a persistent
     // launch of ~#CU workgroups under MQ_GEMM_WGS).  The first K stage of the NEXT tile is requested during the last K step
     // of the current one, so its DMA round trip overlaps the C-store epilogue.
@@ -324,7 +353,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
         int wn = t.n0 + r; if (wn > N - 1) wn = N - 1;
         const size_t chunk = (size_t)(((lane & 3) ^ ((r >> 2) & 3)) * 8);
         t.a_voff = (unsigned)(((size_t)(am - t.m0) * K + chunk) * 2);
-        t.w_voff = (unsigned)(((size_t)(wn - t.n0) * K + chunk) * 2);
+        t.w_voff = wt ? (unsigned)(((size_t)r * XBK + chunk) * 2) : (unsigned)(((size_t)(wn - t.n0) * K + chunk) * 2);
         t.ah = reinterpret_cast<const char*>(Ah + (size_t)t.m0 * K);
         t.al = reinterpret_cast<const char*>(Al + (size_t)t.m0 * K);
         t.wh = reinterpret_cast<const char*>(Wh + (size_t)t.n0 * K);
@@ -334,10 +363,11 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
     auto issue = [&](const Tile& t, int kb, int stg) __attribute__((always_inline)) {
         const unsigned so = lds0 + stg * XS_STAGE;
         const size_t ko = (size_t)kb * (XBK * 2);
+        const size_t kow = wt ? (size_t)kb * X_W_BYTES : ko;  // tile layout: the next K step is the next 16-KiB block
         dma16s(t.ah + ko, t.a_voff, so);
         dma16s(t.al + ko, t.a_voff, so + X_W_BYTES);
-        dma16s(t.wh + ko, t.w_voff, so + 2 * X_W_BYTES);
-        dma16s(t.wl + ko, t.w_voff, so + 3 * X_W_BYTES);
+        dma16s(t.wh + kow, t.w_voff, so + 2 * X_W_BYTES);
+        dma16s(t.wl + kow, t.w_voff, so + 3 * X_W_BYTES);
     };
 
     int tile = blockIdx.x;
@@ -503,7 +533,7 @@ template <int EPI>
 __global__ __launch_bounds__(1024) void gemm_nt_x3_kernel(const float* __restrict__ A, const unsigned short* __restrict__ Wh,
                                                           const unsigned short* __restrict__ Wl, const float* __restrict__ bias,
                                                           const float* __restrict__ R, float* __restrict__ C, int M, int N, int K,
-                                                          int ntm, int ntn) {
+                                                          int ntm, int ntn, int wt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -538,7 +568,8 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3_kernel(const float* __restric
     {
         const int r = 16 * w + (lane >> 2);
         int wn = n0 + r; if (wn > N - 1) wn = N - 1;
-        w_voff = (unsigned)(((size_t)(wn - n0) * K + (size_t)(((lane & 3) ^ ((r >> 2) & 3)) * 8)) * 2);
+        const size_t chunk = (size_t)(((lane & 3) ^ ((r >> 2) & 3)) * 8);
+        w_voff = wt ? (unsigned)(((size_t)r * XBK + chunk) * 2) : (unsigned)(((size_t)(wn - n0) * K + chunk) * 2);
     }
     const char* const abase = reinterpret_cast<const char*>(A + (size_t)m0 * K);
     const char* const whbase = reinterpret_cast<const char*>(Wh + (size_t)n0 * K);
@@ -550,8 +581,9 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3_kernel(const float* __restric
         const unsigned so = stg * X_STAGE;
         dma16s(abase + (size_t)kb * (XBK * 4), a_voff[0], lds_a + so);
         dma16s(abase + (size_t)kb * (XBK * 4), a_voff[1], lds_a + so + 1024);
-        dma16s(whbase + (size_t)kb * (XBK * 2), w_voff, lds_wh + so);
-        dma16s(wlbase + (size_t)kb * (XBK * 2), w_voff, lds_wl + so);
+        const size_t kow = wt ? (size_t)kb * X_W_BYTES : (size_t)kb * (XBK * 2);
+        dma16s(whbase + kow, w_voff, lds_wh + so);
+        dma16s(wlbase + kow, w_voff, lds_wl + so);
     };
 
     const int i = lane & 31, kg = lane >> 5;
@@ -1262,8 +1294,23 @@ int mq_split_bf16_f32(const float* src_dev, int64_t n, uint16_t* hi_dev, uint16_
     return MQ_OK;
 }
 
+int64_t mq_split_bf16_tiled_elems(int N, int K) { return (int64_t)((N + GT - 1) / GT) * GT * (int64_t)K; }
+
+int mq_split_bf16_tiled_f32(const float* W_dev, int N, int K, uint16_t* hi_dev, uint16_t* lo_dev, void* stream) {
+    if (N == 0) return MQ_OK;
+    if (!W_dev || !hi_dev || !lo_dev || N < 0 || K <= 0 || (K % XBK) != 0) return MQ_EINVAL;
+    if (((uintptr_t)hi_dev | (uintptr_t)lo_dev) & 15) return MQ_EINVAL;
+    const long long quads = (long long)mq_split_bf16_tiled_elems(N, K) / 4;
+    hipLaunchKernelGGL(split_bf16_tiled_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W_dev, N, K,
+                       (unsigned short*)hi_dev, (unsigned short*)lo_dev);
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
 int mq_gemm_nt_bf16x3_f32(const float* A_dev, const uint16_t* Wh_dev, const uint16_t* Wl_dev, const float* bias_dev,
                           const float* residual_dev, float* C_dev, int M, int N, int K, int epilogue, void* stream) {
+    const int wt = (epilogue & MQ_GEMM_W_TILED) ? 1 : 0;
+    epilogue &= ~MQ_GEMM_W_TILED;
     if (M == 0 || N == 0) return MQ_OK;
     if (!A_dev || !Wh_dev || !Wl_dev || !C_dev || M < 0 || N < 0 || K <= 0 || (K % XBK) != 0) return MQ_EINVAL;
     if (epilogue < EPI_NONE || epilogue > EPI_BIAS_RESIDUAL) return MQ_EINVAL;
@@ -1277,7 +1324,7 @@ int mq_gemm_nt_bf16x3_f32(const float* A_dev, const uint16_t* Wh_dev, const uint
     case E:                                                                                                           \
         MQ_DYNAMIC_LDS_WITH(ENC_HIP, X_LDS_BYTES, gemm_nt_x3_kernel<E>); \
         hipLaunchKernelGGL(gemm_nt_x3_kernel<E>, grid, block, X_LDS_BYTES, st, A_dev, (const unsigned short*)Wh_dev,    \
-                           (const unsigned short*)Wl_dev, bias_dev, residual_dev, C_dev, M, N, K, ntm, ntn);           \
+                           (const unsigned short*)Wl_dev, bias_dev, residual_dev, C_dev, M, N, K, ntm, ntn, wt);       \
         break;
     switch (epilogue) {
         MQ_LAUNCH(EPI_NONE)
@@ -1294,6 +1341,8 @@ int mq_gemm_nt_bf16x3_f32(const float* A_dev, const uint16_t* Wh_dev, const uint
 int mq_gemm_nt_bf16x3s_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const uint16_t* Wh_dev, const uint16_t* Wl_dev,
                            const float* bias_dev, const float* residual_dev, float* C_dev, uint16_t* Ch_dev, uint16_t* Cl_dev,
                            int M, int N, int K, int epilogue, void* stream) {
+    const int wt = (epilogue & MQ_GEMM_W_TILED) ? 1 : 0;
+    epilogue &= ~MQ_GEMM_W_TILED;
     if (M == 0 || N == 0) return MQ_OK;
     if (!Ah_dev || !Al_dev || !Wh_dev || !Wl_dev || M < 0 || N < 0 || K <= 0 || (K % XBK) != 0) return MQ_EINVAL;
     if ((!C_dev) == (!Ch_dev) || (!Ch_dev != !Cl_dev)) return MQ_EINVAL;  // exactly one output form
@@ -1313,7 +1362,7 @@ int mq_gemm_nt_bf16x3s_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const
         MQ_DYNAMIC_LDS_WITH(ENC_HIP, XS_LDS_BYTES, gemm_nt_x3s_kernel<E, S>); \
         hipLaunchKernelGGL((gemm_nt_x3s_kernel<E, S>), grid, block, XS_LDS_BYTES, st, (const unsigned short*)Ah_dev,    \
                            (const unsigned short*)Al_dev, (const unsigned short*)Wh_dev, (const unsigned short*)Wl_dev, \
-                           bias_dev, residual_dev, C_dev, (unsigned short*)Ch_dev, (unsigned short*)Cl_dev, M, N, K, ntm, ntn); \
+                           bias_dev, residual_dev, C_dev, (unsigned short*)Ch_dev, (unsigned short*)Cl_dev, M, N, K, ntm, ntn, wt); \
     }
 #define MQ_LAUNCH(E)                                                                                                  \
     case E:                                                                                                           \

@@ -62,6 +62,30 @@ def split_bf16(w):
     return hi, lo
 
 
+GEMM_W_TILED = 0x100  # include/meerqat_hip.h MQ_GEMM_W_TILED
+
+
+class TiledSplit(tuple):
+    """(hi, lo) of :func:`split_bf16_tiled`: a weight's bf16 split in the GEMM kernels' tile layout."""
+    tiled = True
+
+
+def split_bf16_tiled(w):
+    """The split of :func:`split_bf16` for a weight matrix [N, K] (K % 32 == 0), stored tile by tile
+    ([ceil(N / 256)][K / 32][256][32], zero rows beyond N): the operand of one K step of a GEMM tile is one contiguous block.
+    ``gemm_nt(..., wsplit=TiledSplit)`` gives the same bits as with the row-major split, 3.5-6 % sooner."""
+    _check_cuda(w)
+    lib = _lib.load()
+    w = w.contiguous()
+    N, K = w.shape
+    n = int(lib.mq_split_bf16_tiled_elems(N, K))
+    hi = torch.empty(n, dtype=torch.int16, device=w.device)
+    lo = torch.empty(n, dtype=torch.int16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.mq_split_bf16_tiled_f32(w.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), _stream(w)), "mq_split_bf16_tiled_f32")
+    return TiledSplit((hi, lo))
+
+
 class SplitAct:
     """An activation kept as its (hi, lo) bf16 pair (two int16 tensors of the activation's [rows, features] shape):
     what the kernels producing GEMM inputs write in split_bf16 mode, and what ``mq_gemm_nt_bf16x3s_f32`` consumes."""
@@ -116,11 +140,12 @@ def gemm_nt(a, w, bias=None, residual=None, epilogue=EPI_NONE, out=None, wsplit=
         r = residual.data_ptr() if residual is not None else None
         res = SplitAct.empty(M, N, a.device) if out_split else (
             out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device))
+        flags = GEMM_W_TILED if getattr(wsplit, "tiled", False) else 0
         with torch.cuda.device(a.device):
             _lib.check(lib.mq_gemm_nt_bf16x3s_f32(
                 a.hi.data_ptr(), a.lo.data_ptr(), wsplit[0].data_ptr(), wsplit[1].data_ptr(), b, r,
                 None if out_split else res.data_ptr(), res.hi.data_ptr() if out_split else None,
-                res.lo.data_ptr() if out_split else None, M, N, K, epilogue, _stream(a.hi)), "mq_gemm_nt_bf16x3s_f32")
+                res.lo.data_ptr() if out_split else None, M, N, K, epilogue | flags, _stream(a.hi)), "mq_gemm_nt_bf16x3s_f32")
         return res
     if out_split:
         raise ValueError("out_split needs a split input activation")
@@ -133,8 +158,9 @@ def gemm_nt(a, w, bias=None, residual=None, epilogue=EPI_NONE, out=None, wsplit=
     r = residual.data_ptr() if residual is not None else None
     with torch.cuda.device(a.device):
         if wsplit is not None and K % 32 == 0:
+            flags = GEMM_W_TILED if getattr(wsplit, "tiled", False) else 0
             _lib.check(lib.mq_gemm_nt_bf16x3_f32(a.data_ptr(), wsplit[0].data_ptr(), wsplit[1].data_ptr(), b, r, out.data_ptr(),
-                                                 M, N, K, epilogue, _stream(a)), "mq_gemm_nt_bf16x3_f32")
+                                                 M, N, K, epilogue | flags, _stream(a)), "mq_gemm_nt_bf16x3_f32")
         else:
             _lib.check(lib.mq_gemm_nt_f32(a.data_ptr(), w.data_ptr(), b, r, out.data_ptr(), M, N, K, epilogue, _stream(a)),
                        "mq_gemm_nt_f32")
@@ -249,8 +275,9 @@ class _HipEncoder(nn.Module):
         w = getattr(self, name)
         cache = self.__dict__.setdefault("_split_cache", {})
         key = (name, w.device, w.data_ptr())
-        if key not in cache:
-            cache[key] = split_bf16(w)
+        if key not in cache:  # tile layout whenever the split-bf16 kernels can take the weight at all (K % 32 == 0)
+            tiled = w.dim() == 2 and w.shape[1] % 32 == 0 and os.environ.get("MQ_ENC_W_TILED", "1") != "0"
+            cache[key] = split_bf16_tiled(w) if tiled else split_bf16(w)
         return cache[key]
 
 
