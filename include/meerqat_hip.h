@@ -271,7 +271,12 @@ int mq_clip_text_embed_packed_f32(const int64_t *input_ids_dev, const int32_t *p
  *   mq_bert_embed_ln_split_f32 mq_bert_embed_ln_f32 writing fp32 and, optionally, the pair
  *   mq_attention_split_f32     mq_attention_causal_f32 writing fp32 (may be NULL) and/or the pair; bf16x3 != 0 computes
  *                              q.k and p.v as three-term split-bf16 products on the bf16 matrix pipe (fp32-class accuracy)
- * Pair outputs need an even feature count. */
+ * PAIR LAYOUT: the two arrays of a pair [M, K] are stored tile by tile -- element (row, col) at
+ * [row / 256][col / 32][row % 256][col % 32] -- so that the operand of one K step of a GEMM tile is one contiguous 16-KiB
+ * block (the layout of mq_split_bf16_tiled_f32, which can mint such a pair from an fp32 matrix).  Each array holds
+ * mq_split_bf16_tiled_elems(M, K) = ceil(M / 256) * 256 * K elements (rows beyond M are neither written nor read) and K must
+ * be a multiple of 32 (MQ_EUNSUPPORTED otherwise).  Every producer below writes it, mq_gemm_nt_bf16x3s_f32 reads it; the
+ * fp32 outputs stay row-major. */
 int mq_gemm_nt_bf16x3s_f32(const uint16_t *Ah_dev, const uint16_t *Al_dev, const uint16_t *Wh_dev, const uint16_t *Wl_dev,
                            const float *bias_dev, const float *residual_dev, float *C_dev, uint16_t *Ch_dev, uint16_t *Cl_dev,
                            int M, int N, int K, int epilogue, void *stream);

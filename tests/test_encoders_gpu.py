@@ -322,7 +322,13 @@ def _pair_of(x):
     return hi.view(torch.int16), lo.view(torch.int16)
 
 
-@pytest.mark.parametrize("M,C", [(5, 128), (300, 768), (33, 512), (4, 1022)])
+def _same_pair(sp, hi, lo):
+    """a SplitAct (pair layout: tile by tile, include/meerqat_hip.h) holds exactly the row-major pair (hi, lo)"""
+    h, l = sp.rowmajor()
+    return sp.shape == tuple(hi.shape) and torch.equal(h, hi) and torch.equal(l, lo)
+
+
+@pytest.mark.parametrize("M,C", [(5, 128), (300, 768), (33, 512), (4, 1024), (257, 96)])
 def test_layernorm_split_outputs_are_the_split_of_the_fp32_output(M, C):
     from viquae_amd import encoders as E
     g = torch.Generator(device="cuda").manual_seed(M + C)
@@ -332,9 +338,9 @@ def test_layernorm_split_outputs_are_the_split_of_the_fp32_output(M, C):
     y2, sp = E.layernorm_split(x, gam, bet, 1e-5)
     assert torch.equal(y, y2)
     hi, lo = _pair_of(y)
-    assert torch.equal(sp.hi, hi) and torch.equal(sp.lo, lo)
+    assert _same_pair(sp, hi, lo)
     none, sp2 = E.layernorm_split(x, gam, bet, 1e-5, want_f32=False)
-    assert none is None and torch.equal(sp2.hi, hi) and torch.equal(sp2.lo, lo)
+    assert none is None and _same_pair(sp2, hi, lo)
     assert (sp.float() - y).abs().max().item() <= 2.0 ** -16 * y.abs().max().item()
 
 
@@ -349,7 +355,7 @@ def test_attention_split_output_is_the_split_of_the_fp32_output(B, L, heads, cau
         out = E.attention(qkv, mask, B, L, heads, 0.125, causal=causal, bf16x3=x3)
         sp = E.attention(qkv, mask, B, L, heads, 0.125, causal=causal, split=True, bf16x3=x3)
         hi, lo = _pair_of(out)
-        assert torch.equal(sp.hi, hi) and torch.equal(sp.lo, lo)
+        assert _same_pair(sp, hi, lo)
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (800, 768, 768), (37, 100, 96), (300, 2304, 768), (513, 128, 3072)])
@@ -366,9 +372,13 @@ def test_split_activation_gemm_is_bit_identical_to_the_in_loop_split(M, N, K, ep
     sa = E.SplitAct(*_pair_of(a))
     out = E.gemm_nt(sa, w, b if epi else None, r if epi == 4 else None, epi, wsplit=ws)
     assert torch.equal(out, ref)
-    sp = E.gemm_nt(sa, w, b if epi else None, r if epi == 4 else None, epi, wsplit=ws, out_split=True)
-    hi, lo = _pair_of(ref)
-    assert torch.equal(sp.hi, hi) and torch.equal(sp.lo, lo)
+    if N % 32 == 0:  # the pair layout is made of 32-column tiles
+        sp = E.gemm_nt(sa, w, b if epi else None, r if epi == 4 else None, epi, wsplit=ws, out_split=True)
+        hi, lo = _pair_of(ref)
+        assert _same_pair(sp, hi, lo)
+        # ... and selecting rows of a pair (the [CLS] rows of the last layer) is selecting rows of the matrix
+        idx = torch.tensor([0, M - 1, M // 2, M // 3], device="cuda")
+        assert _same_pair(sp.rows(idx), hi[idx], lo[idx])
 
 
 def test_split_and_fp32_activation_paths_agree_end_to_end(monkeypatch):
@@ -717,6 +727,17 @@ def test_tiled_weight_split_gives_the_same_bits_as_the_row_major_split(M, N, K):
         want = E.gemm_nt(asp, w, b_, r_, epi, wsplit=rm)
         assert torch.equal(E.gemm_nt(asp, w, b_, r_, epi, wsplit=tl), want)          # split activations (x3s)
         assert torch.equal(E.gemm_nt(a, w, b_, r_, epi, wsplit=tl), E.gemm_nt(a, w, b_, r_, epi, wsplit=rm))  # fp32 activations (x3)
-        if N % 2 == 0:
+        if N % 32 == 0:
             o1, o2 = E.gemm_nt(asp, w, b_, r_, epi, wsplit=tl, out_split=True), E.gemm_nt(asp, w, b_, r_, epi, wsplit=rm, out_split=True)
-            assert torch.equal(o1.hi, o2.hi) and torch.equal(o1.lo, o2.lo)
+            assert _same_pair(o1, *o2.rowmajor())
+
+
+def test_pair_outputs_need_32_column_tiles():
+    from viquae_amd import _lib, encoders as E
+    with pytest.raises(ValueError):
+        E.SplitAct.empty(4, 1022, "cuda")
+    lib = _lib.load()
+    x = torch.zeros((4, 1022), device="cuda")
+    u = torch.zeros(4 * 1024, dtype=torch.int16, device="cuda")
+    rc = lib.mq_layernorm_split_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), None, u.data_ptr(), u.data_ptr(), 4, 1022, 1e-5, None)
+    assert rc == -4  # MQ_EUNSUPPORTED

@@ -292,6 +292,14 @@ __device__ __forceinline__ unsigned split_bits(float x) {
     const __bf16 l = (__bf16)(x - (float)h);
     return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
 }
+// PAIR LAYOUT.  The (hi, lo) arrays of a split activation [M, K] (K a multiple of 32) are stored tile by tile, exactly like the
+// weights of split_bf16_tiled_kernel: element (row, col) lives at pair_index(row, col, K) = [row / 256][col / 32][row % 256][col % 32],
+// and the arrays hold ceil(M / 256) * 256 * K elements (rows beyond M are never written, and never read: the GEMM's A stream
+// re-reads row M - 1 instead).  The A operand of one K step of a GEMM tile is then one contiguous 16-KiB block; 8 consecutive
+// columns of a row (what the producers store at once) stay 16 contiguous bytes.
+__device__ __forceinline__ size_t pair_index(size_t row, int col, int K) {
+    return ((row >> 8) * (size_t)(K >> 5) + (size_t)(col >> 5)) * (GT * XBK) + ((row & 255) << 5) + (size_t)(col & 31);
+}
 __device__ __forceinline__ void store_split_pair(float x, bool valid, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
                                                  size_t even_col_index, int lane) {
     const unsigned mine = split_bits(x);
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
         int am = t.m0 + r; if (am > M - 1) am = M - 1;
         int wn = t.n0 + r; if (wn > N - 1) wn = N - 1;
         const size_t chunk = (size_t)(((lane & 3) ^ ((r >> 2) & 3)) * 8);
-        t.a_voff = (unsigned)(((size_t)(am - t.m0) * K + chunk) * 2);
+        t.a_voff = (unsigned)(((size_t)(am - t.m0) * XBK + chunk) * 2);  // pair layout: row within the tile's 16-KiB block
         t.w_voff = wt ? (unsigned)(((size_t)r * XBK + chunk) * 2) : (unsigned)(((size_t)(wn - t.n0) * K + chunk) * 2);
         t.ah = reinterpret_cast<const char*>(Ah + (size_t)t.m0 * K);
         t.al = reinterpret_cast<const char*>(Al + (size_t)t.m0 * K);
@@ -364,8 +372,9 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
         const unsigned so = lds0 + stg * XS_STAGE;
         const size_t ko = (size_t)kb * (XBK * 2);
         const size_t kow = wt ? (size_t)kb * X_W_BYTES : ko;  // tile layout: the next K step is the next 16-KiB block
-        dma16s(t.ah + ko, t.a_voff, so);
-        dma16s(t.al + ko, t.a_voff, so + X_W_BYTES);
+        const size_t koa = (size_t)kb * X_W_BYTES;            // the activation pair is always in pair layout
+        dma16s(t.ah + koa, t.a_voff, so);
+        dma16s(t.al + koa, t.a_voff, so + X_W_BYTES);
         dma16s(t.wh + kow, t.w_voff, so + 2 * X_W_BYTES);
         dma16s(t.wl + kow, t.w_voff, so + 3 * X_W_BYTES);
     };
@@ -461,10 +470,10 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
                 v11 += rres[4 * (reg & 3) + 3];
             }
             if (SPLIT_OUT) {  // N is even (checked by the host): a pair of columns is in or out together
-                store_split_pair(v00, in00, Ch, Cl, (size_t)mr0 * N + (nb0 & ~1), lane);
-                store_split_pair(v01, in01, Ch, Cl, (size_t)mr0 * N + (nb1 & ~1), lane);
-                store_split_pair(v10, in10, Ch, Cl, (size_t)mr1 * N + (nb0 & ~1), lane);
-                store_split_pair(v11, in11, Ch, Cl, (size_t)mr1 * N + (nb1 & ~1), lane);
+                store_split_pair(v00, in00, Ch, Cl, pair_index(mr0, nb0 & ~1, N), lane);
+                store_split_pair(v01, in01, Ch, Cl, pair_index(mr0, nb1 & ~1, N), lane);
+                store_split_pair(v10, in10, Ch, Cl, pair_index(mr1, nb0 & ~1, N), lane);
+                store_split_pair(v11, in11, Ch, Cl, pair_index(mr1, nb1 & ~1, N), lane);
             } else {
                 if (in00) C[(size_t)mr0 * N + nb0] = v00;
                 if (in01) C[(size_t)mr0 * N + nb1] = v01;
@@ -513,8 +522,9 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
                 if (SPLIT_OUT) {
                     bf16x8_t hi8, lo8;
                     split8(u, v, hi8, lo8);
-                    *reinterpret_cast<uint4*>(Ch + at) = __builtin_bit_cast(uint4, hi8);
-                    *reinterpret_cast<uint4*>(Cl + at) = __builtin_bit_cast(uint4, lo8);
+                    const size_t pt = pair_index((size_t)(m0 + 64 * wr + 32 * (a >> 1) + row), n0 + 64 * wc + 32 * (a & 1) + 8 * g, N);
+                    *reinterpret_cast<uint4*>(Ch + pt) = __builtin_bit_cast(uint4, hi8);
+                    *reinterpret_cast<uint4*>(Cl + pt) = __builtin_bit_cast(uint4, lo8);
                 } else {
                     *reinterpret_cast<float4*>(C + at) = u;
                     *reinterpret_cast<float4*>(C + at + 4) = v;
@@ -677,9 +687,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // normalises v[] (this lane's elements c = lane + 64 t, t < nper) and stores
 // out (fp32 row, may be null) and/or oh, ol (the row's split pair, may be null; C even then)
+// (oh, ol: the WHOLE pair arrays -- pair layout -- and `prow` the row's index in them)
 __device__ __forceinline__ void ln_store(float (&v)[LN_MAXPER], int C, int lane, const float* __restrict__ g,
                                          const float* __restrict__ b, float eps, float* __restrict__ out,
-                                         unsigned short* __restrict__ oh = nullptr, unsigned short* __restrict__ ol = nullptr) {
+                                         unsigned short* __restrict__ oh = nullptr, unsigned short* __restrict__ ol = nullptr,
+                                         size_t prow = 0) {
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < LN_MAXPER; ++t) { const int c = lane + 64 * t; if (c < C) s += v[t]; }
@@ -694,7 +706,7 @@ __device__ __forceinline__ void ln_store(float (&v)[LN_MAXPER], int C, int lane,
         const int c = lane + 64 * t;
         const float y = (c < C) ? (v[t] - mean) * inv * g[c] + b[c] : 0.f;
         if (out && c < C) out[c] = y;
-        if (oh && 64 * t < C) store_split_pair(y, c < C, oh, ol, (size_t)(c & ~1), lane);  // wave-uniform guard
+        if (oh && 64 * t < C) store_split_pair(y, c < C, oh, ol, pair_index(prow, c & ~1, C), lane);  // wave-uniform guard
     }
 }
 
@@ -708,8 +720,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float v[LN_MAXPER];
 #pragma unroll
     for (int t = 0; t < LN_MAXPER; ++t) { const int c = lane + 64 * t; v[t] = (c < C) ? X[(size_t)row * C + c] : 0.f; }
-    ln_store(v, C, lane, g, b, eps, Y ? Y + (size_t)row * C : nullptr, Yh ? Yh + (size_t)row * C : nullptr,
-             Yl ? Yl + (size_t)row * C : nullptr);
+    ln_store(v, C, lane, g, b, eps, Y ? Y + (size_t)row * C : nullptr, Yh, Yl, (size_t)row);
 }
 
 // BertEmbeddings (meerqat/models/bert.py:153-214): (word[id] + type[tt]) + pos[t], then LayerNorm
@@ -731,7 +742,7 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const long long* __r
         const int c = lane + 64 * t;
         v[t] = (c < H) ? (word[(size_t)id * H + c] + type[(size_t)tt * H + c]) + pos[(size_t)t_pos * H + c] : 0.f;
     }
-    ln_store(v, H, lane, g, b, eps, out + (size_t)row * H, oh ? oh + (size_t)row * H : nullptr, ol ? ol + (size_t)row * H : nullptr);
+    ln_store(v, H, lane, g, b, eps, out + (size_t)row * H, oh, ol, (size_t)row);
 }
 
 // CLIPVisionEmbeddings + pre_layrnorm: token 0 = class embedding, token 1+p = patch embedding p; + position
@@ -906,7 +917,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         const size_t at = (row0 + qr) * H + h * DH;
         const float val = Ot[r * 65 + c];
         if (out && qr < L) out[at + c] = val;
-        if (out_h) store_split_pair(val, qr < L, out_h, out_l, at + (c & ~1), lane);
+        if (out_h) store_split_pair(val, qr < L, out_h, out_l, pair_index(row0 + qr, h * DH + (c & ~1), H), lane);
     }
 }
 
@@ -1179,8 +1190,9 @@ __global__ __launch_bounds__(WIDE ? 512 : 256) void attention_x3_kernel(const fl
             if (out_h) {
                 bf16x8_t hi8, lo8;
                 split8(u, v, hi8, lo8);
-                *reinterpret_cast<uint4*>(out_h + at) = __builtin_bit_cast(uint4, hi8);
-                *reinterpret_cast<uint4*>(out_l + at) = __builtin_bit_cast(uint4, lo8);
+                const size_t pt = pair_index(row0 + qr, h * DH + c0, H);
+                *reinterpret_cast<uint4*>(out_h + pt) = __builtin_bit_cast(uint4, hi8);
+                *reinterpret_cast<uint4*>(out_l + pt) = __builtin_bit_cast(uint4, lo8);
             }
         }
     }
@@ -1350,7 +1362,7 @@ int mq_gemm_nt_bf16x3s_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const
     if (epilogue != EPI_NONE && !bias_dev) return MQ_EINVAL;
     if (epilogue == EPI_BIAS_RESIDUAL && !residual_dev) return MQ_EINVAL;
     if (((uintptr_t)Ah_dev | (uintptr_t)Al_dev | (uintptr_t)Wh_dev | (uintptr_t)Wl_dev) & 15) return MQ_EINVAL;
-    if (Ch_dev && (N & 1)) return MQ_EUNSUPPORTED;
+    if (Ch_dev && (N & 31)) return MQ_EUNSUPPORTED;  // pair layout: 32-column tiles
     const int ntm = (M + GT - 1) / GT, ntn = (N + GT - 1) / GT;
     // MQ_GEMM_WGS=n: persistent launch, n workgroups walk the tiles (default: one workgroup per tile)
     const int persist = gemm_persistent_wgs();
@@ -1392,7 +1404,7 @@ int mq_layernorm_split_f32(const float* X_dev, const float* gamma_dev, const flo
     if (M == 0) return MQ_OK;
     if (!X_dev || !gamma_dev || !beta_dev || M < 0 || C <= 0) return MQ_EINVAL;
     if ((!Y_dev && !Yh_dev) || (!Yh_dev != !Yl_dev)) return MQ_EINVAL;
-    if (C > 64 * LN_MAXPER || (Yh_dev && (C & 1))) return MQ_EUNSUPPORTED;
+    if (C > 64 * LN_MAXPER || (Yh_dev && (C & 31))) return MQ_EUNSUPPORTED;
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X_dev, gamma_dev,
                        beta_dev, Y_dev, (unsigned short*)Yh_dev, (unsigned short*)Yl_dev, M, C, eps);
     ENC_HIP(hipGetLastError());
@@ -1414,7 +1426,7 @@ int mq_bert_embed_ln_split_f32(const int64_t* input_ids_dev, const int64_t* toke
     if (!input_ids_dev || !word_dev || !pos_dev || !type_dev || !gamma_dev || !beta_dev || !out_dev || B < 0 || L < 0 || H <= 0)
         return MQ_EINVAL;
     if (!out_h_dev != !out_l_dev) return MQ_EINVAL;
-    if (H > 64 * LN_MAXPER || (out_h_dev && (H & 1))) return MQ_EUNSUPPORTED;
+    if (H > 64 * LN_MAXPER || (out_h_dev && (H & 31))) return MQ_EUNSUPPORTED;
     const int M = B * L;
     hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const long long*)input_ids_dev, (const long long*)token_type_ids_dev, word_dev, pos_dev, type_dev,
@@ -1432,7 +1444,7 @@ int mq_bert_embed_ln_packed_f32(const int64_t* input_ids_dev, const int64_t* tok
         H <= 0)
         return MQ_EINVAL;
     if (!out_h_dev != !out_l_dev) return MQ_EINVAL;
-    if (H > 64 * LN_MAXPER || (out_h_dev && (H & 1))) return MQ_EUNSUPPORTED;
+    if (H > 64 * LN_MAXPER || (out_h_dev && (H & 31))) return MQ_EUNSUPPORTED;
     hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const long long*)input_ids_dev, (const long long*)token_type_ids_dev, word_dev, pos_dev, type_dev,
                        gamma_dev, beta_dev, out_dev, (unsigned short*)out_h_dev, (unsigned short*)out_l_dev, T, 1, H, eps,

@@ -86,38 +86,65 @@ def split_bf16_tiled(w):
     return TiledSplit((hi, lo))
 
 
-class SplitAct:
-    """An activation kept as its (hi, lo) bf16 pair (two int16 tensors of the activation's [rows, features] shape):
-    what the kernels producing GEMM inputs write in split_bf16 mode, and what ``mq_gemm_nt_bf16x3s_f32`` consumes."""
-    __slots__ = ("hi", "lo")
+def _tile(rm):
+    """row-major [M, K] int16 -> the pair layout ([ceil(M / 256)][K / 32][256][32], flat)"""
+    M, K = rm.shape
+    Mt = (M + 255) // 256
+    if Mt * 256 != M:
+        rm = torch.cat([rm, rm.new_zeros((Mt * 256 - M, K))])
+    return rm.view(Mt, 256, K // 32, 32).permute(0, 2, 1, 3).contiguous().view(-1)
 
-    def __init__(self, hi, lo):
-        self.hi, self.lo = hi, lo
+
+def _untile(flat, M, K):
+    """the pair layout -> row-major [M, K]"""
+    Mt = (M + 255) // 256
+    return flat.view(Mt, K // 32, 256, 32).permute(0, 2, 1, 3).reshape(Mt * 256, K)[:M]
+
+
+class SplitAct:
+    """An activation [rows, features] kept as its (hi, lo) bf16 pair: what the kernels producing GEMM inputs write in
+    split_bf16 mode, and what ``mq_gemm_nt_bf16x3s_f32`` consumes.  ``hi`` / ``lo`` are flat int16 tensors in the library's PAIR
+    LAYOUT (include/meerqat_hip.h: tile by tile, [rows / 256][features / 32][256][32], rows padded to 256);
+    :meth:`rowmajor` gives the plain [rows, features] view of either."""
+    __slots__ = ("hi", "lo", "shape")
+
+    def __init__(self, hi, lo, shape=None):
+        if shape is None:  # row-major [M, K] tensors (e.g. from split_bf16): convert
+            shape = tuple(hi.shape)
+            hi, lo = _tile(hi), _tile(lo)
+        self.hi, self.lo, self.shape = hi, lo, (int(shape[0]), int(shape[1]))
 
     @classmethod
     def empty(cls, rows, features, device):
-        return cls(torch.empty((rows, features), dtype=torch.int16, device=device),
-                   torch.empty((rows, features), dtype=torch.int16, device=device))
-
-    @property
-    def shape(self):
-        return self.hi.shape
+        if features % 32:
+            raise ValueError("split activations need a multiple of 32 features")
+        n = ((rows + 255) // 256) * 256 * features
+        return cls(torch.empty(n, dtype=torch.int16, device=device), torch.empty(n, dtype=torch.int16, device=device),
+                   (rows, features))
 
     @property
     def device(self):
         return self.hi.device
 
+    def rowmajor(self):
+        """(hi, lo) as plain [rows, features] int16 tensors"""
+        return _untile(self.hi, *self.shape), _untile(self.lo, *self.shape)
+
     def first_rows(self, B, L):
         """rows 0, L, 2L, ... (the first token of each of B sequences)"""
-        H = self.hi.shape[1]
-        return SplitAct(self.hi.view(B, L, H)[:, 0, :].contiguous(), self.lo.view(B, L, H)[:, 0, :].contiguous())
+        return self.rows(torch.arange(0, B * L, L, device=self.hi.device))
 
     def rows(self, index):
         """the rows `index` (int64 tensor)"""
-        return SplitAct(self.hi.index_select(0, index).contiguous(), self.lo.index_select(0, index).contiguous())
+        K = self.shape[1]
+        blk, r = index // 256, index % 256
+        hi = self.hi.view(-1, K // 32, 256, 32)[blk, :, r, :].reshape(-1, K)
+        lo = self.lo.view(-1, K // 32, 256, 32)[blk, :, r, :].reshape(-1, K)
+        return SplitAct(hi, lo)
 
     def float(self):
-        return self.hi.view(torch.bfloat16).float() + self.lo.view(torch.bfloat16).float()
+        hi, lo = self.rowmajor()
+        return hi.view(torch.bfloat16).float() + lo.view(torch.bfloat16).float()
 
 
 def _use_split(*feature_counts):
@@ -402,7 +429,7 @@ class BertEncoderHIP(_HipEncoder):
         H = self.hidden
         split = self.uses_split()
         if split and hs is None:
-            hs = SplitAct(*split_bf16(h))
+            hs = SplitAct(*split_bf16_tiled(h), shape=h.shape)  # the tile layout of the weights IS the pair layout
         hidden = [h.view(B, L, H)] if output_hidden_states else None
         scale = 1.0 / math.sqrt(H // self.heads)
         for i in range(self.layers):
