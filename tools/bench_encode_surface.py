@@ -159,7 +159,7 @@ def text_job(n_passages=65536, batch=2048, max_length=256, serial_batches=3, wor
     return out
 
 
-def image_job(n_files=256, n_refs=8 * 3072, batch=3072, workdir=None, ext="bmp"):
+def image_job(n_files=256, n_refs=24 * 3072, batch=3072, workdir=None, ext="bmp"):
     import datasets
     from PIL import Image
     from viquae_amd.data import loading
@@ -218,7 +218,13 @@ def image_job(n_files=256, n_refs=8 * 3072, batch=3072, workdir=None, ext="bmp")
             if flag == "1":
                 from viquae_amd.pipeline import image_pipeline_or_none
                 pipe = image_pipeline_or_none(ds, {"batch_size": batch}, decode_pool=workers, **fn)
-                got = ds.map(pipe.embed, batched=True, with_indices=True, batch_size=batch, load_from_cache_file=False)
+                stamps = [time.perf_counter()]
+
+                def stamped(b, idx, _embed=pipe.embed, _stamps=stamps):
+                    r = _embed(b, idx)
+                    _stamps.append(time.perf_counter())
+                    return r
+                got = ds.map(stamped, batched=True, with_indices=True, batch_size=batch, load_from_cache_file=False)
                 pipe.close()
                 st = pipe.stats
             else:
@@ -229,9 +235,16 @@ def image_job(n_files=256, n_refs=8 * 3072, batch=3072, workdir=None, ext="bmp")
             res[name] = {"images": len(ds), "seconds": round(t, 2), "images_per_s": round(len(ds) / t, 1), "ms_per_batch": round(t / nb * 1e3, 1)}
             if st:
                 res[name]["x_forward_only"] = round((len(ds) / t) / (batch / t_fwd), 3)
+                if len(stamps) > 6:  # the job's own pace once it runs: batches 4 .. last (a KB is hundreds of batches)
+                    steady = (len(stamps) - 1 - 4) * batch / (stamps[-1] - stamps[4])
+                    res[name]["steady_state"] = {"images_per_s": round(steady, 1), "x_forward_only": round(steady / (batch / t_fwd), 3),
+                                                 "first_batch_returned_after_s": round(stamps[1] - t0, 2),
+                                                 "after_last_batch_s": round(t0 + t - stamps[-1], 2)}
                 res[name]["pipeline"] = {"worker_prepare_ms_per_batch": round(st["prepare_s"] / nb * 1e3, 1),
                                          "of_which_decode_ms": round(st["decode_s"] / nb * 1e3, 1),
                                          "main_waited_for_worker_ms_per_batch": round(st["wait_prepared_s"] / nb * 1e3, 1),
+                                         "main_launch_ms_per_batch": round(st["launch_s"] / nb * 1e3, 1),
+                                         "main_in_step_ms_per_batch": round(st["wait_result_s"] / nb * 1e3, 1),
                                          "decode": st.get("decode")}
         os.environ["MQ_EMBED_PIPELINE"] = "1"
         out.update(res)
@@ -272,7 +285,7 @@ def main(n_passages=65536):
 if __name__ == "__main__":
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     if len(sys.argv) > 2 and sys.argv[1] == "--image":
-        print(json.dumps(image_job(ext=sys.argv[2])))
+        print(json.dumps(image_job(ext=sys.argv[2], n_refs=int(sys.argv[3]) * 3072 if len(sys.argv) > 3 else 24 * 3072)))
     else:
         n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
         print(json.dumps(main(n)))

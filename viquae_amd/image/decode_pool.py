@@ -57,7 +57,8 @@ def _worker(conn, slots):
             for idx, off in items:
                 im, path = opened.pop(idx)
                 try:
-                    a = np.asarray(im.convert("RGB"))
+                    # load_image's `.convert('RGB')` is the identity on an RGB file: skip its full-size copy there
+                    a = np.asarray(im if im.mode == "RGB" else im.convert("RGB"))
                     n = a.shape[0] * a.shape[1] * 3
                     buf[off:off + n] = a.reshape(-1)
                 except Exception as e:  # noqa: BLE001
