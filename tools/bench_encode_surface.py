@@ -140,6 +140,12 @@ def text_job(n_passages=65536, batch=2048, max_length=256, serial_batches=3, wor
                                       "main_launch_ms_per_batch": round(st.get("launch_s", 0) / nb * 1e3, 1),
                                       "main_wait_result_ms_per_batch": round(st.get("wait_result_s", 0) / nb * 1e3, 1),
                                       "main_waited_for_worker_ms_per_batch": round(st.get("wait_prepared_s", 0) / nb * 1e3, 1)}}
+    ra = st.get("returned_at") or []
+    if len(ra) > 6:  # the job's own pace once it runs (batches 4 .. last); a KB is hundreds of batches
+        steady = (len(ra) - 4) * batch / (ra[-1] - ra[3])
+        out["end_to_end"]["steady_state"] = {"passages_per_s": round(steady, 1), "x_forward_only": round(steady / (batch / t_fwd), 3),
+                                             "first_batch_returned_after_s": round(ra[0] - t0, 2),
+                                             "after_last_batch_s": round(t0 + t_all - ra[-1], 2)}
     emb = np.asarray(got.select(range(batch))["DPR_few_shot"], dtype=np.float32)
     out["end_to_end"]["first_batch_equals_forward_only_output"] = bool(np.array_equal(emb, res.cpu().numpy()))
     # the serial path (what round 2 shipped, = the reference's embed with the HIP model) on a few batches

@@ -352,6 +352,7 @@ class TextEmbedPipeline:
         if texts != batch[self.key]:
             raise RuntimeError(f"the prefetched texts of batch {i} differ from what Dataset.map decoded; set MQ_EMBED_PIPELINE=0")
         self.stats["batches"] = i + 1
+        self.stats.setdefault("returned_at", []).append(time.perf_counter())  # per batch: lets a caller separate start-up from pace
         batch[self.save_as] = out
         return batch
 
@@ -537,6 +538,7 @@ class ImageEmbedPipeline:
         if names != batch[self.image_key]:
             raise RuntimeError(f"the prefetched file names of batch {i} differ from what Dataset.map decoded; set MQ_EMBED_PIPELINE=0")
         self.stats["batches"] = i + 1
+        self.stats.setdefault("returned_at", []).append(time.perf_counter())
         if len(kept) == rows and not failed:
             batch[self.save_as] = found   # every image was readable: ONE [B, H] array (Arrow ingests it without a per-row pass)
             return batch
