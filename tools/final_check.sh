@@ -2,7 +2,7 @@
 # Round-end check on a GPU box: the driver's own sequence (GPU tests, smoke) + the default bench line.
 cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p gpurun_out
-python -m pytest tests/ -q -m gpu 2>&1 | tail -4 > gpurun_out/final_gpu_tests.log
+python -m pytest tests/ -q -m gpu 2>&1 | grep -E "passed|failed|rror" | tail -6 > gpurun_out/final_gpu_tests.log
 cat gpurun_out/final_gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -i smoke
 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
