@@ -202,3 +202,45 @@ def test_runs_kept_as_arrays_equal_the_reference_loop(mapping, many2one):
     for q in want:
         assert list(got[q]) == list(want[q]), q
         assert np.allclose(list(got[q].values()), list(want[q].values()), rtol=0, atol=1e-9), q
+
+
+@pytest.mark.parametrize("window", [0, 16, 20, 64, 4096])
+def test_search_ahead_windows_serve_every_batch_the_arrays_of_its_own_search(tmp_path, monkeypatch, window):
+    """ArrowQueryColumns.search: one search per WINDOW of consecutive rows instead of one per `Dataset.map` batch
+    (MQ_SEARCH_WINDOW; a query's exact top-k does not depend on its batch) -- same runs, fewer trips to the index."""
+    import datasets
+    from viquae_amd.ir import searcher as S
+    from viquae_amd.ir.search import Index, KnowledgeBase, register_index
+    datasets.disable_progress_bars()
+    rng = np.random.default_rng(1)
+    art = rng.standard_normal((200, 16)).astype(np.float32)
+    Q = rng.standard_normal((100, 16)).astype(np.float32)
+    qs = datasets.Dataset.from_dict({"id": [str(i) for i in range(100)], "vec_q": [q for q in Q],
+                                     "output": [{"answer": ["a"], "original_answer": "a"}] * 100})
+    (tmp_path / "qrels.json").write_text("{}")
+    calls = []
+
+    def kb_kwargs():
+        kb = KnowledgeBase(dataset=datasets.Dataset.from_dict({"vec": [v for v in art]}))
+        register_index(kb.dataset, "dense", oracle_index(art))
+        kb.indexes["dense"] = Index(key="vec_q")
+        plain = kb.search_batch
+
+        def counted(index_name, queries, k=100):
+            calls.append(len(queries))
+            return plain(index_name, queries, k=k)
+        kb.search_batch = counted
+        return dict(kb_kwargs={"kb": {}}, k=7, kbs={"kb": kb}, qrels=str(tmp_path / "qrels.json"), do_fusion=False)
+
+    monkeypatch.setenv("MQ_SEARCH_WINDOW", "0")
+    with pytest.warns(UserWarning):
+        want = S.dataset_search(qs, map_kwargs={"batch_size": 16, "load_from_cache_file": False}, **kb_kwargs()).runs
+    assert calls == [16] * 6 + [4]
+    del calls[:]
+    monkeypatch.setenv("MQ_SEARCH_WINDOW", str(window))
+    with pytest.warns(UserWarning):
+        got = S.dataset_search(qs, map_kwargs={"batch_size": 16, "load_from_cache_file": False}, **kb_kwargs()).runs
+    assert got == want and list(got["dense"]) == [str(i) for i in range(100)]
+    # windows are whole batches (20 rows under 16-row batches -> 16 = the batch itself: no window)
+    expect = {0: [16] * 6 + [4], 16: [16] * 6 + [4], 20: [16] * 6 + [4], 64: [64, 36], 4096: [100]}[window]
+    assert calls == expect
