@@ -330,7 +330,11 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 2, wc = w & 3;
-    const int ntiles = ntm * ntn;
+    // Tile b runs on XCD b & 7 (workgroups go round the XCDs) and is the (b >> 3)-th tile of that XCD: row block
+    // ((b >> 3) / ntn) * 8 + (b & 7), column tile (b >> 3) % ntn -- all column tiles of a row block on ONE XCD, so its A rows
+    // cross the fabric once.  The tile space is padded to a multiple of 8 row blocks; tiles beyond ntm are skipped (round 3:
+    // packed batches have any number of row blocks and used to fall back to b / ntn, every row block on up to ntn XCDs).
+    const int ntiles = ((ntm + 7) & ~7) * ntn;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem + 16 * w * 64));
     const int i = lane & 31, kg = lane >> 5;
     const int sww = (i >> 2) & 3;
@@ -342,17 +346,8 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
     // x 64 B each.  gridDim.x is a multiple of 8 whenever it is smaller than the tile count, so tile & 7 is this workgroup's XCD.
     struct Tile { const char *ah, *al, *wh, *wl; unsigned a_voff, w_voff; int m0, n0; };
     auto make_tile = [&](int b) __attribute__((always_inline)) {
-        int mt, nt;
-        if ((ntm & 7) == 0) {
-            const int xcd = b & 7, j = b >> 3;
-            mt = (j / ntn) * 8 + xcd;
-            nt = j % ntn;
-        } else {
-            mt = b / ntn;
-            nt = b % ntn;
-        }
-        mt = __builtin_amdgcn_readfirstlane(mt);
-        nt = __builtin_amdgcn_readfirstlane(nt);
+        const int mt = __builtin_amdgcn_readfirstlane(((b >> 3) / ntn) * 8 + (b & 7));
+        const int nt = __builtin_amdgcn_readfirstlane((b >> 3) % ntn);
         Tile t;
         t.m0 = mt * GT;
         t.n0 = nt * GT;
@@ -379,13 +374,17 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
         dma16s(t.wl + kow, t.w_voff, so + 3 * X_W_BYTES);
     };
 
-    int tile = blockIdx.x;
+    auto valid_from = [&](int t) __attribute__((always_inline)) {  // the first tile t, t + gridDim.x, ... inside the matrix
+        while (t < ntiles && ((t >> 3) / ntn) * 8 + (t & 7) >= ntm) t += (int)gridDim.x;
+        return t;
+    };
+    int tile = valid_from(blockIdx.x);
     if (tile >= ntiles) return;
     Tile cur = make_tile(tile);
     issue(cur, 0, 0);
     int stage = 0;
     for (;;) {
-    const int next = tile + (int)gridDim.x;
+    const int next = valid_from(tile + (int)gridDim.x);
     Tile nxt = cur;
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
     for (int kb = 0; kb < nk; ++kb) {
@@ -549,20 +548,9 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3_kernel(const float* __restric
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 2, wc = w & 3;
-    int mt, nt;
-    {
-        const int b = blockIdx.x;
-        if ((ntm & 7) == 0) {
-            const int xcd = b & 7, j = b >> 3;
-            mt = (j / ntn) * 8 + xcd;
-            nt = j % ntn;
-        } else {
-            mt = b / ntn;
-            nt = b % ntn;
-        }
-    }
-    mt = __builtin_amdgcn_readfirstlane(mt);
-    nt = __builtin_amdgcn_readfirstlane(nt);
+    const int mt = __builtin_amdgcn_readfirstlane((((int)blockIdx.x >> 3) / ntn) * 8 + ((int)blockIdx.x & 7));  // see gemm_nt_x3s_kernel
+    const int nt = __builtin_amdgcn_readfirstlane(((int)blockIdx.x >> 3) % ntn);
+    if (mt >= ntm) return;  // padding of the tile space to 8 row blocks
     const int m0 = mt * GT, n0 = nt * GT;
 
     // DMA: wave w moves rows [16w, 16w+16) of A (two instructions of 8 rows x 128 B) and of Wh, Wl (one
@@ -1330,7 +1318,7 @@ int mq_gemm_nt_bf16x3_f32(const float* A_dev, const uint16_t* Wh_dev, const uint
     if (epilogue == EPI_BIAS_RESIDUAL && !residual_dev) return MQ_EINVAL;
     if (((uintptr_t)A_dev | (uintptr_t)Wh_dev | (uintptr_t)Wl_dev) & 15) return MQ_EINVAL;
     const int ntm = (M + GT - 1) / GT, ntn = (N + GT - 1) / GT;
-    const dim3 grid((unsigned)(ntm * ntn)), block(1024);
+    const dim3 grid((unsigned)(((ntm + 7) & ~7) * ntn)), block(1024);  // tile space padded to 8 row blocks (XCD placement)
     hipStream_t st = (hipStream_t)stream;
 #define MQ_LAUNCH(E)                                                                                                  \
     case E:                                                                                                           \
@@ -1366,7 +1354,7 @@ int mq_gemm_nt_bf16x3s_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const
     const int ntm = (M + GT - 1) / GT, ntn = (N + GT - 1) / GT;
     // MQ_GEMM_WGS=n: persistent launch, n workgroups walk the tiles (default: one workgroup per tile)
     const int persist = gemm_persistent_wgs();
-    const int ntiles = ntm * ntn;
+    const int ntiles = ((ntm + 7) & ~7) * ntn;  // tile space padded to 8 row blocks (XCD placement, see the kernel)
     const dim3 grid((unsigned)(persist > 0 && ntiles > persist ? persist : ntiles)), block(1024);
     hipStream_t st = (hipStream_t)stream;
 #define MQ_LAUNCH2(E, S)                                                                                              \
