@@ -128,7 +128,18 @@ def host_cpus():
         physical = len(cores) or None
     except OSError:
         pass
-    return {"physical_cores": physical or logical, "hardware_threads": logical, "usable_threads": usable}
+    # the container's CPU bandwidth (cgroup `cpu.max` = quota period): the GPU boxes of this pool show 256 hardware threads
+    # and grant 16 CPUs' worth of time -- every CPU leg below is a number measured UNDER that quota, whatever its thread count
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+        if q != "max":
+            quota = round(int(q) / int(period), 2)
+    except (OSError, ValueError):
+        pass
+    return {"physical_cores": physical or logical, "hardware_threads": logical, "usable_threads": usable,
+            "cgroup_cpu_quota": quota}
 
 
 def cpu_baseline(idx, Q, seconds):
