@@ -612,6 +612,13 @@ def main():
                 c = bench_encoders.clip_throughput(B=3072, steps=2)
                 tt = bench_encoders.clip_text_throughput(B=2048, L=77, steps=2)
                 try:
+                    ec = bench_encoders.eca_throughput()
+                    eca = {"workload": "ECAEncoder as shipped (experiments/mm/eca/config.yaml: bert-base, n_faces 0, one clip-RN50 feature of "
+                                       "1024 dims; KB config: batch 2048, text padded to 256, ~130 real tokens) -- text + image token",
+                           "passages_per_s": round(ec["passages_per_s"], 1), "ms_per_batch": round(ec["ms_per_batch"], 2)}
+                except Exception as e:
+                    eca = {"error": repr(e)}
+                try:
                     import bench_image
                     ip = bench_image.main()
                 except Exception as e:
@@ -686,6 +693,7 @@ def main():
                              "algorithmic_tflops": round(c["tflops"], 2), "x_f32_mfma_peak": round(c["tflops"] / PEAK_F32_MFMA_TFLOPS, 3),
                              "executed_bf16_mfma_frac": round(3 * c["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)},
                     "image_preprocess": dict(ip, workload="Pillow-exact bicubic resize + crop + normalise of 3072 decoded RGB images on the device (csrc/image.hip)"),
+                    "eca_multimodal_encoder": eca,
                     "titles_encoded_per_s": round(tt["titles_per_s"], 1),
                     "clip_text": {"workload": "CLIP ViT-B/32 text tower, 2048 x 77 synthetic tokens per batch (causal)",
                                   "ms_per_batch": round(tt["ms_per_batch"], 2), "algorithmic_tflops": round(tt["tflops"], 2)},

@@ -504,15 +504,21 @@ def test_eca_with_the_shipped_max_length_text_plus_faces_plus_image():
                 face_inputs={"face": _cuda(face), "bbox": _cuda(bbox), "attention_mask": _cuda(fmask)},
                 image_inputs={"clip-RN50": {"input": _cuda(img), "attention_mask": torch.ones((B, 1), dtype=torch.long, device="cuda")}})
     calls = []
-    orig = E._pooled_by_groups
-    E._pooled_by_groups = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    orig, orig_packed = E._pooled_by_groups, model.bert_model.packed_layers
+    E._pooled_by_groups = lambda *a, **k: (calls.append("groups"), orig(*a, **k))[1]
+    model.bert_model.packed_layers = lambda *a, **k: (calls.append("packed"), orig_packed(*a, **k))[1]
     try:
-        fast = model(**args)["pooler_output"].cpu().numpy()
+        fast = model(**args)["pooler_output"].cpu().numpy()           # the packed forward over the compacted joint sequences
+        os.environ["MQ_ENC_PACKED"] = "0"
+        groups = model(**args)["pooler_output"].cpu().numpy()         # length groups (the round-2 path)
     finally:
         E._pooled_by_groups = orig
-    assert calls, "the compaction path did not run"
+        del model.bert_model.packed_layers
+        os.environ.pop("MQ_ENC_PACKED", None)
+    assert calls == ["packed", "groups"], "the compaction paths did not run"
     dense = model(output_hidden_states=True, **args)["pooler_output"].cpu().numpy()
     assert np.abs(fast - want2).max() < TOL and np.abs(fast - dense).max() < 1e-5
+    assert np.abs(groups - want2).max() < TOL and np.abs(groups - dense).max() < 1e-5
 
 
 def _padded_batch(rng, cfg, B, L, lo=3):

@@ -142,6 +142,32 @@ def clip_throughput(B=3072, steps=2, device="cuda"):
     return {"images_per_s": B / t, "ms_per_batch": t * 1e3, "batch": B, "tflops": 8.82e9 * B / t / 1e12}
 
 
+def eca_throughput(B=2048, L=256, mean_len=130, std_len=30, steps=2, device="cuda"):
+    """The reference's multimodal KB encoder as shipped (experiments/mm/eca/config.yaml:82-87: bert-base, n_faces 0, one
+    clip-RN50 image feature of 1024 dims; experiments/ir/viquae/eca/embedding/kb_config.json: batch 2048, max_length 256):
+    text padded to 256 tokens (~130 real ones) + one image token, `ECAEncoder` (meerqat/models/mm.py:557-754)."""
+    from viquae_amd.encoders import ECAEncoder
+    cfg = dict(BERT_BASE, n_images=1, n_faces=0, face_kwargs=dict(face_dim=512, bbox_dim=7),
+               image_kwargs={"clip-RN50": {"input_dim": 1024}}, face_and_image_are_exclusive=False, no_text=False, gating=False)
+    state = {k.replace("ctx_encoder.", ""): v for k, v in random_bert_state(BERT_BASE, 5).items()}
+    g0 = torch.Generator().manual_seed(6)
+    state["image_embeddings.clip-RN50.linear.weight"] = torch.randn(768, 1024, generator=g0) * 0.02
+    state["image_embeddings.clip-RN50.linear.bias"] = torch.randn(768, generator=g0) * 0.02
+    model = ECAEncoder.from_state_dict(cfg, {k: v.numpy() for k, v in state.items()}).to(device).eval()
+    rng = np.random.default_rng(7)
+    lens = np.clip(rng.normal(mean_len, std_len, B).astype(int), 8, L)
+    mask = torch.from_numpy((np.arange(L)[None] < lens[:, None]).astype(np.int64)).to(device)
+    g = torch.Generator(device=device).manual_seed(8)
+    ids = torch.randint(1000, 30000, (B, L), generator=g, device=device) * mask
+    img = torch.randn((B, 1, 1024), generator=g, device=device)
+    args = dict(text_inputs={"input_ids": ids, "attention_mask": mask},
+                face_inputs={"face": torch.zeros((B, 1, 0, 512), device=device), "bbox": torch.zeros((B, 1, 0, 7), device=device),
+                             "attention_mask": torch.zeros((B, 1, 0), dtype=torch.int64, device=device)},
+                image_inputs={"clip-RN50": {"input": img, "attention_mask": torch.ones((B, 1), dtype=torch.int64, device=device)}})
+    t = time_it(lambda: model(**args)["pooler_output"], steps)
+    return {"passages_per_s": B / t, "ms_per_batch": t * 1e3, "batch": B, "padded_to": L, "mean_tokens": float(lens.mean()) + 1}
+
+
 def clip_text_throughput(B=2048, L=77, steps=2, device="cuda"):
     """experiments/ir/viquae/clip/config.json: batches of 2048 titles, at most 77 tokens (worst case: all 77 long)."""
     cfg = CLIP_TEXT_VITB32

@@ -395,6 +395,17 @@ class BertEncoderHIP(_HipEncoder):
                 self.w_pos.data_ptr(), self.w_type.data_ptr(), self.emb_g.data_ptr(), self.emb_b.data_ptr(), h.data_ptr(),
                 hs.hi.data_ptr() if split else None, hs.lo.data_ptr() if split else None, T, H, self.eps, _stream(h)),
                 "mq_bert_embed_ln_packed_f32")
+        return self.packed_layers(h, hs, cu, classes, cls_rows)
+
+    @torch.no_grad()
+    def packed_layers(self, h, hs, cu, classes, cls_rows):
+        """The encoder stack over PACKED embeddings h [T, H] (hs = their split pair in split mode, or None to make it here):
+        sequence b = rows [cu[b], cu[b + 1]), attention per sequence (``classes`` of :func:`pack_plan_from_lengths`) -> the
+        rows ``cls_rows`` of the last layer's output, [B, H]."""
+        H = self.hidden
+        split = self.uses_split()
+        if split and hs is None:
+            hs = SplitAct(*split_bf16_tiled(h), shape=h.shape)
         scale = 1.0 / math.sqrt(H // self.heads)
         for i in range(self.layers):
             w = lambda n: getattr(self, f"l{i}_{n}")  # noqa: E731
@@ -1087,6 +1098,14 @@ class ECAEncoder(_MMEmbeddings):
             # summation order (~1e-6), not bit for bit.
             order = torch.argsort((full_mask == 0).to(torch.int8), dim=1, stable=True)
             cmask = torch.gather(full_mask, 1, order)
+            pack = _pack_plan(cmask)
+            if pack is not None:
+                # the PACKED forward over the joint sequences (round 3): only the attended tokens of every example go through
+                # the stack, attention runs per example over exactly its own keys (12.5 k -> see bench.py eca_multimodal_encoder)
+                keep, _, cu, classes, cls_rows = pack
+                flat = (order + torch.arange(B, device=dev)[:, None] * Lt).reshape(-1).index_select(0, keep)
+                pooled = bert.packed_layers(h.view(B * Lt, H).index_select(0, flat), None, cu, classes, cls_rows)
+                return ModelOutput(pooler_output=pooled, last_hidden_state=pooled[:, None, :], hidden_states=None, attentions=None)
             plan = _length_buckets(cmask)
             if plan is not None:
                 hc = torch.gather(h, 1, order[:, :, None].expand(-1, -1, H))
