@@ -1148,8 +1148,11 @@ class IntermediateLinearFusion(_MMEmbeddings):
     def forward(self, text_inputs=None, face_inputs=None, image_inputs=None, **unused):
         mmc = self.mm
         lib = _lib.load()
-        plan = _length_buckets(text_inputs.get("attention_mask"))
-        if plan is not None:
+        pack = _pack_plan(text_inputs.get("attention_mask"))
+        plan = None if pack is not None else _length_buckets(text_inputs.get("attention_mask"))
+        if pack is not None:     # the DPR encoders' packed forward: real tokens only, bit-identical [CLS] rows
+            pooled = self.bert_model.forward_packed(text_inputs["input_ids"], text_inputs.get("token_type_ids"), pack)
+        elif plan is not None:
             pooled = _pooled_by_groups(self.bert_model, plan, text_inputs["input_ids"], text_inputs["attention_mask"],
                                        text_inputs.get("token_type_ids"))
         else:
