@@ -601,16 +601,21 @@ def main():
         if world == 1 and not args.no_encoders:
             # secondary BASELINE figures (configs[2], configs[3]); the headline `value` stays queries/s
             try:
+                # the shard itself stays (the CPU legs at the end read its rows back); its search workspace and whatever the
+                # caching allocator kept from the headline steps go back to the device first
+                local._ws = None
+                del ws
+                torch.cuda.empty_cache()
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_encoders
-                d = bench_encoders.dpr_throughput(B=2048, L=100, steps=2)
+                d = bench_encoders.dpr_throughput(B=2048, L=100, steps=5)   # (2 steps right after the headline: 104-122 ms; 5: steady)
                 try:
                     dp = bench_encoders.dpr_padded_throughput()
                     dq = bench_encoders.dpr_padded_throughput(mean_len=16, std_len=5, steps=5)
                 except Exception as e:
                     dp = dq = {"error": repr(e)}
-                c = bench_encoders.clip_throughput(B=3072, steps=2)
-                tt = bench_encoders.clip_text_throughput(B=2048, L=77, steps=2)
+                c = bench_encoders.clip_throughput(B=3072, steps=5)
+                tt = bench_encoders.clip_text_throughput(B=2048, L=77, steps=5)
                 try:
                     ec = bench_encoders.eca_throughput()
                     eca = {"workload": "ECAEncoder as shipped (experiments/mm/eca/config.yaml: bert-base, n_faces 0, one clip-RN50 feature of "

@@ -78,7 +78,7 @@ def random_clip_text_state(cfg, seed):
     return st
 
 
-def time_it(fn, steps, warmup=1):
+def time_it(fn, steps, warmup=2):
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
