@@ -1240,15 +1240,19 @@ __global__ __launch_bounds__(256) void clip_eos_pool_ln_kernel(const float* __re
     ln_store(v, H, lane, g, b, eps, out + (size_t)seq * H);
 }
 
-// Workgroups of a split-bf16 GEMM launch.  Default 0 = one workgroup per output tile.  MQ_GEMM_WGS=n (a multiple of 8, e.g.
-// the CU count) makes the launch persistent: n workgroups walk the tiles and request the next tile's first K stage during the
-// current tile's last step.  Measured on every encoder shape (tools/bench_gemm_shapes.py, round 2): 976 vs 975, 740 vs 731,
-// 949 vs 941, 1093 vs 1092 executed TFLOP/s -- the dispatcher already starts the next workgroup as fast as the overlap does,
-// so the plain launch stays the default (it also leaves CUs to the side streams of the grouped forward).
+// Workgroups of a split-bf16 GEMM launch: PERSISTENT by default -- one workgroup per CU (a multiple of 8) walks the tiles and
+// requests the next tile's first K stage during the current tile's last step; MQ_GEMM_WGS=n overrides the count, 0 = one
+// workgroup per output tile.  Round 2 measured the two launches equal (976 vs 975, 740 vs 731, 949 vs 941, 1093 vs 1092 executed
+// TFLOP/s) and kept the plain one; with the operands stored tile by tile (round 3) the persistent launch is ahead on every
+// shape (tools/bench_gemm_shapes.py: QKV 1.982 -> 1.972 ms, out-proj 0.725 -> 0.699, FFN1 2.616 -> 2.586, FFN2 2.357 -> 2.324) and
+// on whole forwards (DPR 2048 x 100 104.0 -> 102.4 ms, pad-to-256 139.2 -> 137.8 ms).
 int gemm_persistent_wgs() {
     static const int wgs = [] {
         const char* e = getenv("MQ_GEMM_WGS");
-        return e ? atoi(e) / 8 * 8 : 0;
+        if (e) return atoi(e) / 8 * 8;
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n / 8 * 8;
     }();
     return wgs;
 }
