@@ -40,7 +40,8 @@ extern "C" {
 /* `--k` is a user option of the reference (meerqat/ir/search.py:12,135; default 100) and faiss IndexFlat takes any k.  One
  * fused scan keeps up to MQ_KNN_FUSED_K neighbours; a larger k (up to MQ_KNN_MAX_K, FAISS-GPU's own limit) is served by
  * ceil(k / 128) scans, round r + 1 admitting only candidates strictly below the last (score, id) key of round r -- the
- * rounds' results concatenate into the exact sorted top-k.  Such calls always take the exact fp32 scan. */
+ * rounds' results concatenate into the exact sorted top-k.  The rounds are exact fp32 scans; mq_knn_search_screened_f32 serves
+ * k <= 224 through its screen (same results) and takes the rounds beyond. */
 #define MQ_KNN_FUSED_K 128
 #define MQ_KNN_MAX_K 2048
 
@@ -146,8 +147,8 @@ int mq_knn_search_f32_ev(const float *packed_dev, const float *sqnorm_dev, int64
  * Query tiles whose bounded candidate buffers overflow are recomputed by the exact scan inside the
  * same call (from the panel copy, or from the row-major copy when packed_dev is NULL: same MFMA sequence, same bits, a
  * slower operand path); FAISS's small-batch L2 form (MQ_KNN_L2_DIRECT_BELOW) likewise reads whichever copy exists.
- * Workspace: mq_knn_workspace_bytes (covers both paths).  k > MQ_KNN_FUSED_K: the call is served by the exact scan
- * in ceil(k / 128) rounds (the bounded screening buffers are sized for the reference's k = 100).
+ * Workspace: mq_knn_workspace_bytes (covers both paths).  k > 224: the call is served by the exact scan in
+ * ceil(k / 128) rounds (the bounded screening buffers are sized for the reference's k = 100; up to 224 they still hold).
  * ------------------------------------------------------------------------------------------- */
 size_t mq_knn_screen_bytes(int64_t n_rows, int d, int metric);
 int mq_knn_screen_prepare(const float *packed_dev, const float *sqnorm_dev, int64_t capacity_rows, int d, int metric,

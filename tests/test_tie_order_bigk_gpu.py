@@ -100,16 +100,39 @@ def test_shard_merges_follow_the_tie_order(tie, metric):
 
 @pytest.mark.parametrize("metric", [0, 1])
 @pytest.mark.parametrize("screen", [False, True])
-@pytest.mark.parametrize("k", [129, 256, 1000])
+@pytest.mark.parametrize("k", [129, 200, 224, 225, 256, 1000])
 @pytest.mark.parametrize("kind", ["normal", "ties"])
 def test_k_above_128(kind, k, screen, metric):
     """ceil(k / 128) scans with key ceilings == the oracle's single pass, for both index kinds (a screened index without a
     panel copy scans its row-major rows), both metrics, free-form and tie-heavy data (equal-score runs that straddle the
-    round boundaries), more than one query tile."""
+    round boundaries), more than one query tile.  A screened index serves k <= 224 through its screen (a 256-key final
+    sort; the tie-heavy data overflows its pools and exercises the fallback rounds under the screen), the rounds beyond."""
     from oracle import knn as ok
     n, d, nq = (5000, 96, 300) if kind == "normal" else (3000, 16, 40)
     X, Q = _mk(n, d, nq, 7 + k, kind)
     _same(_search(X, Q, k, metric, "id_asc", screen), ok.knn(X, Q, k, metric=metric), f"k={k}")
+
+
+@pytest.mark.parametrize("tie", ["id_asc", "id_desc"])
+def test_k_129_to_224_through_the_screen_on_a_large_shard(tie):
+    """Enough rows for several slabs and chunks per slab, so that the screen's own machinery (stripe bound, pool compactions,
+    candidate selection, 256-key final sort) decides -- against the exact fp32 scan of the same index."""
+    import torch
+    from viquae_amd.index import MI355XFlatIndex
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = torch.randn((200_000, 128), generator=g, device="cuda")
+    X[1000:1040] = X[0:40]            # duplicates: equal scores across the cut
+    Q = torch.randn((700, 128), generator=g, device="cuda")
+    res = {}
+    for screen in (True, False):
+        idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=screen, tie_order=tie)
+        idx.add(X)
+        res[screen] = [tuple(t.cpu().numpy() for t in idx.search_device(Q, k)) for k in (129, 200, 224)]
+        if screen:
+            st = idx.screen_stats(Q.shape[0], 224)
+            assert st[0] == 0, "the 224-neighbour search was meant to stay inside the screen (no tile recomputed)"
+    for a, b in zip(res[True], res[False]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
 def test_k_above_128_other_shapes():

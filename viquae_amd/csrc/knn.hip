@@ -52,6 +52,11 @@ constexpr int LDS_QS = LDS_XS + NSTAGE * 4 * BK * 64 * 4;   // [NSTAGE][4][16][6
 constexpr int LDS_CNT = LDS_QS + NSTAGE * 4 * BK * 64 * 4;  // gcnt[256] int, tau[256] f32
 constexpr int LDS_TOTAL = LDS_CNT + 2 * TQ * 4;
 constexpr int KF = MQ_KNN_FUSED_K;  // neighbours one fused scan keeps; a larger k runs ceil(k / KF) rounds (see knn_search_impl)
+// neighbours the screened search serves itself (final_select sorts up to 256 exact keys).  Measured at 1.5M x 768, 4096 queries:
+// k = 129 / 200 / 224 / 240: 8.8 / 9.8 / 10.2 / 11.1 ms; from k = 248 the stripe bound (256 slots per query) no longer yields a
+// threshold, the slab pools overflow and every tile falls back to the exact rounds (160-176 ms against 146 for the rounds alone).
+constexpr int SCREEN_MAX_K = 224;
+constexpr int FINAL_SORT_KEYS = 256;
 static_assert(KF + TN <= POOL, "a compacted pool must take every row of one more chunk");
 static_assert(KF == 128, "sort128_desc / the merge kernels are written for 128-entry lists");
 
@@ -313,6 +318,41 @@ __device__ __forceinline__ void sort128_desc(u64 (&v)[2], int lane) {
             } else {
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
+                    const bool up = ((r * 64 + lane) & kk) != 0;
+                    const bool lower = (lane & j) == 0;
+                    const unsigned lo = __shfl_xor((unsigned)v[r], j);
+                    const unsigned hi = __shfl_xor((unsigned)(v[r] >> 32), j);
+                    const u64 o = ((u64)hi << 32) | lo;
+                    const bool take_max = (lower != up);
+                    v[r] = take_max ? (v[r] > o ? v[r] : o) : (v[r] < o ? v[r] : o);
+                }
+            }
+        }
+    }
+}
+
+// the same network for R x 64 keys (R a power of two): strides below 64 exchange lanes, strides of 64 and more exchange
+// registers.  R = 2 is sort128_desc (kept as it is: it sits in the scans' compaction path).
+template <int R>
+__device__ __forceinline__ void sort_desc_n(u64 (&v)[R], int lane) {
+#pragma unroll
+    for (int kk = 2; kk <= 64 * R; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j >= 1; j >>= 1) {
+            if (j >= 64) {
+                const int jr = j >> 6;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (r & jr) continue;
+                    const bool up = ((r * 64) & kk) != 0;  // (lane < 64 never reaches bit kk >= 128)
+                    const u64 a = v[r], b = v[r | jr];
+                    const u64 mx = a > b ? a : b, mn = a > b ? b : a;
+                    v[r] = up ? mn : mx;
+                    v[r | jr] = up ? mx : mn;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
                     const bool up = ((r * 64 + lane) & kk) != 0;
                     const bool lower = (lane & j) == 0;
                     const unsigned lo = __shfl_xor((unsigned)v[r], j);
@@ -1320,9 +1360,10 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         MQ_HIP(hipGetLastError());
         q_rm = qtmp;
     }
-    if (k > KF) {
-        // More than 128 neighbours: the bounded screening buffers are sized for the reference's k = 100; the exact scan
-        // serves the call in ceil(k / 128) rounds (from the panel copy, or from the row-major copy of an index without one).
+    if (k > SCREEN_MAX_K) {
+        // More than SCREEN_MAX_K neighbours: the bounded screening buffers are sized for the reference's k = 100 (the pools hold
+        // 512 survivors per slab, the stripe bound works on 256 slots: k <= 224 still goes through the screen, round 3); the exact
+        // scan serves the call in ceil(k / 128) rounds (from the panel copy, or from the row-major copy of an index without one).
         MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
         hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((nq + PANEL - 1) / PANEL)), dim3(256), 0, st, q_rm, (int64_t)nq, d,
                            g.dpad, (int64_t)0, 0, Qp, qn, (const int*)nullptr);
@@ -1374,8 +1415,12 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq, RMAX / 64), dim3(256), 0, st, rowmajor_dev, q_rm, d, cand, ccount, ckeys,
                        l2 ? (const float*)qn : (const float*)nullptr, sqnorm_dev, flip);
     MQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(final_select_kernel, dim3((unsigned)nq), dim3(64), 0, st, ckeys, ccount, ovf, k, (long long)id_offset, D_dev,
-                       (long long*)I_dev, l2, flip);
+    if (k <= KF)
+        hipLaunchKernelGGL(final_select_kernel<128>, dim3((unsigned)nq), dim3(64), 0, st, ckeys, ccount, ovf, k, (long long)id_offset,
+                           D_dev, (long long*)I_dev, l2, flip);
+    else
+        hipLaunchKernelGGL(final_select_kernel<FINAL_SORT_KEYS>, dim3((unsigned)nq), dim3(64), 0, st, ckeys, ccount, ovf, k,
+                           (long long)id_offset, D_dev, (long long*)I_dev, l2, flip);
     MQ_HIP(hipGetLastError());
     // 5. query tiles whose bounded buffers overflowed are recomputed by the exact scan (no-op otherwise:
     //    every workgroup of an unflagged tile returns at once)

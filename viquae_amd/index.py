@@ -37,7 +37,7 @@ from . import _lib
 
 METRIC_INNER_PRODUCT = 0  # faiss.METRIC_INNER_PRODUCT
 METRIC_L2 = 1  # faiss.METRIC_L2
-MAX_K = 2048  # MQ_KNN_MAX_K; one fused scan keeps 128, a larger k runs ceil(k / 128) exact scans (include/meerqat_hip.h)
+MAX_K = 2048  # MQ_KNN_MAX_K; the screened search serves k <= 224, a larger k runs ceil(k / 128) exact scans (include/meerqat_hip.h)
 FLAG_L2NORM_QUERIES, FLAG_TIE_ID_DESC, MERGE_TIE_ID_DESC = 1, 2, 0x100  # MQ_KNN_FLAG_*, MQ_MERGE_TIE_ID_DESC
 TIE_ORDERS = ("id_asc", "id_desc")
 _MAGIC = b"MQFLAT01"
