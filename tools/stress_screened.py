@@ -17,7 +17,7 @@ def case(seed):
     n = pick([5000, 40000, 70000, 200000, 333333, 600000])
     d = pick([32, 64, 100, 256, 512, 768])
     nq = pick([1, 100, 256, 300, 1024, 2500, 4096, 5000])
-    k = pick([1, 10, 100, 128])
+    k = pick([1, 10, 100, 128, 129, 160, 200, 224])
     regime = pick(["normal", "clustered", "dups", "scaled", "lowrank", "sorted", "l2norm"])
     metric = pick([0, 0, 1])
     X = torch.randn((n, d), generator=g, device="cuda")
