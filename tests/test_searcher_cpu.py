@@ -38,13 +38,15 @@ def check(s, want):
     assert {q: sorted(v) for q, v in s.qnonrels.items()} == {q: sorted(v) for q, v in want["qnonrels"].items()}
 
 
-def oracle_index(art):
+def oracle_index(art, metric=0):
     from datasets.search import BaseIndex, BatchedSearchResults
     from oracle import knn as ok
 
     class OracleIndex(BaseIndex):
+        metric_type = metric
+
         def search_batch(self, queries, k=10, **kw):
-            D, I = ok.knn(art, queries, k, metric=0)
+            D, I = ok.knn(art, queries, k, metric=metric)
             return BatchedSearchResults(D, I.astype(int))
     return OracleIndex()
 
@@ -243,4 +245,48 @@ def test_search_ahead_windows_serve_every_batch_the_arrays_of_its_own_search(tmp
     assert got == want and list(got["dense"]) == [str(i) for i in range(100)]
     # windows are whole batches (20 rows under 16-row batches -> 16 = the batch itself: no window)
     expect = {0: [16] * 6 + [4], 16: [16] * 6 + [4], 20: [16] * 6 + [4], 64: [64, 36], 4096: [100]}[window]
+    assert calls == expect
+
+
+@pytest.mark.parametrize("batch_size,expect", [(24, [110, 14]), (16, [16] * 6 + [14]), (32, [110, 14])])
+def test_search_ahead_keeps_the_l2_form_of_every_batch(tmp_path, monkeypatch, batch_size, expect):
+    """under the L2 metric the arithmetic of a score depends on the SIZE of the call (fewer than 20 queries: FAISS's
+    direct sums; 20 or more: the BLAS form), so a batch of fewer than 20 rows must not be served from a window's arrays, and a
+    window is only searched ahead when the batch and the window both have at least 20 rows.  110 questions: the last batch has
+    14 rows (24- and 32-row batches) -- runs bit-equal to MQ_SEARCH_WINDOW=0, with the short batch searched by its own call."""
+    import datasets
+    from viquae_amd.ir import searcher as S
+    from viquae_amd.ir.search import Index, KnowledgeBase, register_index
+    datasets.disable_progress_bars()
+    rng = np.random.default_rng(3)
+    art = rng.standard_normal((300, 24)).astype(np.float32)
+    Q = rng.standard_normal((110, 24)).astype(np.float32)
+    qs = datasets.Dataset.from_dict({"id": [str(i) for i in range(110)], "vec_q": [q for q in Q],
+                                     "output": [{"answer": ["a"], "original_answer": "a"}] * 110})
+    (tmp_path / "qrels.json").write_text("{}")
+    calls = []
+
+    def kb_kwargs():
+        kb = KnowledgeBase(dataset=datasets.Dataset.from_dict({"vec": [v for v in art]}))
+        register_index(kb.dataset, "dense", oracle_index(art, metric=1))
+        kb.indexes["dense"] = Index(key="vec_q")
+        plain = kb.search_batch
+
+        def counted(index_name, queries, k=100):
+            calls.append(len(queries))
+            return plain(index_name, queries, k=k)
+        kb.search_batch = counted
+        return dict(kb_kwargs={"kb": {}}, k=9, kbs={"kb": kb}, qrels=str(tmp_path / "qrels.json"), do_fusion=False)
+
+    from oracle import knn as ok
+    tail = Q[110 - 14:]
+    assert not np.array_equal(ok.knn(art, tail, 9, metric=1)[0], ok.knn(art, Q, 9, metric=1)[0][110 - 14:])  # the forms differ
+    monkeypatch.setenv("MQ_SEARCH_WINDOW", "0")
+    with pytest.warns(UserWarning):
+        want = S.dataset_search(qs, map_kwargs={"batch_size": batch_size, "load_from_cache_file": False}, **kb_kwargs()).runs
+    del calls[:]
+    monkeypatch.setenv("MQ_SEARCH_WINDOW", "4096")
+    with pytest.warns(UserWarning):
+        got = S.dataset_search(qs, map_kwargs={"batch_size": batch_size, "load_from_cache_file": False}, **kb_kwargs()).runs
+    assert got == want
     assert calls == expect

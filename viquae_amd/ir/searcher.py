@@ -28,6 +28,7 @@ from pathlib import Path
 
 import numpy as np
 
+from ..index import L2_DIRECT_BELOW
 from .search import KnowledgeBase
 
 
@@ -278,8 +279,13 @@ class ArrowQueryColumns:
     # one search of 4096 queries costs 2.05 us per query on the device against 3.4 us in batches of 256 (the KB is streamed once
     # per search either way) and one trip through the index wrappers instead of sixteen.  When the query vectors come from the
     # Arrow table anyway, the searcher therefore searches a WINDOW of consecutive rows at the first batch that needs them and
-    # serves the following batches from the result arrays.  A query's exact top-k does not depend on what else is in its
-    # batch, so every batch gets exactly the arrays it would have got.  MQ_SEARCH_WINDOW=<rows> (0 = off).  (A helper thread
+    # serves the following batches from the result arrays.  With the inner product a query's exact top-k does not depend on
+    # what else is in its batch, so every batch gets exactly the arrays it would have got.  With the L2 metric it does depend
+    # on the SIZE of the call: FAISS (and this library: MQ_KNN_L2_DIRECT_BELOW) computes a batch of fewer than 20 queries
+    # with the direct sums of (q - x)^2 and a larger one with the BLAS form ||q||^2 + ||x||^2 - 2 q.x -- other score bits,
+    # possibly another order of near-ties.  An L2 index is therefore only searched ahead when the batch AND the window call
+    # both have at least 20 rows (both then use the BLAS form, as the per-batch calls would); a short batch -- a small
+    # batch_size, or the last few rows of the dataset -- is searched by its own call.  MQ_SEARCH_WINDOW=<rows> (0 = off).  (A helper thread
     # searching window j + 1 while `map` hands out window j measured nothing -- 307 k against 312 k queries/s: the map loop holds
     # the GIL, the helper waits a switch interval for each of its Python steps -- and was dropped.)
 
@@ -291,15 +297,29 @@ class ArrowQueryColumns:
         width = self._width.setdefault(slot, self.window // n * n if n else 0)  # whole batches: windows start where batches do
         if not n or int(indices[-1]) - first + 1 != n or width <= n:
             return kb.search_batch(index_name, self.batch(key, indices), k=k)
+        size_matters = self._call_size_matters(kb, index_name)
+        if size_matters and n < L2_DIRECT_BELOW:
+            return kb.search_batch(index_name, self.batch(key, indices), k=k)
         hit = self._ahead.get(slot)
         if hit is None or not (hit[0] <= first and first + n <= hit[1]):
             stop = min(first + width, len(self.columns[key]))
+            if size_matters and stop - first < L2_DIRECT_BELOW:  # the tail of the column: a call of its own form
+                return kb.search_batch(index_name, self.batch(key, indices), k=k)
             scores, ids = kb.search_batch(index_name, self.batch(key, range(first, stop)), k=k)
             if not (isinstance(scores, np.ndarray) and isinstance(ids, np.ndarray)):
                 return scores[:n], ids[:n]  # an index that answers with lists: no slicing guarantees, no cache
             hit = self._ahead[slot] = (first, stop, scores, ids)
         lo = first - hit[0]
         return hit[2][lo:lo + n], hit[3][lo:lo + n]
+
+    @staticmethod
+    def _call_size_matters(kb, index_name):
+        """True unless the index is known to score by inner product (whose arithmetic is the same for any batch size)."""
+        try:
+            index = kb.dataset._indexes[index_name]
+        except (AttributeError, KeyError, TypeError):
+            return True
+        return getattr(index, "metric_type", 1) != 0
 
     def close(self):
         self._ahead.clear()
