@@ -166,6 +166,17 @@ int mq_knn_search_screened_f32(const float *packed_dev, const float *sqnorm_dev,
  * tiles recomputed by the exact scan, out[1] = candidates re-scored in total, out[2] = max per query,
  * out[3] / out[4] = max / total slab-pool entries, out[5] = max margin (1e-6 units), out[6] = slabs. */
 int mq_knn_screen_stats(int64_t N, int d, int nq, int k, const void *ws_dev, int64_t out[8], void *stream);
+/* Which screening scan mq_knn_search_screened_f32 runs for this problem on this device: the 256 x 256 tile kernel
+ * (screen_scan_kernel) or, for ONE query tile (nq <= 256 -- the reference's Dataset.map batch,
+ * experiments/ir/viquae/dpr/search/config.json:25 -> meerqat/ir/search.py:146) over a shard of at least 65,536 rows with at
+ * most 768 bf16 columns and k <= 128, the streaming kernel that keeps the queries in registers (csrc/knn_small.inc).
+ * MQ_SCAN_KIND_NONE: the call is not served by a screening scan at all (k > 224: exact rounds; fewer than 20 L2 queries:
+ * FAISS's direct form).  Negative: MQ_EINVAL.  Environment: MQ_KNN_SMALL=0 switches the streaming kernel off,
+ * MQ_KNN_SMALL_MIN_TILES=<n> sets its floor of 32-row tiles per workgroup (default 8). */
+#define MQ_SCAN_KIND_NONE 0
+#define MQ_SCAN_KIND_TILE 1
+#define MQ_SCAN_KIND_STREAM 2
+int mq_knn_screen_scan_kind(int64_t N, int d, int nq, int k, int metric);
 
 /* Name and launch geometry of the scan kernel for the given problem (for bench.py / profiles):
  * out[0]=workgroups, out[1]=threads per workgroup, out[2]=LDS bytes (exact scan), out[3]=query tiles,

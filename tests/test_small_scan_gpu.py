@@ -1,0 +1,157 @@
+"""GPU: the streaming screening scan for ONE query tile (csrc/knn_small.inc: queries in registers, the whole LDS a ring of 32-row
+tiles, one workgroup per CU) must give exactly what the 256 x 256 tile kernel, the exact fp32 scan and the CPU oracle give --
+scores bit for bit, ids, tie order.  It serves searches of at most 256 queries (the reference's ``Dataset.map`` batch,
+experiments/ir/viquae/dpr/search/config.json:25 -> meerqat/ir/search.py:146) over shards of >= 65,536 rows with at most 768
+bf16 columns (one workgroup per CU = 256 slabs of at least eight 32-row tiles)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _default_switches(monkeypatch):
+    monkeypatch.delenv("MQ_KNN_SMALL", raising=False)
+    monkeypatch.delenv("MQ_KNN_SMALL_MIN_TILES", raising=False)
+
+
+def _index(X, metric=0, factory="Flat", screen=True, tie_order=None):
+    from viquae_amd.index import MI355XFlatIndex
+    idx = MI355XFlatIndex(string_factory=factory, metric_type=metric, screen=screen, tie_order=tie_order)
+    idx.add_vectors(X)
+    return idx
+
+
+def _both_scans(idx, Q, k):
+    """(D, I) through the streaming kernel and through the tile kernel of the same index."""
+    assert idx.scan_kind(len(Q), k) == "stream"
+    D1, I1 = idx.search_batch(Q, k)
+    stats = idx.screen_stats(len(Q), k)
+    os.environ["MQ_KNN_SMALL"] = "0"
+    try:
+        assert idx.scan_kind(len(Q), k) == "tile"
+        D0, I0 = idx.search_batch(Q, k)
+    finally:
+        del os.environ["MQ_KNN_SMALL"]
+    return (D1, I1), (D0, I0), stats
+
+
+@pytest.mark.parametrize("n,d,nq,k,metric", [
+    (66000, 768, 256, 100, 0),    # the reference's shape (DPR, inner product)
+    (65549, 768, 199, 100, 0),    # ragged: N not a multiple of 32, a partial query tile
+    (70000, 512, 64, 100, 0),     # CLIP width: the 8-K-block instance (ring of four tiles); one live wave
+    (90000, 64, 21, 10, 0),       # one K block, ring of six
+    (72345, 320, 130, 128, 0),    # five K blocks, k at the limit of the fused selection
+    (66666, 700, 37, 1, 0),       # d not a multiple of 64 (zero-padded columns)
+    (68000, 510, 100, 100, 1),    # L2 through two extra columns: dp = 512
+    (66000, 766, 256, 50, 1),     # L2 at the widest the registers take (dp = 768)
+    (200000, 128, 256, 100, 0),   # 24 tiles per slab
+])
+def test_streaming_scan_equals_tile_scan_and_oracle(n, d, nq, k, metric):
+    from oracle import knn as ok
+    rng = np.random.default_rng(n + d)
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    idx = _index(X, metric)
+    (D1, I1), (D0, I0), stats = _both_scans(idx, Q, k)
+    assert np.array_equal(I1, I0) and np.array_equal(D1, D0)
+    Do, Io = ok.knn(X, Q, k, metric=metric)
+    assert np.array_equal(I1, Io) and np.array_equal(D1, Do)
+    assert stats[0] == 0 and stats[1] >= nq * k  # the screen did the work: nothing fell back to the exact scan
+
+
+def test_not_served_cases_keep_the_tile_kernel():
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((66000, 768), dtype=np.float32)
+    ip, l2 = _index(X, 0), _index(X, 1)
+    assert ip.scan_kind(256, 100) == "stream" and ip.scan_kind(257, 100) == "tile"    # more than one query tile
+    assert ip.scan_kind(256, 129) == "tile" and ip.scan_kind(10, 300) == "none"        # k beyond the fused selection / the screen
+    assert l2.scan_kind(256, 100) == "tile"                                            # d = 768 + the two L2 columns: 13 K blocks
+    assert l2.scan_kind(19, 100) == "none"                                             # FAISS's small-batch L2 form
+    small = _index(X[:60000], 0)
+    assert small.scan_kind(256, 100) == "tile"                                         # fewer than eight 32-row tiles per workgroup
+
+
+def test_l2norm_factory_and_both_tie_orders():
+    from oracle import knn as ok
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((66500, 96), dtype=np.float32)
+    X[100:140] = X[50:90]  # exact duplicates: tied scores inside the top-k
+    Q = rng.standard_normal((77, 96), dtype=np.float32)
+    for tie in ("id_asc", "id_desc"):
+        idx = _index(X, 0, factory="L2norm,Flat", tie_order=tie)
+        (D1, I1), (D0, I0), stats = _both_scans(idx, Q, 100)
+        assert np.array_equal(I1, I0) and np.array_equal(D1, D0)
+        Do, Io = ok.knn(X, Q, 100, l2norm=True, tie_order=tie)
+        assert np.array_equal(I1, Io) and np.array_equal(D1, Do)
+
+
+def test_tie_heavy_data_overflows_the_pool_halves_and_falls_back():
+    """Small-integer data: thousands of rows tie at the k-th score, every lane's pool half fills up, the tile is flagged and the
+    exact scan recomputes it (lower id wins)."""
+    from oracle import knn as ok
+    rng = np.random.default_rng(11)
+    X = rng.integers(0, 2, (70000, 16)).astype(np.float32)
+    Q = rng.integers(0, 2, (21, 16)).astype(np.float32)
+    Q[0] = 1.0
+    idx = _index(X, 0)
+    assert idx.scan_kind(21, 100) == "stream"
+    D, I = idx.search_batch(Q, 100)
+    Do, Io = ok.knn(X, Q, 100)
+    assert np.array_equal(I, Io) and np.array_equal(D, Do)
+    assert idx.screen_stats(21, 100)[0] == 1
+
+
+def test_heavy_tailed_and_clustered_rows():
+    """Rows of wildly different norms and a shared direction (what the centred screen is for): thresholds stay valid."""
+    from oracle import knn as ok
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((80000, 128), dtype=np.float32) + 3.0 * rng.standard_normal((1, 128), dtype=np.float32)
+    X[::7] *= 20.0
+    X[1::13] *= 1e-3
+    Q = rng.standard_normal((200, 128), dtype=np.float32) + 2.0
+    idx = _index(X, 0)
+    (D1, I1), (D0, I0), _ = _both_scans(idx, Q, 100)
+    assert np.array_equal(I1, I0) and np.array_equal(D1, D0)
+    Do, Io = ok.knn(X, Q, 100)
+    assert np.array_equal(I1, Io) and np.array_equal(D1, Do)
+
+
+def test_planted_neighbours_in_every_slab_position():
+    """One planted best row per query, spread over the shard so that every slab boundary, the warm-up tiles (scored twice) and the
+    last, ragged tile hold some: each must come back first, once."""
+    rng = np.random.default_rng(9)
+    n, d, nq = 66000 + 17, 256, 256
+    X = 0.05 * rng.standard_normal((n, d), dtype=np.float32)
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    rows = np.unique(np.concatenate([np.linspace(0, n - 1, nq - 8).astype(np.int64), np.arange(n - 8, n)]))[:nq]
+    rows = np.resize(rows, nq)
+    for q, r in enumerate(rows):
+        X[r] = Q[q]
+    idx = _index(X, 0)
+    assert idx.scan_kind(nq, 100) == "stream"
+    D, I = idx.search_batch(Q, 100)
+    owner = {int(r): q for q, r in enumerate(rows)}  # a row planted twice keeps its last query
+    for q, r in enumerate(rows):
+        if owner[int(r)] == q:
+            assert I[q, 0] == r, (q, r, I[q, :3])
+        assert len(set(I[q].tolist())) == 100
+    exact = _index(X, 0, screen=False)
+    De, Ie = exact.search_batch(Q, 100)
+    assert np.array_equal(I, Ie) and np.array_equal(D, De)
+
+
+def test_consecutive_searches_reuse_the_workspace():
+    """The slot / bound words are reset by every call: a second search with other queries must not see the first one's bounds."""
+    from oracle import knn as ok
+    rng = np.random.default_rng(21)
+    X = rng.standard_normal((66000, 200), dtype=np.float32)
+    idx = _index(X, 0)
+    for scale in (5.0, 0.01, 1.0):
+        Q = scale * rng.standard_normal((256, 200), dtype=np.float32)
+        D, I = idx.search_batch(Q, 100)
+        Do, Io = ok.knn(X, Q, 100)
+        assert np.array_equal(I, Io) and np.array_equal(D, Do)

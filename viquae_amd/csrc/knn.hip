@@ -897,6 +897,7 @@ __global__ __launch_bounds__(256) void shard_merge_big_kernel(const float* __res
 }
 
 #include "knn_screen.inc"
+#include "knn_small.inc"
 #include "knn_direct.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -1023,6 +1024,45 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus, int metric = -1) {
     return g;
 }
 
+// The streaming kernel for one query tile (knn_small.inc) serves a screened search when its geometry holds: one query tile,
+// one slab per stripe slot (S = 256 = TQ: the workgroup of slab s owns query s), at most 12 K blocks of queries in registers,
+// k within the stripe bound, and enough 32-row tiles per slab for the ring to pay.  MQ_KNN_SMALL=0 switches it off,
+// MQ_KNN_SMALL_MIN_TILES=<n> lowers the tiles-per-slab floor (tests).
+bool small_scan_serves(const Geometry& g, int64_t N, int dp, int k) {
+    const char* const e0 = getenv("MQ_KNN_SMALL");  // read per call: tests and A/B runs flip it inside one process
+    const char* const e1 = getenv("MQ_KNN_SMALL_MIN_TILES");
+    const int enabled = e0 ? atoi(e0) : 1, min_tiles = e1 ? atoi(e1) : SM_MIN_TILES_PER_SLAB;
+    if (!enabled || g.nqt != 1 || g.S != TQ || g.ms != SMAX_SLOTS || g.sps != 1) return false;
+    if (dp / SBK > SM_MAX_NKB || k > KF) return false;
+    return (N + SM_ROWS - 1) / SM_ROWS >= (int64_t)g.S * (min_tiles > 1 ? min_tiles : 1);
+}
+
+template <int NKB>
+int launch_small_scan_n(const SmallArgs& sa, int S, hipStream_t st) {
+    constexpr int lds = sm_nst(NKB) * (NKB * SM_PIECE + 2 * SM_AUX) + 2 * TQ * 4 + SM_AUX;
+    MQ_DYNAMIC_LDS(lds, screen_small_kernel<NKB>);
+    hipLaunchKernelGGL(screen_small_kernel<NKB>, dim3((unsigned)S), dim3(256), lds, st, sa);
+    return MQ_OK;
+}
+
+int launch_small_scan(const SmallArgs& sa, int nkb, int S, hipStream_t st) {
+    switch (nkb) {
+        case 1: return launch_small_scan_n<1>(sa, S, st);
+        case 2: return launch_small_scan_n<2>(sa, S, st);
+        case 3: return launch_small_scan_n<3>(sa, S, st);
+        case 4: return launch_small_scan_n<4>(sa, S, st);
+        case 5: return launch_small_scan_n<5>(sa, S, st);
+        case 6: return launch_small_scan_n<6>(sa, S, st);
+        case 7: return launch_small_scan_n<7>(sa, S, st);
+        case 8: return launch_small_scan_n<8>(sa, S, st);
+        case 9: return launch_small_scan_n<9>(sa, S, st);
+        case 10: return launch_small_scan_n<10>(sa, S, st);
+        case 11: return launch_small_scan_n<11>(sa, S, st);
+        case 12: return launch_small_scan_n<12>(sa, S, st);
+        default: return MQ_EUNSUPPORTED;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1104,6 +1144,14 @@ int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[8]) {
     out[6] = 1024;         // screening scan: threads per workgroup
     out[7] = S_LDS_TOTAL;  // screening scan: LDS bytes
     return MQ_OK;
+}
+
+int mq_knn_screen_scan_kind(int64_t N, int d, int nq, int k, int metric) {
+    if (N <= 0 || d <= 0 || nq <= 0 || k <= 0 || k > MQ_KNN_MAX_K) return MQ_EINVAL;
+    if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
+    if (k > SCREEN_MAX_K || (metric == MQ_METRIC_L2 && nq < MQ_KNN_L2_DIRECT_BELOW)) return MQ_SCAN_KIND_NONE;
+    const Geometry g = geometry(N, d, nq, k, num_cus(), metric);
+    return small_scan_serves(g, N, screen_dp(d, metric), k) ? MQ_SCAN_KIND_STREAM : MQ_SCAN_KIND_TILE;
 }
 
 // tie order of a call: key low word = ~(row ^ flip)
@@ -1403,8 +1451,17 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         a.dbg = dbg_ptr();
         a.N = N; a.dp = dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx_screen; a.nchunks = g.nchunks;
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
-        MQ_DYNAMIC_LDS(S_LDS_TOTAL, screen_scan_kernel);
-        hipLaunchKernelGGL(screen_scan_kernel, dim3((unsigned)(g.nqt * g.S)), dim3(1024), S_LDS_TOTAL, st, a);
+        if (small_scan_serves(g, N, dp, k)) {
+            // one query tile: the streaming kernel with the queries in registers (knn_small.inc)
+            SmallArgs sa;
+            sa.s = a;
+            sa.ntiles = (N + SM_ROWS - 1) / SM_ROWS;
+            const int rc = launch_small_scan(sa, dp / SBK, g.S, st);
+            if (rc != MQ_OK) return rc;
+        } else {
+            MQ_DYNAMIC_LDS(S_LDS_TOTAL, screen_scan_kernel);
+            hipLaunchKernelGGL(screen_scan_kernel, dim3((unsigned)(g.nqt * g.S)), dim3(1024), S_LDS_TOTAL, st, a);
+        }
         MQ_HIP(hipGetLastError());
         if (ev_scan_end) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_end, st));
     }

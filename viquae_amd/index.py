@@ -444,6 +444,16 @@ class MI355XFlatIndex(BaseIndex):
         scores, indices = self.search_batch(query.reshape(1, -1), k)
         return SearchResults(scores[0], indices[0].astype(int))
 
+    def scan_kind(self, nq, k):
+        """Which screening scan serves a ``search_device`` call of ``nq`` queries: "tile" (256 x 256 tiles), "stream" (one query
+        tile, queries in registers: csrc/knn_small.inc) or "none" (exact rounds / FAISS's small-batch L2 form / exact index)."""
+        if not self.screen or not self.ntotal:
+            return "none"
+        kind = int(_lib.load().mq_knn_screen_scan_kind(self.ntotal, self.d, int(nq), int(k), self.metric_type))
+        if kind < 0:
+            raise ValueError(f"mq_knn_screen_scan_kind: invalid arguments (status {kind})")
+        return ("none", "tile", "stream")[kind]
+
     # ------------------------------------------------------------------ persistence
     def screen_stats(self, nq, k):
         """(query tiles recomputed exactly, candidates re-scored, max per query, ...) of the LAST C-ABI call of the last
