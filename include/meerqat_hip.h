@@ -55,7 +55,21 @@ extern "C" {
  * mq_topk_merge_*: OR MQ_MERGE_TIE_ID_DESC into `metric` to merge shard results produced with MQ_KNN_FLAG_TIE_ID_DESC. */
 #define MQ_KNN_FLAG_L2NORM_QUERIES 1
 #define MQ_KNN_FLAG_TIE_ID_DESC 2
+#define MQ_KNN_FLAG_L2NORM_FAISS 4 /* the query transform in FAISS's arithmetic (below); implies MQ_KNN_FLAG_L2NORM_QUERIES */
 #define MQ_MERGE_TIE_ID_DESC 0x100
+
+/* The two arithmetics of the "L2norm," prefix -- the `l2norm` argument of mq_pack_rows_f32 / mq_knn_screen_add_rows_f32 (0 = no
+ * transform), the `form` of mq_l2norm_rows_form_f32, and MQ_KNN_FLAG_L2NORM_FAISS for the queries of a search:
+ *   MQ_L2NORM_NUMPY  x / sqrtf(sum x^2): the reference's L2norm() (meerqat/ir/search.py:43-46), which it also applies to the KB
+ *                    column itself when `device` is given (its GPU work-around, :238-244).  A zero row becomes NaN.
+ *   MQ_L2NORM_FAISS  FAISS's NormalizationTransform -> fvec_renorm_L2 (faiss/utils/distances.cpp, as published): when
+ *                    nr = sum x^2 > 0, x *= (float)(1.0 / sqrtf(nr)) -- one double reciprocal per row rounded to float, one
+ *                    multiplication per element; a row with nr not > 0 (zero, underflowed, NaN) stays as it is (a zero row
+ *                    remains retrievable with score 0).  What "L2norm,Flat" computes with `device: null`, i.e. in every shipped
+ *                    config (:230-245): for the KB rows on add and, inside the index, for the (already host-normalised) queries.
+ * In both forms sum x^2 is the k-ordered fp32 fma chain (FAISS's SIMD summation order is not knowable here: parity unpinned). */
+#define MQ_L2NORM_NUMPY 1
+#define MQ_L2NORM_FAISS 2
 
 /* faiss::distance_compute_blas_threshold.  A METRIC_L2 search of FEWER queries than this takes FAISS's
  * sequential path: distances are the direct sums of (q[k] - x[k])^2 (faiss fvec_L2sqr), not the BLAS form
@@ -91,7 +105,8 @@ int mq_unpack_rows_f32(const float *packed_dev, int64_t capacity_rows, int d, in
                        float *rows_dev, void *stream);
 
 /* In-place row L2 normalisation of a row-major [n,d] device matrix: L2norm(), meerqat/ir/search.py:43-46. */
-int mq_l2norm_rows_f32(float *rows_dev, int64_t n, int d, void *stream);
+int mq_l2norm_rows_f32(float *rows_dev, int64_t n, int d, void *stream);                     /* MQ_L2NORM_NUMPY */
+int mq_l2norm_rows_form_f32(float *rows_dev, int64_t n, int d, int form, void *stream);      /* form: MQ_L2NORM_NUMPY | MQ_L2NORM_FAISS */
 
 /* ---------------------------------------------------------------------------------------------
  * Exact brute-force top-k: replaces faiss IndexFlat.search behind FaissIndex.search_batch

@@ -56,6 +56,8 @@ def lib():
         L.oracle_heap_add_block_panels.restype = None
         L.oracle_l2norm_rows_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int]
         L.oracle_l2norm_rows_f32.restype = None
+        L.oracle_l2norm_rows_faiss_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int]
+        L.oracle_l2norm_rows_faiss_f32.restype = None
         L.oracle_sqnorm_rows_f32.argtypes = [fp, ctypes.c_int64, ctypes.c_int, fp]
         L.oracle_sqnorm_rows_f32.restype = None
         L.oracle_topk_merge.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp]
@@ -81,12 +83,19 @@ def set_num_threads(n):
         lib().oracle_set_num_threads(int(n))
 
 
-def l2norm_rows(x):
-    """Row L2-normalisation with the oracle's fixed arithmetic (returns a new array)."""
+def l2norm_rows(x, form="numpy"):
+    """Row L2-normalisation with the oracle's fixed arithmetic (returns a new array).  ``form``: "numpy" = the reference's
+    ``L2norm()`` (x / sqrt(sum x^2), a zero row becomes NaN), "faiss" = FAISS's ``fvec_renorm_L2`` (x * float(1.0 / sqrt(sum x^2)),
+    rows whose squared norm is not > 0 left untouched) -- see oracle/knn_oracle.c."""
     x = _f32(x).copy()
     if x.ndim != 2:
         raise ValueError("expected a 2-D array")
-    lib().oracle_l2norm_rows_f32(x.ctypes.data, x.shape[0], x.shape[1])
+    if form == "numpy":
+        lib().oracle_l2norm_rows_f32(x.ctypes.data, x.shape[0], x.shape[1])
+    elif form == "faiss":
+        lib().oracle_l2norm_rows_faiss_f32(x.ctypes.data, x.shape[0], x.shape[1])
+    else:
+        raise ValueError(f"l2norm form must be 'numpy' or 'faiss', got {form!r}")
     return x
 
 
@@ -102,11 +111,12 @@ L2_FORMS = {"auto": 0, "expanded": 1, "direct": 2}
 TIE_ORDERS = {"id_asc": 0, "id_desc": 1}  # knn_oracle.c header: this library's documented tie policy, not FAISS's
 
 
-def knn(X, Q, k, metric=0, id_offset=0, l2norm=False, l2_form="auto", tie_order="id_asc"):
+def knn(X, Q, k, metric=0, id_offset=0, l2norm=False, l2_form="auto", tie_order="id_asc", l2norm_form="numpy"):
     """Brute-force top-k of Q against X; returns (D f32 [nq,k], I i64 [nq,k]).
 
     ``l2norm=True`` applies the "L2norm," transform to both sides first (FAISS
-    NormalizationTransform on add and on search).  ``l2_form`` (metric 1): "auto" = FAISS's rule
+    NormalizationTransform on add and on search) in the arithmetic ``l2norm_form`` names ("numpy" | "faiss", see l2norm_rows).
+    ``l2_form`` (metric 1): "auto" = FAISS's rule
     (fewer than 20 queries: direct sum of (q-x)^2; otherwise ||q||^2+||x||^2-2<q,x> clamped at 0),
     or force "expanded" / "direct".  ``tie_order``: "id_asc" (default: among exactly equal scores the lower id
     is better) or "id_desc" (the higher id is better), for membership at the k-th boundary and output order alike."""
@@ -114,7 +124,7 @@ def knn(X, Q, k, metric=0, id_offset=0, l2norm=False, l2_form="auto", tie_order=
     if Q.ndim != 2 or X.ndim != 2 or Q.shape[1] != X.shape[1]:
         raise ValueError("shape mismatch")
     if l2norm:
-        X, Q = l2norm_rows(X), l2norm_rows(Q)
+        X, Q = l2norm_rows(X, l2norm_form), l2norm_rows(Q, l2norm_form)
     nq, d = Q.shape
     D = np.empty((nq, k), dtype=np.float32)
     I = np.empty((nq, k), dtype=np.int64)

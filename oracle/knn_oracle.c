@@ -117,6 +117,27 @@ void oracle_l2norm_rows_f32(float *rows, int64_t n, int d) {
     }
 }
 
+/* The same prefix in FAISS's own arithmetic: NormalizationTransform::apply_noalloc -> fvec_renorm_L2
+ * (faiss/utils/distances.cpp, as published, un-vendored faiss-gpu>=1.7.1):
+ *     float nr = fvec_norm_L2sqr(xi, d);
+ *     if (nr > 0) { const float inv_nr = 1.0 / sqrtf(nr); for (j...) xi[j] *= inv_nr; }
+ * i.e. ONE reciprocal per row -- a double division (the literal 1.0 is a double) rounded to float -- and a multiplication per
+ * element, and a row whose squared norm is not > 0 (a zero row, an underflowed one, NaN) is left exactly as it is: it stays
+ * retrievable with score 0 where the numpy form above turns it into NaN.  This is what the reference runs for KB rows and,
+ * inside the index, for queries when "L2norm,Flat" meets `device: null` (every shipped config: meerqat/ir/search.py:230-245);
+ * the numpy form is its GPU work-around (:238-244) and its host-side L2norm() (:43-46).  fvec_norm_L2sqr's SIMD summation
+ * order is not restated (unknowable here): the squared norm is the k-ordered fmaf chain, like everywhere in this oracle. */
+void oracle_l2norm_rows_faiss_f32(float *rows, int64_t n, int d) {
+    for (int64_t i = 0; i < n; ++i) {
+        float *r = rows + i * (int64_t)d;
+        const float nr = chain_dot(r, r, d);
+        if (nr > 0) {
+            const float inv_nr = (float)(1.0 / (double)sqrtf(nr));
+            for (int k = 0; k < d; ++k) r[k] *= inv_nr;
+        }
+    }
+}
+
 void oracle_sqnorm_rows_f32(const float *rows, int64_t n, int d, float *out) {
     for (int64_t i = 0; i < n; ++i) out[i] = chain_dot(rows + i * (int64_t)d, rows + i * (int64_t)d, d);
 }

@@ -18,7 +18,7 @@ def _oracle_index(X, metric, l2norm=False):
         def search_batch(self, queries, k=10, **kw):
             if len(np.shape(queries)) != 2:
                 raise ValueError("Shape of query must be 2D")
-            D, I = ok.knn(X, queries, k, metric=metric, l2norm=l2norm)
+            D, I = ok.knn(X, queries, k, metric=metric, l2norm=l2norm, l2norm_form="faiss")  # FAISS's NormalizationTransform
             return BatchedSearchResults(D, I.astype(int))
 
     return OracleIndex()

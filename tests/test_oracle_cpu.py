@@ -36,7 +36,7 @@ def test_oracle_reproduces_golden(name):
         if l2:
             # the reference normalises queries on the host (ir/search.py:144-145) before the index does it again
             Qin = (Q / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float32)
-        D, I = ok.knn(X, Qin, k, metric=metric, l2norm=l2)
+        D, I = ok.knn(X, Qin, k, metric=metric, l2norm=l2, l2norm_form="faiss")  # "L2norm,Flat" with `device: null`
         assert np.array_equal(I, g[f"I_{tag}"]), tag
         assert np.array_equal(D, g[f"D_{tag}"]), tag
         n += 1
@@ -176,6 +176,37 @@ def test_l2norm_rows_close_to_numpy():
     b = X / np.linalg.norm(X, axis=1, keepdims=True)
     assert np.allclose(a, b, rtol=0, atol=2e-7)
     assert np.isnan(ok.l2norm_rows(np.zeros((1, 4), np.float32))).all()  # no epsilon, like the reference
+
+
+def test_l2norm_rows_faiss_form():
+    """FAISS's NormalizationTransform (fvec_renorm_L2, as published): one float reciprocal per row taken from a DOUBLE division,
+    one multiplication per element, rows whose squared norm is not > 0 left exactly as they are."""
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((50, 33)).astype(np.float32)
+    X[3] = 0.0                    # zero row: stays zero (numpy form: NaN)
+    X[5] = 1e-30                  # squares underflow to 0: stays as it is
+    X[7] = 1e-20                  # squared norm is a denormal > 0: normalised
+    X[9, 0] = np.nan              # nr is NaN, not > 0: untouched
+    a = ok.l2norm_rows(X, form="faiss")
+    nr = ok.sqnorm_rows(X)
+    for i in range(50):
+        if nr[i] > 0:
+            inv = np.float32(1.0 / np.float64(np.sqrt(np.float32(nr[i]))))
+            assert np.array_equal(a[i], X[i] * inv), i
+        else:
+            assert np.array_equal(a[i], X[i], equal_nan=True), i
+    assert not a[3].any() and np.array_equal(a[5], X[5]) and abs(float(np.linalg.norm(a[7].astype(np.float64))) - 1) < 1e-4  # (a denormal squared norm keeps ~17 bits)
+    b = ok.l2norm_rows(X)         # the numpy form on the same rows
+    assert np.isnan(b[3]).all() and not np.isfinite(b[5]).any()
+    ok_rows = [i for i in range(50) if i not in (3, 5, 9)]
+    assert np.allclose(a[ok_rows], b[ok_rows], rtol=3e-7, atol=0) and not np.array_equal(a[ok_rows], b[ok_rows])
+    with pytest.raises(ValueError):
+        ok.l2norm_rows(X, form="blas")
+    # through knn(): a zero KB row is retrievable (score 0) in FAISS's form and never in numpy's
+    Q = rng.standard_normal((4, 33)).astype(np.float32)
+    Df, If = ok.knn(X[:8], Q, 8, l2norm=True, l2norm_form="faiss")
+    Dn, In = ok.knn(X[:8], Q, 8, l2norm=True, l2norm_form="numpy")
+    assert all(3 in row for row in If) and all(3 not in row for row in In) and (In[:, -1] == -1).all()
 
 
 @pytest.mark.parametrize("metric", [0, 1])

@@ -86,11 +86,11 @@ class _PreTransformStandIn:
 
     def add(self, x):
         from oracle import knn as ok
-        self.index.add(ok.l2norm_rows(np.asarray(x, np.float32)))
+        self.index.add(ok.l2norm_rows(np.asarray(x, np.float32), form="faiss"))  # NormalizationTransform = fvec_renorm_L2
 
     def search(self, q, k):
         from oracle import knn as ok
-        return self.index.search(ok.l2norm_rows(np.asarray(q, np.float32)), k)
+        return self.index.search(ok.l2norm_rows(np.asarray(q, np.float32), form="faiss"), k)
 
 
 class _RunStandIn:

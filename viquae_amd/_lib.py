@@ -26,6 +26,7 @@ SIGNATURES = {
     "mq_pack_rows_f32": (c_int, [c_ptr, c_i64, c_int, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr]),
     "mq_unpack_rows_f32": (c_int, [c_ptr, c_i64, c_int, c_i64, c_i64, c_ptr, c_ptr]),
     "mq_l2norm_rows_f32": (c_int, [c_ptr, c_i64, c_int, c_ptr]),
+    "mq_l2norm_rows_form_f32": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr]),
     "mq_knn_workspace_bytes": (c_sz, [c_i64, c_int, c_int, c_int]),
     "mq_knn_workspace_bytes_metric": (c_sz, [c_i64, c_int, c_int, c_int, c_int]),
     "mq_knn_search_f32": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_int, c_int, c_i64,

@@ -99,6 +99,19 @@ __device__ __forceinline__ unsigned key_row(u64 key) { return 0xFFFFFFFFu - (uns
 // layout kernels
 // ------------------------------------------------------------------------------------------------
 
+// The "L2norm," prefix in its two arithmetics (include/meerqat_hip.h: MQ_L2NORM_NUMPY / MQ_L2NORM_FAISS; oracle/knn_oracle.c):
+// the per-row factor from the squared norm nr (the k-ordered fmaf chain), and its application to one element.
+//   numpy form (meerqat/ir/search.py:43-46, and :238-244 for the KB rows when `device` is given):  x / sqrtf(nr)
+//   FAISS form (NormalizationTransform -> fvec_renorm_L2, what "L2norm,Flat" runs with `device: null`):
+//       if (nr > 0) x *= (float)(1.0 / (double)sqrtf(nr));   rows whose nr is not > 0 stay as they are
+__device__ __forceinline__ float l2norm_scale(float nr, int form) {
+    if (form == MQ_L2NORM_FAISS) return nr > 0.f ? (float)(1.0 / (double)sqrtf(nr)) : 1.0f;
+    return sqrtf(nr);
+}
+__device__ __forceinline__ float l2norm_apply(float x, float scale, int form) {
+    return form == MQ_L2NORM_FAISS ? x * scale : x / scale;
+}
+
 // 256 threads; loads rows [row0, row0+64) x k [kc, kc+64) of a row-major [n,d] matrix into
 // tile[64][65] (zero outside the matrix)
 __device__ __forceinline__ void load_tile64(const float* __restrict__ src, int64_t n, int d, int64_t row0, int kc,
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
             }
             __syncthreads();
         }
-        if (t < 64) nrm[t] = sqrtf(acc);
+        if (t < 64) nrm[t] = l2norm_scale(acc, l2norm);
         __syncthreads();
     }
     float acc2 = 0.f;
@@ -156,10 +169,10 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
         load_tile64(src, n, d, row0, kc, tile);
         __syncthreads();
         if (l2norm) {
-            // x / ||x||: same two roundings as the oracle (sqrtf, then one division per element)
+            // numpy form: x / ||x||, the oracle's two roundings (sqrtf, then one division per element); FAISS form: x * inv
             for (int e = t; e < 64 * 64; e += 256) {
                 const int r = e >> 6, k = e & 63;
-                if (row0 + r < n && kc + k < d) tile[r][k] = tile[r][k] / nrm[r];
+                if (row0 + r < n && kc + k < d) tile[r][k] = l2norm_apply(tile[r][k], nrm[r], l2norm);
             }
             __syncthreads();
         }
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(256) void store_rows_kernel(const float* __restrict
             }
             __syncthreads();
         }
-        if (t < 64) nrm[t] = sqrtf(acc);
+        if (t < 64) nrm[t] = l2norm_scale(acc, l2norm);
         __syncthreads();
     }
     float acc2 = 0.f;
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(256) void store_rows_kernel(const float* __restrict
         if (l2norm) {
             for (int e = t; e < 64 * 64; e += 256) {
                 const int r = e >> 6, k = e & 63;
-                if (row0 + r < n && kc + k < d) tile[r][k] = tile[r][k] / nrm[r];
+                if (row0 + r < n && kc + k < d) tile[r][k] = l2norm_apply(tile[r][k], nrm[r], l2norm);
             }
             __syncthreads();
         }
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(256) void store_rows_kernel(const float* __restrict
     if (t < 64 && row0 + t < n) sqnorm[row_offset + row0 + t] = acc2;
 }
 
-__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ rows, int64_t n, int d) {
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ rows, int64_t n, int d, int form = MQ_L2NORM_NUMPY) {
     __shared__ float tile[64][65];
     __shared__ float nrm[64];
     const int t = threadIdx.x;
@@ -255,14 +268,14 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ ro
         }
         __syncthreads();
     }
-    if (t < 64) nrm[t] = sqrtf(acc);
+    if (t < 64) nrm[t] = l2norm_scale(acc, form);
     __syncthreads();
     for (int64_t e = t; e < 64 * (int64_t)d; e += 256) {
         const int r = (int)(e / d);
         const int k = (int)(e - (int64_t)r * d);
         if (row0 + r < n) {
             float* p = rows + (row0 + r) * (int64_t)d + k;
-            *p = *p / nrm[r];
+            *p = l2norm_apply(*p, nrm[r], form);
         }
     }
 }
@@ -1113,13 +1126,17 @@ int mq_unpack_rows_f32(const float* packed_dev, int64_t capacity_rows, int d, in
     return MQ_OK;
 }
 
-int mq_l2norm_rows_f32(float* rows_dev, int64_t n, int d, void* stream) {
+int mq_l2norm_rows_form_f32(float* rows_dev, int64_t n, int d, int form, void* stream) {
     if (n == 0) return MQ_OK;
-    if (!rows_dev || n < 0 || d <= 0) return MQ_EINVAL;
+    if (!rows_dev || n < 0 || d <= 0 || (form != MQ_L2NORM_NUMPY && form != MQ_L2NORM_FAISS)) return MQ_EINVAL;
     const unsigned grid = (unsigned)((n + 63) / 64);
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rows_dev, n, d);
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rows_dev, n, d, form);
     MQ_HIP(hipGetLastError());
     return MQ_OK;
+}
+
+int mq_l2norm_rows_f32(float* rows_dev, int64_t n, int d, void* stream) {
+    return mq_l2norm_rows_form_f32(rows_dev, n, d, MQ_L2NORM_NUMPY, stream);
 }
 
 size_t mq_knn_workspace_bytes(int64_t N, int d, int nq, int k) {
@@ -1154,6 +1171,13 @@ int mq_knn_screen_scan_kind(int64_t N, int d, int nq, int k, int metric) {
     return small_scan_serves(g, N, screen_dp(d, metric), k) ? MQ_SCAN_KIND_STREAM : MQ_SCAN_KIND_TILE;
 }
 
+// "L2norm," arithmetic of a call's query transform: 0 = none, MQ_L2NORM_NUMPY, MQ_L2NORM_FAISS (the flag alone means FAISS form too)
+static inline int query_l2norm_form(int flags) {
+    if (flags & MQ_KNN_FLAG_L2NORM_FAISS) return MQ_L2NORM_FAISS;
+    return (flags & MQ_KNN_FLAG_L2NORM_QUERIES) ? MQ_L2NORM_NUMPY : 0;
+}
+constexpr int MQ_KNN_ALL_FLAGS = MQ_KNN_FLAG_L2NORM_QUERIES | MQ_KNN_FLAG_TIE_ID_DESC | MQ_KNN_FLAG_L2NORM_FAISS;
+
 // tie order of a call: key low word = ~(row ^ flip)
 static inline unsigned tie_flip(int flags) { return (flags & MQ_KNN_FLAG_TIE_ID_DESC) ? 0xFFFFFFFFu : 0u; }
 
@@ -1173,9 +1197,9 @@ static int knn_search_l2_direct(const float* packed_dev, const float* rowmajor_d
     u64* ceil = (u64*)(ws + g.off_ceil);
     const unsigned flip = tie_flip(flags);
     const float* q_rm = queries_dev;
-    if (flags & MQ_KNN_FLAG_L2NORM_QUERIES) {
+    if (query_l2norm_form(flags)) {
         MQ_HIP(hipMemcpyAsync(qtmp, queries_dev, (size_t)nq * d * 4, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, qtmp, (int64_t)nq, d);
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, qtmp, (int64_t)nq, d, query_l2norm_form(flags));
         MQ_HIP(hipGetLastError());
         q_rm = qtmp;
     }
@@ -1262,7 +1286,7 @@ static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int
     if (nq == 0) return MQ_OK;
     if (!packed_dev || !sqnorm_dev || !queries_dev || !D_dev || !I_dev || !ws_dev) return MQ_EINVAL;
     if (N < 0 || d <= 0 || nq < 0 || k <= 0 || (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2)) return MQ_EINVAL;
-    if (flags & ~(MQ_KNN_FLAG_L2NORM_QUERIES | MQ_KNN_FLAG_TIE_ID_DESC)) return MQ_EINVAL;
+    if (flags & ~MQ_KNN_ALL_FLAGS) return MQ_EINVAL;
     if (k > MQ_KNN_MAX_K) return MQ_EUNSUPPORTED;
     if (N >= 0xFFFFFFFFll) return MQ_EUNSUPPORTED;  // 32-bit local row ids
     const Geometry g = geometry(N, d, nq, k, num_cus(), metric);
@@ -1278,7 +1302,7 @@ static int knn_search_impl(const float* packed_dev, const float* sqnorm_dev, int
     // queries -> panel layout (+ optional "L2norm," transform, + ||q||^2); padded queries are zero
     MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
     hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((nq + PANEL - 1) / PANEL)), dim3(256), 0, st, queries_dev, (int64_t)nq, d,
-                       g.dpad, (int64_t)0, (flags & MQ_KNN_FLAG_L2NORM_QUERIES) ? 1 : 0, Qp, qn, (const int*)nullptr);
+                       g.dpad, (int64_t)0, query_l2norm_form(flags), Qp, qn, (const int*)nullptr);
     MQ_HIP(hipGetLastError());
 
     ScanArgs a;
@@ -1368,8 +1392,8 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
                                void* ws_dev, size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
     if (nq == 0) return MQ_OK;
     if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
-    if (flags & ~(MQ_KNN_FLAG_L2NORM_QUERIES | MQ_KNN_FLAG_TIE_ID_DESC)) return MQ_EINVAL;
-    const int l2norm_queries = (flags & MQ_KNN_FLAG_L2NORM_QUERIES) ? 1 : 0;
+    if (flags & ~MQ_KNN_ALL_FLAGS) return MQ_EINVAL;
+    const int l2norm_queries = query_l2norm_form(flags);
     const unsigned flip = tie_flip(flags);
     const int l2 = metric == MQ_METRIC_L2;
     const int dp = screen_dp(d, metric);
@@ -1404,7 +1428,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     const float* q_rm = queries_dev;
     if (l2norm_queries) {
         MQ_HIP(hipMemcpyAsync(qtmp, queries_dev, (size_t)nq * d * 4, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, qtmp, (int64_t)nq, d);
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, qtmp, (int64_t)nq, d, l2norm_queries);
         MQ_HIP(hipGetLastError());
         q_rm = qtmp;
     }

@@ -39,6 +39,8 @@ METRIC_INNER_PRODUCT = 0  # faiss.METRIC_INNER_PRODUCT
 METRIC_L2 = 1  # faiss.METRIC_L2
 MAX_K = 2048  # MQ_KNN_MAX_K; the screened search serves k <= 224, a larger k runs ceil(k / 128) exact scans (include/meerqat_hip.h)
 FLAG_L2NORM_QUERIES, FLAG_TIE_ID_DESC, MERGE_TIE_ID_DESC = 1, 2, 0x100  # MQ_KNN_FLAG_*, MQ_MERGE_TIE_ID_DESC
+FLAG_L2NORM_FAISS = 4                            # MQ_KNN_FLAG_L2NORM_FAISS
+L2NORM_FORMS = {"numpy": 1, "faiss": 2}         # MQ_L2NORM_NUMPY, MQ_L2NORM_FAISS
 TIE_ORDERS = ("id_asc", "id_desc")
 _MAGIC = b"MQFLAT01"
 _UPLOAD_ROWS = 1 << 16  # rows per host->device staging copy (multiple of 64)
@@ -112,7 +114,7 @@ class MI355XFlatIndex(BaseIndex):
 
     def __init__(self, device: Optional[Union[int, list]] = None, string_factory: Optional[str] = None,
                  metric_type: Optional[int] = None, custom_index=None, id_offset: int = 0, screen: Optional[bool] = None,
-                 keep_panel: Optional[bool] = None, tie_order: Optional[str] = None):
+                 keep_panel: Optional[bool] = None, tie_order: Optional[str] = None, l2norm_form: Optional[str] = None):
         if custom_index is not None:
             raise ValueError("custom_index is a FAISS object; MI355XFlatIndex builds its own index")
         self.device = device
@@ -122,6 +124,15 @@ class MI355XFlatIndex(BaseIndex):
         if self.metric_type not in (METRIC_INNER_PRODUCT, METRIC_L2):
             raise ValueError(f"Unsupported metric_type {metric_type} (0 = inner product, 1 = L2)")
         self.do_l2norm = parse_string_factory(string_factory)
+        # Arithmetic of the "L2norm," prefix (include/meerqat_hip.h): "numpy" = x / sqrt(sum x^2), the reference's L2norm()
+        # (meerqat/ir/search.py:43-46) and what its GPU work-around applies to the KB column when `device` is given (:238-244);
+        # "faiss" = FAISS's NormalizationTransform (x * float(1.0 / sqrt(sum x^2)), rows of norm 0 left untouched), what
+        # "L2norm,Flat" computes with `device: null` -- KnowledgeBase.add_or_load_faiss_index asks for it then.
+        # MQ_KNN_L2NORM_FORM sets the default of a directly constructed index ("numpy").
+        l2norm_form = l2norm_form or os.environ.get("MQ_KNN_L2NORM_FORM", "numpy")
+        if l2norm_form not in L2NORM_FORMS:
+            raise ValueError(f"l2norm_form must be one of {sorted(L2NORM_FORMS)}, got {l2norm_form!r}")
+        self.l2norm_form = l2norm_form
         # Which of several EXACTLY tied rows is the better one: "id_asc" (default, the lower id) or "id_desc" (the higher
         # id), for membership at the k-th boundary and output order alike.  Both are this library's documented policies;
         # FAISS's own behaviour on exact ties depends on its version and on k (oracle/knn_oracle.c).
@@ -229,7 +240,8 @@ class MI355XFlatIndex(BaseIndex):
                 head = (head if isinstance(head, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(head)))
                 head = head.to(device=self._torch_device, dtype=torch.float32).contiguous().clone()
                 if self.do_l2norm:
-                    _lib.check(lib.mq_l2norm_rows_f32(head.data_ptr(), head.shape[0], self.d, stream), "mq_l2norm_rows_f32")
+                    _lib.check(lib.mq_l2norm_rows_form_f32(head.data_ptr(), head.shape[0], self.d, L2NORM_FORMS[self.l2norm_form], stream),
+                               "mq_l2norm_rows_form_f32")
                 blk = torch.cat([tail, head]).contiguous()
                 _lib.check(lib.mq_pack_rows_f32(blk.data_ptr(), blk.shape[0], self.d, floor, 0, self._packed.data_ptr(),
                                                 self._capacity, self._sqnorm.data_ptr(), stream), "mq_pack_rows_f32")
@@ -251,7 +263,7 @@ class MI355XFlatIndex(BaseIndex):
                     if not part.flags.writeable:
                         part = part.copy()
                     dev = torch.from_numpy(part).to(self._torch_device, non_blocking=False)
-                _lib.check(lib.mq_pack_rows_f32(dev.data_ptr(), dev.shape[0], self.d, self.ntotal, int(self.do_l2norm),
+                _lib.check(lib.mq_pack_rows_f32(dev.data_ptr(), dev.shape[0], self.d, self.ntotal, self._l2norm_arg(),
                                                 self._packed.data_ptr(), self._capacity, self._sqnorm.data_ptr(),
                                                 stream), "mq_pack_rows_f32")
                 if self.screen:
@@ -288,11 +300,15 @@ class MI355XFlatIndex(BaseIndex):
                     self._xmax2 = torch.zeros(3, dtype=torch.float32, device=self._torch_device)
                     self._center = self._choose_center(dev)
                 _lib.check(lib.mq_knn_screen_add_rows_f32(
-                    dev.data_ptr(), dev.shape[0], self.d, self.ntotal, int(self.do_l2norm), self.metric_type, self._capacity,
+                    dev.data_ptr(), dev.shape[0], self.d, self.ntotal, self._l2norm_arg(), self.metric_type, self._capacity,
                     self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(), self._xmax2.data_ptr(),
                     self._center.data_ptr() if self._center is not None else None, stream), "mq_knn_screen_add_rows_f32")
                 self.ntotal += dev.shape[0]
                 torch.cuda.current_stream(self._torch_device).synchronize()  # `dev` must outlive the kernels
+
+    def _l2norm_arg(self):
+        """The `l2norm` argument of the row-ingest entry points: 0 or the MQ_L2NORM_* code of this index's arithmetic."""
+        return L2NORM_FORMS[self.l2norm_form] if self.do_l2norm else 0
 
     def _choose_center(self, first_rows):
         """Centre of the bf16 screening copy: the mean of the first rows added (as stored, i.e. after "L2norm,").  Any
@@ -304,7 +320,8 @@ class MI355XFlatIndex(BaseIndex):
             return None
         x = first_rows.to(torch.float32)
         if self.do_l2norm:
-            x = x / x.norm(dim=1, keepdim=True)
+            nrm = x.norm(dim=1, keepdim=True)
+            x = x / (torch.where(nrm > 0, nrm, torch.ones_like(nrm)) if self.l2norm_form == "faiss" else nrm)
         c = torch.nan_to_num(x, nan=0.0, posinf=0.0, neginf=0.0).mean(dim=0)
         return c.contiguous() if bool(torch.isfinite(c).all()) else None
 
@@ -381,6 +398,8 @@ class MI355XFlatIndex(BaseIndex):
                 ws = self._workspace(nb)
                 Dq, Iq = D[s:e], I[s:e]
                 flags = (FLAG_L2NORM_QUERIES if self.do_l2norm else 0) | (FLAG_TIE_ID_DESC if self.tie_order == "id_desc" else 0)
+                if self.do_l2norm and self.l2norm_form == "faiss":
+                    flags |= FLAG_L2NORM_FAISS
                 if self.screen:
                     _lib.check(lib.mq_knn_search_screened_f32(
                         self._packed.data_ptr() if self._packed is not None else None, self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(),
@@ -496,13 +515,14 @@ class MI355XFlatIndex(BaseIndex):
             f.write(rows.tobytes())
 
     @classmethod
-    def load(cls, file: Union[str, PurePath], device=None, storage_options: Optional[dict] = None, tie_order=None):
+    def load(cls, file: Union[str, PurePath], device=None, storage_options: Optional[dict] = None, tie_order=None, l2norm_form=None):
         """FaissIndex.load (datasets/search.py:399-416).  Reads this class's own files and the FAISS files
         the reference's ``save_path`` / ``dataset.save_faiss_index`` wrote for the factories it ships
         (IndexFlat, and IndexPreTransform(NormalizationTransform, IndexFlat) for "L2norm,Flat")."""
         path = os.fspath(file)
         n, d, metric, l2norm, data_off = read_index_file_header(path)
-        idx = cls(device=device, string_factory="L2norm,Flat" if l2norm else "Flat", metric_type=metric, tie_order=tie_order)
+        idx = cls(device=device, string_factory="L2norm,Flat" if l2norm else "Flat", metric_type=metric, tie_order=tie_order,
+                  l2norm_form=l2norm_form)
         if n:
             rows = np.fromfile(path, dtype=np.float32, count=n * d, offset=data_off).reshape(n, d)
             # rows were stored after normalisation: do not normalise twice on load

@@ -130,13 +130,16 @@ class KnowledgeBase:
 
     def add_or_load_faiss_index(self, column, index_name=None, load=False, save_path=None, string_factory=None,
                                 device=None, metric_type=None, batch_size=1000, train_size=None, file=None,
-                                faiss_verbose=None, tie_order=None, **kwargs):
+                                faiss_verbose=None, tie_order=None, l2norm_form=None, **kwargs):
         """Builds (or loads from ``file``) the exact index over ``column`` and registers it as
         ``index_name``.  Returns ``do_L2norm`` (inferred from 'L2norm' in ``string_factory``).
 
-        The reference's GPU work-around (normalise the column with numpy, strip "L2norm" from the
-        factory; meerqat/ir/search.py:238-244) is unnecessary here: the "L2norm," transform is
-        applied on device while packing (csrc/knn.hip), for any ``device``.  ``tie_order`` (extra key, "id_asc" |
+        The "L2norm," transform is applied on device while packing (csrc/knn.hip), in the arithmetic the reference would have
+        used for the same ``device`` key: with ``device: null`` (every shipped config) FAISS's own NormalizationTransform
+        normalises the KB rows on add and the queries on search -- ``x * float(1.0 / sqrt(sum x^2))``, a zero row stays a
+        zero row (``l2norm_form="faiss"``); with a ``device``, the reference's GPU work-around (meerqat/ir/search.py:238-244)
+        normalises the column with numpy's ``L2norm`` instead -- ``x / sqrt(sum x^2)``, a zero row becomes NaN
+        (``l2norm_form="numpy"``).  ``l2norm_form`` (extra key) overrides the choice.  ``tie_order`` (extra key, "id_asc" |
         "id_desc"): which of several EXACTLY tied rows ranks first -- this library's policy knob, see
         viquae_amd.index.MI355XFlatIndex and INTEGRATION.md section D."""
         if kwargs:
@@ -147,18 +150,22 @@ class KnowledgeBase:
         # which index class serves `device` (one GPU, all GPUs of this process, or this rank's shard of a
         # torch.distributed job): viquae_amd.sharded.make_flat_index
         from ..sharded import ShardedFlatIndex, make_flat_index
+        if l2norm_form is None and do_L2norm:
+            l2norm_form = "faiss" if device is None else "numpy"
         if load:
             if file is None:
                 raise ValueError("load=True needs `file` (the path passed to save_faiss_index / save_path)")
-            index = make_flat_index(device=device, string_factory=string_factory, metric_type=metric_type, tie_order=tie_order)
+            index = make_flat_index(device=device, string_factory=string_factory, metric_type=metric_type, tie_order=tie_order,
+                                    l2norm_form=l2norm_form)
             if isinstance(index, ShardedFlatIndex):
                 index.load_rows(file)  # every rank reads only its own row range
             elif isinstance(index, MI355XFlatIndex):
-                index = MI355XFlatIndex.load(file, device=device, tie_order=tie_order)
+                index = MI355XFlatIndex.load(file, device=device, tie_order=tie_order, l2norm_form=l2norm_form)
             else:
                 index.load_rows(file)  # LocalShardsFlatIndex: metric and "L2norm," from the file, set on EVERY shard
         else:
-            index = make_flat_index(device=device, string_factory=string_factory, metric_type=metric_type, tie_order=tie_order)
+            index = make_flat_index(device=device, string_factory=string_factory, metric_type=metric_type, tie_order=tie_order,
+                                    l2norm_form=l2norm_form)
             index.add_vectors(self.dataset, column=column, batch_size=batch_size, train_size=train_size,
                               faiss_verbose=faiss_verbose)
             if save_path is not None:

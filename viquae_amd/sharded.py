@@ -143,7 +143,7 @@ class _ShardedBase(BaseIndex):
 
 class ShardedFlatIndex(_ShardedBase):
     def __init__(self, string_factory: Optional[str] = None, metric_type: Optional[int] = None, group=None,
-                 local_index=None, merge_fn=None, device=None, screen=None, always_gather=False, tie_order=None):
+                 local_index=None, merge_fn=None, device=None, screen=None, always_gather=False, tie_order=None, l2norm_form=None):
         import torch.distributed as dist
         self.group = group
         # always_gather: run the collective and the record merge even with ONE rank (tests / 1-GPU profiling of the N>1 path)
@@ -156,7 +156,7 @@ class ShardedFlatIndex(_ShardedBase):
         if local_index is None:
             from .index import _resolve_device
             local_index = MI355XFlatIndex(device=device, string_factory=string_factory, metric_type=metric_type, screen=screen,
-                                          tie_order=tie_order)
+                                          tie_order=tie_order, l2norm_form=l2norm_form)
             # resolved NOW: a rank whose shard turns out empty still needs a device for its records
             local_index._torch_device = _resolve_device(device)
         self.local = local_index
@@ -335,7 +335,7 @@ class LocalShardsFlatIndex(_ShardedBase):
     copied peer-to-peer to the first device, merged there."""
 
     def __init__(self, devices, string_factory: Optional[str] = None, metric_type: Optional[int] = None, screen=None,
-                 allow_repeated_devices=False, tie_order=None):
+                 allow_repeated_devices=False, tie_order=None, l2norm_form=None):
         import torch
         from . import _lib
         _lib.require_gpu()
@@ -351,7 +351,7 @@ class LocalShardsFlatIndex(_ShardedBase):
         self.string_factory = string_factory
         self.do_l2norm = parse_string_factory(string_factory)
         self.shards = [MI355XFlatIndex(device=g, string_factory=string_factory, metric_type=metric_type, screen=screen,
-                                       tie_order=tie_order) for g in devices]
+                                       tie_order=tie_order, l2norm_form=l2norm_form) for g in devices]
         self.tie_order = self.shards[0].tie_order
         for sh, g in zip(self.shards, devices):
             sh._torch_device = torch.device("cuda", g)
@@ -459,7 +459,7 @@ def visible_gpus():
     return list(range(torch.cuda.device_count()))
 
 
-def make_flat_index(device=None, string_factory=None, metric_type=None, screen=None, tie_order=None):
+def make_flat_index(device=None, string_factory=None, metric_type=None, screen=None, tie_order=None, l2norm_form=None):
     """The index ``KnowledgeBase.add_or_load_faiss_index`` builds, chosen as the reference's ``device``
     key is documented (datasets/search.py:315-347: int >= 0 -> that GPU, int < 0 -> all GPUs, list ->
     those GPUs; None = CPU FAISS there, the process's current GPU here):
@@ -472,6 +472,8 @@ def make_flat_index(device=None, string_factory=None, metric_type=None, screen=N
     kw = dict(string_factory=string_factory, metric_type=metric_type, screen=screen)
     if tie_order is not None:  # only forwarded when asked for: "id_asc" is every class's default
         kw["tie_order"] = tie_order
+    if l2norm_form is not None:  # arithmetic of the "L2norm," prefix (viquae_amd.index.MI355XFlatIndex)
+        kw["l2norm_form"] = l2norm_form
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         return ShardedFlatIndex(device=None, **kw)
     if isinstance(device, int) and not isinstance(device, bool) and device < 0:
