@@ -151,7 +151,9 @@ def cpu_baseline(idx, Q, seconds):
                               1024 database rows through the host BLAS's sgemm (torch.mm = MKL, all cores), then FAISS's
                               strict-'>' heap rule per query in C / OpenMP (oracle_heap_add_block) -- the faster leg, and
                               the one `value` reports.
-    Neither is FAISS itself (not installable here): kind = "port (FAISS organisation)"."""
+    Neither is FAISS itself.  When `import faiss` works on the box (then "the reference path verbatim"), a
+    third leg runs first and wins: IndexFlatIP.add + .search in the reference's own call shape -- batches of 256 queries
+    (experiments/ir/viquae/dpr/search/config.json:25) -- kind = "faiss"; it never is in this image."""
     from oracle import knn as ok
     import torch
     cpus = host_cpus()
@@ -204,12 +206,26 @@ def cpu_baseline(idx, Q, seconds):
     except Exception as e:
         legs["faiss_organisation"] = {"value": 0.0, "what": f"failed: {e!r}"}
     best = max(legs, key=lambda n: legs[n]["value"])
+    try:
+        import faiss  # the reference's own dependency (requirements.txt:14); absent from this image
+        faiss.omp_set_num_threads(cpus["usable_threads"])
+
+        def faiss_leg(X, Qq):
+            index = faiss.IndexFlatIP(X.shape[1])
+            index.add(np.ascontiguousarray(X, np.float32))
+            for s0 in range(0, Qq.shape[0], 256):
+                index.search(np.ascontiguousarray(Qq[s0:s0 + 256], np.float32), TOPK)
+        legs["faiss"] = leg(faiss_leg, 1 << 16, seconds * 0.7, f"faiss {getattr(faiss, '__version__', '?')} IndexFlatIP.add + .search in batches "
+                            f"of 256 queries, {cpus['usable_threads']} OpenMP threads (add included)")
+        best, used_threads = "faiss", cpus["usable_threads"]
+    except ImportError:
+        pass
     rec = {
         # `cores` = the threads the reported leg's matrix product actually ran on (its heap pass and the chain oracle use
         # every OpenMP thread); the machine is described once in `host`
         "value": legs[best]["value"], "unit": "queries/s",
-        "cores": used_threads if best == "faiss_organisation" else threads, "threads": threads,
-        "kind": "port (FAISS organisation)" if best == "faiss_organisation" else "port",
+        "cores": used_threads if best in ("faiss_organisation", "faiss") else threads, "threads": threads,
+        "kind": "faiss" if best == "faiss" else "port (FAISS organisation)" if best == "faiss_organisation" else "port",
         "host": cpus,
         "sample": f"{best}: {legs[best]['what']}; {nq} queries x the first {legs[best]['kb_rows_sampled']} KB rows, top-{TOPK}: "
                   f"{legs[best]['seconds']} s ({legs[best]['gflops']} GFLOP/s); scaled by rows to {idx.ntotal} x {DIM}",
@@ -495,6 +511,52 @@ def main():
         del small, sidx
 
     # the other exact path, timed next to the headline (rank 0, N = 1): a few steps are enough
+    # The reference's own call size: Dataset.map hands KnowledgeBase.search_batch 256 questions at a time
+    # (experiments/ir/viquae/dpr/search/config.json:25 -> meerqat/ir/search.py:146).  One query tile = the KB is streamed once per
+    # search: the regime north_star's "HBM-read roofline" is about.  Same shard, same C-ABI call, HIP events around the scan.
+    small_batch = None
+    if world == 1 and mode == "screened":
+        try:
+            nqs, reps = 256, 30
+            qs = Q[:nqs].contiguous()
+            outs = (torch.empty((nqs, k), dtype=torch.float32, device=device), torch.empty((nqs, k), dtype=torch.int64, device=device))
+            for _ in range(5):
+                local_step(q=qs, out=outs)
+            evs_s = make_events(reps)
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            for a_, b_ in evs_s:
+                local_step(a_, b_, q=qs, out=outs)
+            torch.cuda.synchronize()
+            call_ms = (time.perf_counter() - ts0) / reps * 1e3
+            k_ms = sum(a_.elapsed_time(b_) for a_, b_ in evs_s) / reps
+            kb_bytes = rows * DIM * 2  # the bf16 screening copy, read once
+            kind = int(lib.mq_knn_screen_scan_kind(rows, DIM, nqs, k, 0))
+            # the same search through the 256 x 256 tile kernel (MQ_KNN_SMALL=0), same process, for the A/B the notes quote
+            os.environ["MQ_KNN_SMALL"] = "0"
+            try:
+                for _ in range(3):
+                    local_step(q=qs, out=outs)
+                evs_t = make_events(reps)
+                torch.cuda.synchronize()
+                for a_, b_ in evs_t:
+                    local_step(a_, b_, q=qs, out=outs)
+                torch.cuda.synchronize()
+                tile_ms = sum(a_.elapsed_time(b_) for a_, b_ in evs_t) / reps
+            finally:
+                del os.environ["MQ_KNN_SMALL"]
+            small_batch = {
+                "workload": f"{nqs} queries (the reference's Dataset.map batch) x {rows}x{DIM} KB, exact IP top-{k}, one C-ABI call",
+                "scan_kernel": {0: "none", 1: "screen_scan_kernel (256 x 256 tiles)", 2: "screen_small_kernel<12> (queries in registers, LDS ring of 32-row tiles)"}.get(kind, str(kind)),
+                "ms": round(call_ms, 4), "queries_per_s": round(nqs / call_ms * 1e3, 1),
+                "scan_kernel_ms": round(k_ms, 4),
+                "algorithmic_hbm_bytes": kb_bytes, "achieved_gbps": round(kb_bytes / (k_ms * 1e-3) / 1e9, 1),
+                "hbm_frac": round(kb_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                "mfma_frac": round(2.0 * nqs * rows * DIM / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                "tile_kernel_scan_ms": round(tile_ms, 4),
+            }
+        except Exception as e:  # never a reason to lose the line
+            small_batch = {"error": repr(e)}
     other = None
     if world == 1 and not args.no_other_path:
         which = "exact_f32" if mode == "screened" else "screened"
@@ -592,6 +654,8 @@ def main():
             local._ws = keep
             rec["config"]["screen"] = {"query_tiles_recomputed_exactly": st[0], "candidates_rescored_per_query": round(st[1] / nqc, 1),
                                        "max_candidates_of_a_query": st[2]}
+        if small_batch is not None:
+            rec.setdefault("secondary", {})["small_batch"] = small_batch
         if other is not None:
             rec["other_exact_path"] = other
             if other["path"] == "exact_f32":
@@ -680,7 +744,7 @@ def main():
                     encode_surface = bench_encode_surface.main()
                 except Exception as e:
                     encode_surface = {"error": repr(e)}
-                rec["secondary"] = {
+                rec.setdefault("secondary", {}).update({
                     "reference_call_surface": surface,
                     "encode_call_surface": encode_surface,
                     "dpr_like_data": dpr_like,
@@ -702,9 +766,9 @@ def main():
                     "titles_encoded_per_s": round(tt["titles_per_s"], 1),
                     "clip_text": {"workload": "CLIP ViT-B/32 text tower, 2048 x 77 synthetic tokens per batch (causal)",
                                   "ms_per_batch": round(tt["ms_per_batch"], 2), "algorithmic_tflops": round(tt["tflops"], 2)},
-                }
+                })
             except Exception as e:
-                rec["secondary"] = {"error": repr(e)}
+                rec.setdefault("secondary", {})["error"] = repr(e)
         # The CPU legs come LAST: whatever they leave behind in the process (128-thread BLAS / OpenMP pools, Hugging Face
         # models) cost the host-bound call-surface legs a third of their rate when it ran before them (map_arrow 300 k -> 170-200 k
         # queries/s, measured); the GPU legs above do not care, the CPU legs neither.
