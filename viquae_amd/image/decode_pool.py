@@ -13,6 +13,7 @@ The slots are anonymous shared mappings created BEFORE the fork (so every worker
 runtime as page-locked, which makes the host -> device copy of a packed batch a plain asynchronous DMA.  Workers never touch the
 GPU.  A worker reproduces `meerqat.data.loading.load_image` (:108-119): unreadable or empty images are reported and become
 `None` in the output, with the same warning text issued by the parent."""
+import errno
 import mmap
 import multiprocessing as mp
 import os
@@ -21,6 +22,9 @@ import warnings
 import numpy as np
 
 _SLOTS = []   # the staging mappings; inherited by the forked workers
+
+
+_MAX_OPEN = 128  # lazily opened images a worker keeps between the `sizes` and the `decode` phase
 
 
 def _worker(conn, slots):
@@ -40,13 +44,24 @@ def _worker(conn, slots):
             out = []
             for n, path in enumerate(paths):
                 try:
+                    # Lazily opened images keep their file descriptor until they are decoded.  Only a bounded number stays open
+                    # between the two phases (a worker with a 1000-image chunk would pass the usual RLIMIT_NOFILE of 1024, and
+                    # the EMFILE would be reported as an unreadable image): the rest is closed here and reopened in `decode`.
                     im = Image.open(path)
                     w, h = im.size
                     if w < 1 or h < 1:
+                        im.close()
                         out.append((None, f"Empty image '{path}'"))
                         continue
+                    if len(opened) >= _MAX_OPEN:
+                        im.close()
+                        im = None
                     opened[base + n] = (im, path)
                     out.append(((h, w), None))
+                except OSError as e:
+                    if e.errno in (errno.EMFILE, errno.ENFILE, errno.ENOMEM):
+                        raise  # resource exhaustion is not "this image is unreadable"
+                    out.append((None, f"Caught exception '{e}' with image '{path}'"))
                 except Exception as e:  # noqa: BLE001 - load_image catches everything too
                     out.append((None, f"Caught exception '{e}' with image '{path}'"))
             conn.send(out)
@@ -57,6 +72,8 @@ def _worker(conn, slots):
             for idx, off in items:
                 im, path = opened.pop(idx)
                 try:
+                    if im is None:
+                        im = Image.open(path)
                     # load_image's `.convert('RGB')` is the identity on an RGB file: skip its full-size copy there
                     a = np.asarray(im if im.mode == "RGB" else im.convert("RGB"))
                     n = a.shape[0] * a.shape[1] * 3

@@ -65,7 +65,8 @@ def dataset_embed(dataset_path, map_kwargs={}, model_kwargs={}, transform_kwargs
         dataset = dataset.remove_columns([c for c in dataset.column_names if c not in keep_columns])
     # the decode workers of the pipeline are forked FIRST, while this process owns no page-locked memory (decode_pool.py)
     from .decode_pool import early_pool
-    workers = early_pool(processes, int(map_kwargs.get("batch_size", 1000)))
+    from ..pipeline import _map_batch_size
+    workers = early_pool(processes, _map_batch_size(map_kwargs)) if _map_batch_size(map_kwargs) is not None else None
     fn_kwargs.update(get_model_and_transform(model_kwargs=model_kwargs, transform_kwargs=transform_kwargs))
     from ..ir.embedding import _rank_shard, _save_rank_shards, process_rank_and_world
     rank, world = process_rank_and_world()
@@ -79,6 +80,10 @@ def dataset_embed(dataset_path, map_kwargs={}, model_kwargs={}, transform_kwargs
     if pipe is None and workers is not None:
         workers.close()
     if pipe is not None:
+        map_kwargs = dict(map_kwargs)
+        if "new_fingerprint" not in map_kwargs:  # see viquae_amd/ir/embedding.py: never pickle the pipeline (model + column) for a hash
+            from datasets.fingerprint import generate_random_fingerprint
+            map_kwargs["new_fingerprint"] = generate_random_fingerprint()
         try:
             dataset = dataset.map(pipe.embed, batched=True, with_indices=True, **map_kwargs)
         finally:

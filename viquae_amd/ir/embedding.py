@@ -175,6 +175,13 @@ def dataset_embed(dataset_path, map_kwargs={}, output_path=None, keep_columns=No
     from ..pipeline import text_pipeline_or_none
     pipe = text_pipeline_or_none(dataset, map_kwargs, **fn_kwargs)
     if pipe is not None:
+        # `datasets` fingerprints the mapped function by pickling it: for the bound method of the pipeline that is the model's
+        # weights AND the whole text column (seconds and gigabytes for a passage KB), and the hash would depend on run state,
+        # so the map cache could never hit anyway.  A fresh fingerprint instead, unless the caller names one.
+        map_kwargs = dict(map_kwargs)
+        if "new_fingerprint" not in map_kwargs:
+            from datasets.fingerprint import generate_random_fingerprint
+            map_kwargs["new_fingerprint"] = generate_random_fingerprint()
         try:
             dataset = dataset.map(pipe.embed, batched=True, with_indices=True, **map_kwargs)
         finally:

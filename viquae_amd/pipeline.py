@@ -383,6 +383,19 @@ def _plain_dataset(dataset, map_kwargs):
             and not map_kwargs.get("with_rank") and not map_kwargs.get("input_columns") and not map_kwargs.get("with_indices"))
 
 
+def _map_batch_size(map_kwargs):
+    """``Dataset.map``'s batch size, or None when the pipeline does not apply: ``batch_size=None`` means "the whole dataset as one
+    batch" there (nothing to pipeline), and a non-positive value is the caller's business."""
+    bs = map_kwargs.get("batch_size", 1000)
+    if bs is None or isinstance(bs, bool):
+        return None
+    try:
+        bs = int(bs)
+    except (TypeError, ValueError):
+        return None
+    return bs if bs > 0 else None
+
+
 def text_pipeline_or_none(dataset, map_kwargs, model=None, tokenizer=None, tokenization_kwargs={}, key="passage",
                           save_as="text_embedding", output_key=None, forward_kwargs={}, layers=None, kb=None, call=None, run=None,
                           qe_predictions_key=None, **other):
@@ -391,6 +404,8 @@ def text_pipeline_or_none(dataset, map_kwargs, model=None, tokenizer=None, token
     then maps the serial ``embed``)."""
     if not pipeline_enabled() or other or layers is not None or kb is not None or run is not None or qe_predictions_key is not None:
         return None
+    if _map_batch_size(map_kwargs) is None or getattr(tokenizer, "truncation_side", "right") != "right":
+        return None  # (the fast tokenizer path truncates on the right like the tokenizer's default; anything else: the serial embed)
     if model is None or tokenizer is None or not torch.cuda.is_available() or not _plain_dataset(dataset, map_kwargs):
         return None
     from .ir.embedding import is_multimodal
@@ -401,7 +416,7 @@ def text_pipeline_or_none(dataset, map_kwargs, model=None, tokenizer=None, token
     if first is None or not first.is_cuda or _arrow_strings(dataset, key) is None:
         return None
     return TextEmbedPipeline(dataset, model, tokenizer, tokenization_kwargs, key, save_as, output_key, forward_kwargs, call,
-                             int(map_kwargs.get("batch_size", 1000)))
+                             _map_batch_size(map_kwargs))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -443,7 +458,9 @@ class ImageEmbedPipeline:
             except Exception as e:  # noqa: BLE001 - e.g. not enough lockable memory: decode in threads instead
                 import warnings
                 warnings.warn(f"image decode processes unavailable ({e!r}): decoding in threads")
-        if self.decode is None and pool is None:
+        if pool is None:
+            # also beside the decode processes: a batch whose packed bytes exceed the staging slots (images larger than the slots
+            # were sized for) is decoded here, by a few threads -- not one image after the other inside the prefetch thread
             from concurrent.futures import ThreadPoolExecutor
             self.threads = ThreadPoolExecutor(max(1, int(os.environ.get("MQ_IMAGE_DECODE_THREADS", min(8, os.cpu_count() or 1)))))
         self._slot_busy = {}
@@ -461,7 +478,7 @@ class ImageEmbedPipeline:
             return kept, set(), None, None
         geom, totals = self.transform.plan(np.array([sizes[i] for i in kept], dtype=np.int64))
         if int(totals[0]) > self.decode.slot_bytes:
-            return None  # larger images than the slots were sized for: this batch takes the thread path
+            return None  # larger images than the slots were sized for: this batch takes the thread (or caller's pool) path
         slot = self.decode.take_slot()
         busy = self._slot_busy.pop(slot, None)
         if busy is not None:      # the copy that last read this slot (two batches ago) must be over before it is rewritten
@@ -566,5 +583,7 @@ def image_pipeline_or_none(dataset, map_kwargs, model=None, transform=None, save
         return None
     if not torch.cuda.is_available() or not _plain_dataset(dataset, map_kwargs) or _arrow_strings(dataset, image_key) is None:
         return None
-    return ImageEmbedPipeline(dataset, model, transform, save_as, image_key, call, pool, int(map_kwargs.get("batch_size", 1000)),
+    if _map_batch_size(map_kwargs) is None:
+        return None
+    return ImageEmbedPipeline(dataset, model, transform, save_as, image_key, call, pool, _map_batch_size(map_kwargs),
                               decode_procs=decode_procs, decode_pool=decode_pool)

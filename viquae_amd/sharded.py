@@ -125,13 +125,52 @@ class _ShardedBase(BaseIndex):
         raise TypeError(f"{type(self).__name__} lives in HBM and cannot be pickled: use save()")
 
     def search_batch(self, queries, k: int = 10, **kwargs) -> BatchedSearchResults:
+        """The host boundary of MI355XFlatIndex.search_batch: page-locked staging buffers kept by the index, asynchronous copies
+        on the search stream, ONE synchronisation (not a pageable upload and two blocking downloads per batch)."""
         import torch
+        from .index import _PINNED_IO_MAX_QUERIES
         queries = np.asarray(queries)
         if len(queries.shape) != 2:
             raise ValueError("Shape of query must be 2D")
-        q = torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32)).to(self._query_device())
-        D, I = self.search_device(q, k)
-        return BatchedSearchResults(D.cpu().numpy(), I.cpu().numpy().astype(int))
+        dev = self._query_device()
+        nq, d = queries.shape
+        on_gpu = torch.device(dev).type == "cuda"  # (the gloo CPU tests serve the local index from the oracle: plain copies there)
+        if not on_gpu or nq == 0 or nq > _PINNED_IO_MAX_QUERIES:
+            q = torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32)).to(dev)
+            D, I = self.search_device(q, k)
+            if on_gpu:
+                torch.cuda.current_stream(dev).synchronize()
+            return BatchedSearchResults(D.cpu().numpy(), I.cpu().numpy().astype(int))
+        io = getattr(self, "_io", None)
+        if io is None or io[0].shape[0] < nq or io[0].shape[1] != d or io[2].shape[1] != k or io[1].device != dev:
+            cap = max(256, 1 << (int(nq) - 1).bit_length())
+            io = self._io = (torch.empty((cap, d), dtype=torch.float32).pin_memory(), torch.empty((cap, d), dtype=torch.float32, device=dev),
+                             torch.empty((cap, k), dtype=torch.float32).pin_memory(), torch.empty((cap, k), dtype=torch.int64).pin_memory())
+        q_pin, q_dev, D_pin, I_pin = io
+        np.copyto(q_pin[:nq].numpy(), queries, casting="same_kind" if queries.dtype.kind == "f" else "unsafe")
+        with torch.cuda.device(dev):
+            q_dev[:nq].copy_(q_pin[:nq], non_blocking=True)
+            D, I = self.search_device(q_dev[:nq], k)
+            D_pin[:nq].copy_(D, non_blocking=True)
+            I_pin[:nq].copy_(I, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        return BatchedSearchResults(D_pin[:nq].numpy().copy(), I_pin[:nq].numpy().astype(int))
+
+    def _chunk_buffers(self, n, k, dev, slot):
+        """(record, gathered) of one <= 4096-query chunk, kept per (n, k) in two alternating slots: chunk i's buffers are still
+        being gathered / merged while chunk i + 1 scans into the other pair."""
+        import torch
+        cache = self.__dict__.setdefault("_chunk_cache", {})
+        key = (n, k, str(dev), slot)
+        buf = cache.get(key)
+        if buf is None:
+            if len(cache) > 16:
+                cache.clear()
+            rec_bytes, _ = record_layout(n, k)
+            record = torch.empty(rec_bytes, dtype=torch.uint8, device=dev)
+            gathered = torch.empty(self.world * rec_bytes, dtype=torch.uint8, device=dev) if (self.world > 1 or getattr(self, "always_gather", False)) else record
+            buf = cache[key] = (record, gathered)
+        return buf
 
     def search(self, query, k: int = 10, **kwargs) -> SearchResults:
         query = np.asarray(query)
@@ -266,17 +305,16 @@ class ShardedFlatIndex(_ShardedBase):
             D[s:s + n].copy_(Dm)
             I[s:s + n].copy_(Im)
 
-        for s, e in query_chunks(nq, chunk):
+        for ci, (s, e) in enumerate(query_chunks(nq, chunk)):
             q = queries[s:e]
             n = e - s
-            rec_bytes, _ = record_layout(n, k)
-            record = torch.empty(rec_bytes, dtype=torch.uint8, device=dev)
+            # the chunk two back has been merged (finish() below runs before the next scan is enqueued on the same stream)
+            record, gathered = self._chunk_buffers(n, k, dev, ci & 1)
             self._scan(q, k, record)
             if self.world > 1 or self.always_gather:
-                gathered = torch.empty(self.world * rec_bytes, dtype=torch.uint8, device=dev)
                 work = dist.all_gather_into_tensor(gathered, record, group=self.group, async_op=True)
             else:
-                gathered, work = record, None
+                work = None
             if pending is not None:
                 finish(pending)
             pending = (work, gathered, s, n)
