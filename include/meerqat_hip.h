@@ -417,6 +417,28 @@ int mq_diag_mfma_bf16_loop(int iters, int random_operands, int workgroups, float
  * instruction's undocumented internal summation). */
 int mq_diag_mfma_bf16_dot(const uint16_t *A_dev, const uint16_t *B_dev, int dp, float *out_dev, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * ArcFace r50 face encoder (meerqat/image/face_recognition.py:44-102; insightface arcface_torch IResNet-50 and OpenCV /
+ * scikit-image are un-vendored and not installable here: parity unpinned, oracle/arcface.py restates the published algorithms).
+ * A convolution = mq_im2col_split_f32 (patch gather + the layer's elementwise pre-operations -> the GEMM's split pair) followed
+ * by mq_gemm_nt_bf16x3s_f32 (BatchNorms behind the convolution folded into W / bias, residual in the epilogue); NHWC.
+ *   x_dev   fp32 activation, NHWC [B, H, W, C] (nchw != 0: NCHW [B, C, H, W], the network's input)
+ *   A       rows = B * Ho * Wo output pixels (Ho = (H + 2 pad - KH) / stride + 1), column (kh * KW + kw) * C + c, zero beyond
+ *           KH * KW * C up to Kpad (a multiple of 32); PAIR LAYOUT, mq_split_bf16_tiled_elems(rows, Kpad) elements per array
+ *   pre-operations on every in-bounds element, in this order: PReLU (prelu_slope_dev [C] or NULL), then x * scale + shift
+ *           (scale_dev / shift_dev [C], both or neither: an eval-mode BatchNorm in front of the convolution); padding is zero.
+ * mq_warp_affine_faces_f32: cv2.warpAffine(image, M, (size, size), borderValue = 0) in OpenCV's fixed-point bilinear
+ * arithmetic + ToTensor + Normalize(0.5, 0.5) for `nfaces` faces.  images_dev: the decoded RGB images of a batch packed in one
+ * uint8 buffer (image i = H_i x W_i x 3 at byte offsets_dev[i], hw_dev[2 i] = H_i, hw_dev[2 i + 1] = W_i); face f is cut from image
+ * face_image_dev[f] with the INVERTED 2 x 3 matrix minv_dev[6 f ..] (doubles); out_dev fp32 [nfaces, 3, size, size].
+ * ------------------------------------------------------------------------------------------- */
+int mq_im2col_split_f32(const float *x_dev, int B, int H, int W, int C, int nchw, int KH, int KW, int stride, int pad,
+                        const float *prelu_slope_dev, const float *scale_dev, const float *shift_dev, uint16_t *Ah_dev,
+                        uint16_t *Al_dev, int Kpad, void *stream);
+int mq_warp_affine_faces_f32(const uint8_t *images_dev, const int64_t *offsets_dev, const int32_t *hw_dev,
+                             const int32_t *face_image_dev, const double *minv_dev, int nfaces, int size, float *out_dev,
+                             void *stream);
+
 #ifdef __cplusplus
 }
 #endif

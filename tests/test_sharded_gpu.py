@@ -109,8 +109,13 @@ def test_knowledge_base_device_minus_one_and_device_list():
         kb = KnowledgeBase(dataset=ds, index_kwargs={"idx": {"column": "vec", "string_factory": "L2norm,Flat", "device": device,
                                                              "metric_type": 0}})
         res.append(kb.search_batch("idx", Q, k=100))
-    for D, I in res[1:]:
-        assert np.array_equal(I, res[0][1]) and np.array_equal(D, res[0][0])
+    # 0, -1 and [0] name the same device: the reference's GPU work-around (numpy's L2norm on the column) -- equal bit for bit.
+    for D, I in res[2:]:
+        assert np.array_equal(I, res[1][1]) and np.array_equal(D, res[1][0])
+    # `device: null` is FAISS's own NormalizationTransform (x * float(1.0 / sqrt(nr))): the same neighbours, scores within the
+    # last bits of the other arithmetic (tests/test_l2norm_forms_gpu.py pins each form against its oracle)
+    assert np.array_equal(res[0][1], res[1][1]) and np.allclose(res[0][0], res[1][0], rtol=0, atol=3e-7)
+    assert not np.array_equal(res[0][0], res[1][0])
 
 
 def test_faiss_file_written_by_the_reference_loads(tmp_path):
@@ -119,7 +124,7 @@ def test_faiss_file_written_by_the_reference_loads(tmp_path):
     from oracle import knn as ok
     from viquae_amd.index import MI355XFlatIndex
     rng = np.random.default_rng(6)
-    X = ok.l2norm_rows(rng.standard_normal((1000, 48), dtype=np.float32))   # what the FAISS file stores: normalised rows
+    X = ok.l2norm_rows(rng.standard_normal((1000, 48), dtype=np.float32), form="faiss")   # what the FAISS file stores: normalised rows
     Q = rng.standard_normal((25, 48), dtype=np.float32)
 
     def hdr(d, n, metric):
@@ -131,7 +136,8 @@ def test_faiss_file_written_by_the_reference_loads(tmp_path):
     idx = MI355XFlatIndex.load(str(p))
     assert idx.do_l2norm and idx.metric_type == 0 and idx.ntotal == 1000
     D, I = idx.search_batch(Q, 20)
-    Do, Io = ok.knn(X, ok.l2norm_rows(Q), 20, metric=0)
+    assert idx.l2norm_form == "faiss"  # a stored IndexPreTransform is FAISS's object: its queries take FAISS's NormalizationTransform
+    Do, Io = ok.knn(X, ok.l2norm_rows(Q, form="faiss"), 20, metric=0)
     assert np.array_equal(I, Io) and np.array_equal(D, Do)
 
 

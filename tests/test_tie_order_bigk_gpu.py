@@ -316,7 +316,8 @@ def test_save_in_faiss_format_and_load_back(tmp_path, metric, factory):
     got2 = kb2.search_batch("idx", Q, k=60)
     assert np.array_equal(got2[1], want[1]) and np.array_equal(got2[0], want[0])
     # a multi-shard index writes the same file
-    sh = LocalShardsFlatIndex([0, 0, 0], string_factory=factory, metric_type=metric, allow_repeated_devices=True)
+    sh = LocalShardsFlatIndex([0, 0, 0], string_factory=factory, metric_type=metric, allow_repeated_devices=True,
+                              l2norm_form="faiss")  # what KnowledgeBase asked for above (`device` absent = null)
     sh.add_vectors(X)
     sh.save(str(tmp_path / "kb_shards.faiss"))
     assert open(str(tmp_path / "kb_shards.faiss"), "rb").read() == open(path, "rb").read()

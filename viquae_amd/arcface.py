@@ -1,0 +1,173 @@
+"""ArcFace r50 (insightface `arcface_torch` IResNet-50) on MI355X -- the model behind ``meerqat.image.face_recognition``
+(meerqat/image/face_recognition.py:55-61: ``get_model('r50', fp16=True)`` + ``backbone.pth``).
+
+Every convolution runs as a GEMM on the split-bf16 matrix-pipe kernels of csrc/encoder.hip (three bf16 MFMA products per fp32
+product: fp32-class accuracy, where the reference runs fp16 autocast): activations are NHWC, so the GEMM's output
+``[B * Ho * Wo, Cout]`` IS the next layer's input; the patch matrix is written by ``mq_im2col_split_f32`` (csrc/conv.hip) directly as
+the (hi, lo) pair the GEMM streams, with the layer's elementwise pre-operations applied on the way.  BatchNorms are eval-mode
+affines: the one BEHIND a convolution is folded into its weights and bias here, at load (exact); the one IN FRONT of a
+convolution (IBasicBlock.bn1, the final bn2) and PReLU ride on the im2col.  An IBasicBlock is thus four launches:
+
+    A1 = im2col3x3(bn1(x));  y1 = A1 . (a2 W1)^T + b2;  A2 = im2col3x3(prelu(y1), stride);  x' = A2 . (a3 W2)^T + b3 + identity
+
+(+ two for the strided 1 x 1 downsample of a stage's first block), the head one 7 x 7 "convolution" = flatten + fc + BN1d.
+
+Parity: arcface_torch is not vendored by the reference and not installable here -- ``oracle/arcface.py`` restates the PUBLISHED
+definition (parity unpinned); ``tests/test_arcface_gpu.py`` holds this module to that oracle within 1e-3."""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .encoders import EPI_BIAS, EPI_BIAS_RESIDUAL, SplitAct, _HipEncoder, _check_cuda, _stream, gemm_nt, split_bf16_tiled
+
+EPS = 1e-5
+LAYERS = (3, 4, 14, 3)
+
+
+def _affine(state, name):
+    """eval-mode BatchNorm ``name`` as (scale, shift) float64 arrays: y = x * scale + shift"""
+    g, b = np.asarray(state[name + ".weight"], np.float64), np.asarray(state[name + ".bias"], np.float64)
+    m, v = np.asarray(state[name + ".running_mean"], np.float64), np.asarray(state[name + ".running_var"], np.float64)
+    a = g / np.sqrt(v + EPS)
+    return a, b - m * a
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+class _Conv:
+    """One convolution as the GEMM sees it: W [Cout, Kpad] (kh, kw, cin order, the BatchNorm behind it folded in), bias [Cout]."""
+
+    def __init__(self, weight, post_bn, k, stride, pad):
+        w = np.asarray(weight, np.float64)                       # [Cout, Cin, k, k]
+        a, b = post_bn
+        w2 = w.transpose(0, 2, 3, 1).reshape(w.shape[0], -1) * a[:, None]
+        self.k_true = w2.shape[1]
+        self.kpad = (self.k_true + 31) // 32 * 32
+        if self.kpad != self.k_true:
+            w2 = np.concatenate([w2, np.zeros((w2.shape[0], self.kpad - self.k_true))], axis=1)
+        self.w2, self.b = w2.astype(np.float32), b.astype(np.float32)
+        self.cout, self.cin, self.k, self.stride, self.pad = w.shape[0], w.shape[1], k, stride, pad
+
+
+class ArcFaceR50(_HipEncoder):
+    """``model(pixel_values)`` -> fp32 [B, 512]; ``pixel_values`` fp32 [B, 3, 112, 112] in [-1, 1] on a GPU."""
+
+    image_size = 112
+    num_features = 512
+
+    def __init__(self, state, layers=LAYERS, chunk=256):
+        super().__init__()
+        state = {k: _np(v).astype(np.float32) for k, v in state.items() if not k.endswith("num_batches_tracked")}
+        self.layers, self.chunk = tuple(layers), int(chunk)
+        self._convs, self._vecs = {}, {}
+
+        def conv(name, post, k, stride, pad):
+            c = _Conv(state[name + ".weight"], _affine(state, post), k, stride, pad)
+            self._reg(name + ".w2", torch.from_numpy(c.w2))
+            self._reg(name + ".b", torch.from_numpy(c.b))
+            self._convs[name] = c
+
+        def vec(name, arr):
+            self._reg(name, torch.from_numpy(np.ascontiguousarray(arr, np.float32)))
+            self._vecs[name] = name.replace(".", "_")
+
+        conv("conv1", "bn1", 3, 1, 1)
+        vec("prelu", state["prelu.weight"])
+        for s, n in enumerate(self.layers, start=1):
+            for i in range(n):
+                p = f"layer{s}.{i}"
+                a, b = _affine(state, p + ".bn1")
+                vec(p + ".pre_scale", a)
+                vec(p + ".pre_shift", b)
+                conv(p + ".conv1", p + ".bn2", 3, 1, 1)
+                vec(p + ".prelu", state[p + ".prelu.weight"])
+                conv(p + ".conv2", p + ".bn3", 3, 2 if i == 0 else 1, 1)
+                if i == 0:
+                    conv(p + ".downsample.0", p + ".downsample.1", 1, 2, 0)
+        # head: bn2 (on the im2col) - flatten in NCHW order - fc - BatchNorm1d.  The 7 x 7 x 512 patch of the NHWC activation has
+        # column (h * 7 + w) * 512 + c where the checkpoint's fc has column c * 49 + h * 7 + w: permute once; fold `features` in.
+        a2, b2 = _affine(state, "bn2")
+        vec("head.pre_scale", a2)
+        vec("head.pre_shift", b2)
+        fa, fb = _affine(state, "features")
+        wfc = np.asarray(state["fc.weight"], np.float64).reshape(-1, 512, 7, 7).transpose(0, 2, 3, 1).reshape(-1, 512 * 49)
+        self._reg("fc.w2", torch.from_numpy((wfc * fa[:, None]).astype(np.float32)))
+        self._reg("fc.b", torch.from_numpy((np.asarray(state["fc.bias"], np.float64) * fa + fb).astype(np.float32)))
+        self.num_features = wfc.shape[0]
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_state_dict(cls, state, **kw):
+        return cls(state, **kw)
+
+    @classmethod
+    def from_pretrained(cls, weight_path, **kw):
+        """``backbone.pth`` of insightface's arcface_torch (a plain state dict), e.g. ms1mv3_arcface_r50_fp16/backbone.pth."""
+        state = torch.load(os.fspath(weight_path), map_location="cpu", weights_only=True)
+        return cls(state, **kw)
+
+    # ------------------------------------------------------------------ forward
+    def _v(self, name):
+        return getattr(self, self._vecs[name]) if name is not None else None
+
+    def _conv(self, name, x, B, H, W, nchw=False, slope=None, scale=None, shift=None, residual=None):
+        """x: fp32 [B, H, W, Cin] (or NCHW) -> ([B * Ho * Wo, Cout] fp32, Ho, Wo)"""
+        c = self._convs[name]
+        Ho, Wo = (H + 2 * c.pad - c.k) // c.stride + 1, (W + 2 * c.pad - c.k) // c.stride + 1
+        A = self._im2col(x, B, H, W, c.cin, nchw, c.k, c.k, c.stride, c.pad, c.kpad, slope, scale, shift)
+        y = gemm_nt(A, getattr(self, (name + ".w2").replace(".", "_")), bias=getattr(self, (name + ".b").replace(".", "_")),
+                    residual=residual, epilogue=EPI_BIAS_RESIDUAL if residual is not None else EPI_BIAS,
+                    wsplit=self._wsplit(name + ".w2"))
+        return y, Ho, Wo
+
+    def _wsplit(self, name):
+        w = getattr(self, name.replace(".", "_"))
+        cache = self.__dict__.setdefault("_split_cache", {})
+        key = (name, w.device, w.data_ptr())
+        if key not in cache:
+            cache[key] = split_bf16_tiled(w)
+        return cache[key]
+
+    @staticmethod
+    def _im2col(x, B, H, W, C, nchw, KH, KW, stride, pad, kpad, slope, scale, shift):
+        lib = _lib.load()
+        _check_cuda(x)
+        Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        A = SplitAct.empty(B * Ho * Wo, kpad, x.device)
+        p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        with torch.cuda.device(x.device):
+            _lib.check(lib.mq_im2col_split_f32(x.data_ptr(), B, H, W, C, int(nchw), KH, KW, stride, pad, p(slope), p(scale), p(shift),
+                                               A.hi.data_ptr(), A.lo.data_ptr(), kpad, _stream(x)), "mq_im2col_split_f32")
+        return A
+
+    def forward(self, pixel_values):
+        _check_cuda(pixel_values)
+        x = pixel_values.to(torch.float32).contiguous()
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.image_size or x.shape[3] != self.image_size:
+            raise ValueError(f"expected [B, 3, {self.image_size}, {self.image_size}] pixel values, got {tuple(x.shape)}")
+        if x.shape[0] > self.chunk:
+            return torch.cat([self._forward(x[s:s + self.chunk]) for s in range(0, x.shape[0], self.chunk)])
+        return self._forward(x)
+
+    def _forward(self, x):
+        B, H, W = x.shape[0], self.image_size, self.image_size
+        # stem: conv - BN (folded); its PReLU is applied where the result is read (the first block's im2cols)
+        y, H, W = self._conv("conv1", x, B, H, W, nchw=True)
+        pending = self._v("prelu")
+        for s, n in enumerate(self.layers, start=1):
+            for i in range(n):
+                p = f"layer{s}.{i}"
+                o1, _, _ = self._conv(p + ".conv1", y, B, H, W, slope=pending, scale=self._v(p + ".pre_scale"), shift=self._v(p + ".pre_shift"))
+                if i == 0:
+                    identity, Ho, Wo = self._conv(p + ".downsample.0", y, B, H, W, slope=pending)
+                else:
+                    assert pending is None
+                    identity = y
+                y, Ho, Wo = self._conv(p + ".conv2", o1, B, H, W, slope=self._v(p + ".prelu"), residual=identity)
+                H, W, pending = Ho, Wo, None
+        A = self._im2col(y, B, H, W, 512, False, H, W, 1, 0, H * W * 512, None, self._v("head.pre_scale"), self._v("head.pre_shift"))
+        return gemm_nt(A, self.fc_w2, bias=self.fc_b, epilogue=EPI_BIAS, wsplit=self._wsplit("fc.w2"))

@@ -16,6 +16,8 @@ from pathlib import Path
 from .. import encoders as _encoders
 
 IMAGE_PATH = Path(os.environ.get("VIQUAE_IMAGES_PATH", "data/Commons"))
+# the reference's data root (meerqat/data/loading.py:75, `<repo>/data`): where the ArcFace checkpoint is looked up
+DATA_ROOT_PATH = Path(os.environ.get("VIQUAE_DATA_ROOT", "data")).resolve()
 
 
 # the transform of experiments/image_embedding/clip/vit_config.json ("CLIPFeatureExtractor", gone from transformers 5;

@@ -1176,3 +1176,11 @@ class IntermediateLinearFusion(_MMEmbeddings):
 
 HIP_CLASSES = {"DPRContextEncoder": DPRContextEncoder, "DPRQuestionEncoder": DPRQuestionEncoder, "CLIPModel": CLIPModel,
                "ECAEncoder": ECAEncoder, "IntermediateLinearFusion": IntermediateLinearFusion}
+
+
+def __getattr__(name):
+    """``viquae_amd.encoders.ArcFaceR50`` (the face encoder lives in viquae_amd/arcface.py, which imports this module)."""
+    if name == "ArcFaceR50":
+        from .arcface import ArcFaceR50
+        return ArcFaceR50
+    raise AttributeError(name)

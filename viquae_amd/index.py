@@ -521,6 +521,10 @@ class MI355XFlatIndex(BaseIndex):
         (IndexFlat, and IndexPreTransform(NormalizationTransform, IndexFlat) for "L2norm,Flat")."""
         path = os.fspath(file)
         n, d, metric, l2norm, data_off = read_index_file_header(path)
+        if l2norm and l2norm_form is None:
+            # a stored "L2norm,Flat" index is the reference's CPU-FAISS object (meerqat/ir/search.py:247-248 saves, :235 loads it):
+            # its queries go through FAISS's own NormalizationTransform
+            l2norm_form = os.environ.get("MQ_KNN_L2NORM_FORM", "faiss")
         idx = cls(device=device, string_factory="L2norm,Flat" if l2norm else "Flat", metric_type=metric, tie_order=tie_order,
                   l2norm_form=l2norm_form)
         if n:

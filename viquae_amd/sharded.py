@@ -192,6 +192,7 @@ class ShardedFlatIndex(_ShardedBase):
         self.metric_type = METRIC_L2 if metric_type is None else int(metric_type)
         self.string_factory = string_factory
         self.do_l2norm = parse_string_factory(string_factory)
+        self._l2norm_form = l2norm_form  # None: the index class's default on add, FAISS's form for a loaded "L2norm,Flat" file
         if local_index is None:
             from .index import _resolve_device
             local_index = MI355XFlatIndex(device=device, string_factory=string_factory, metric_type=metric_type, screen=screen,
@@ -364,6 +365,8 @@ class ShardedFlatIndex(_ShardedBase):
             self.local.do_l2norm = False  # stored rows are already normalised
             self.local.add(rows, total_hint=hi - lo)
         self.local.do_l2norm = bool(l2norm)
+        if l2norm and hasattr(self.local, "l2norm_form"):  # like MI355XFlatIndex.load: a stored "L2norm,Flat" index is FAISS's object
+            self.local.l2norm_form = self._l2norm_form or os.environ.get("MQ_KNN_L2NORM_FORM", "faiss")
         self._set_total(n, d)
         return self
 
@@ -388,6 +391,7 @@ class LocalShardsFlatIndex(_ShardedBase):
         self.metric_type = METRIC_L2 if metric_type is None else int(metric_type)
         self.string_factory = string_factory
         self.do_l2norm = parse_string_factory(string_factory)
+        self._l2norm_form = l2norm_form
         self.shards = [MI355XFlatIndex(device=g, string_factory=string_factory, metric_type=metric_type, screen=screen,
                                        tie_order=tie_order, l2norm_form=l2norm_form) for g in devices]
         self.tie_order = self.shards[0].tie_order
@@ -450,6 +454,8 @@ class LocalShardsFlatIndex(_ShardedBase):
             self.add_vectors(np.memmap(path, dtype=np.float32, mode="r", offset=data_off, shape=(n, d)))
         for sh in self.shards:
             sh.do_l2norm = bool(l2norm)
+            if l2norm:  # like MI355XFlatIndex.load: a stored "L2norm,Flat" index is FAISS's object
+                sh.l2norm_form = self._l2norm_form or os.environ.get("MQ_KNN_L2NORM_FORM", "faiss")
         self.ntotal, self.d = n, (d or None)
         return self
 
