@@ -305,6 +305,31 @@ def load_traffic(workload_key):
         return None, None
 
 
+def profile_kernel_ms(kernel_prefix, suffix="_kernel_stats.csv"):
+    """Average launch duration (ms) of the kernel whose name starts with `kernel_prefix` in the newest TRACKED rocprofv3 summary
+    profiles/rNN<suffix> -- the number DESIGN.md quotes, shown beside the HIP-event figure of this run (they come from different
+    boxes and one of them ran under the profiler: a few per cent apart).  (None, None) when there is no such file / row."""
+    import csv
+    import glob
+    import re
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]" + suffix))]
+    if not files:
+        return None, None
+    f = max(files, key=lambda p: int(re.search(r"r(\d+)", os.path.basename(p)).group(1)))
+    try:
+        best = None
+        for row in csv.DictReader(open(f)):
+            name = row["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            if name.startswith(kernel_prefix) and float(row["AverageNs"]) > 1e5:  # (the fallback's no-op launches share a name)
+                if best is None or float(row["TotalDurationNs"]) > float(best["TotalDurationNs"]):
+                    best = row
+        if best is None:
+            return None, None
+        return round(float(best["AverageNs"]) / 1e6, 4), os.path.relpath(f, ROOT)
+    except Exception:
+        return None, None
+
+
 def spawn_ranks(args):
     """`bench.py --gpus N` started by hand: run the N ranks as children of a torch.distributed.run launcher.  Nothing in
     THIS process has touched a GPU (torch.cuda.device_count() does not initialise HIP on this image), and it never will:
@@ -554,6 +579,10 @@ def main():
                 "hbm_frac": round(kb_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
                 "mfma_frac": round(2.0 * nqs * rows * DIM / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                 "tile_kernel_scan_ms": round(tile_ms, 4),
+                "scan_kernel_ms_profile": profile_kernel_ms("screen_small_kernel", "_nq256_kernel_stats.csv")[0],
+                "scan_kernel_ms_profile_from": profile_kernel_ms("screen_small_kernel", "_nq256_kernel_stats.csv")[1],
+                "traffic": load_traffic("screened_1500000x768_nq256_k100")[0],
+                "traffic_from_profile": load_traffic("screened_1500000x768_nq256_k100")[1],
             }
         except Exception as e:  # never a reason to lose the line
             small_batch = {"error": repr(e)}
@@ -630,6 +659,8 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4),
                 "kernel_ms": round(scan_ms, 3),
+                "kernel_ms_profile": profile_kernel_ms(kernel.split("<")[0].split(" ")[0])[0],
+                "kernel_ms_profile_from": profile_kernel_ms(kernel.split("<")[0].split(" ")[0])[1],
                 "algorithmic_flops_per_launch": flops,
                 "algorithmic_hbm_bytes_per_launch": alg_bytes,
                 "hbm_frac_at_one_pass": round(alg_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
@@ -687,6 +718,15 @@ def main():
                            "passages_per_s": round(ec["passages_per_s"], 1), "ms_per_batch": round(ec["ms_per_batch"], 2)}
                 except Exception as e:
                     eca = {"error": repr(e)}
+                try:
+                    af = bench_encoders.arcface_throughput()
+                    arc = {"workload": "ArcFace r50 (IResNet-50), 256 aligned 112x112 faces per batch, seeded weights; convolutions = im2col + "
+                                       "split-bf16 GEMMs (csrc/conv.hip, csrc/encoder.hip)",
+                           "faces_per_s": round(af["faces_per_s"], 1), "ms_per_batch": round(af["ms_per_batch"], 2),
+                           "algorithmic_tflops": round(af["tflops"], 2),
+                           "executed_bf16_mfma_frac": round(3 * af["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)}
+                except Exception as e:
+                    arc = {"error": repr(e)}
                 try:
                     import bench_image
                     ip = bench_image.main()
@@ -763,6 +803,7 @@ def main():
                              "executed_bf16_mfma_frac": round(3 * c["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)},
                     "image_preprocess": dict(ip, workload="Pillow-exact bicubic resize + crop + normalise of 3072 decoded RGB images on the device (csrc/image.hip)"),
                     "eca_multimodal_encoder": eca,
+                    "arcface": arc,
                     "titles_encoded_per_s": round(tt["titles_per_s"], 1),
                     "clip_text": {"workload": "CLIP ViT-B/32 text tower, 2048 x 77 synthetic tokens per batch (causal)",
                                   "ms_per_batch": round(tt["ms_per_batch"], 2), "algorithmic_tflops": round(tt["tflops"], 2)},

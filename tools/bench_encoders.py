@@ -142,6 +142,21 @@ def clip_throughput(B=3072, steps=2, device="cuda"):
     return {"images_per_s": B / t, "ms_per_batch": t * 1e3, "batch": B, "tflops": 8.82e9 * B / t / 1e12}
 
 
+def arcface_throughput(B=256, steps=3, device="cuda"):
+    """ArcFace r50 (meerqat/image/face_recognition.py:55-61) on aligned 112 x 112 faces: seeded weights (oracle/arcface.py's
+    layout), fp32-class arithmetic.  Algorithmic work: 12.63 GFLOP per face (6.31 G multiply-adds: the 50 convolutions + fc)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import arcface as oa
+    from viquae_amd.arcface import ArcFaceR50
+    model = ArcFaceR50.from_state_dict(oa.seeded_state(0)).to(device).eval()
+    g = torch.Generator(device=device).manual_seed(4)
+    px = torch.rand((B, 3, 112, 112), generator=g, device=device) * 2 - 1
+    t = time_it(lambda: model(px), steps)
+    flops = 12.63e9
+    return {"faces_per_s": B / t, "ms_per_batch": t * 1e3, "batch": B, "tflops": flops * B / t / 1e12}
+
+
 def eca_throughput(B=2048, L=256, mean_len=130, std_len=30, steps=2, device="cuda"):
     """The reference's multimodal KB encoder as shipped (experiments/mm/eca/config.yaml:82-87: bert-base, n_faces 0, one
     clip-RN50 image feature of 1024 dims; experiments/ir/viquae/eca/embedding/kb_config.json: batch 2048, max_length 256):

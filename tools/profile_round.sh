@@ -16,6 +16,13 @@ timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- $B > $
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT -d $O/sq --output-format csv -- $B > $O/sq.log 2>&1
 timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/tcc --output-format csv -- $B > $O/tcc.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/enc --output-format csv -- python3 $R/tools/bench_encoders.py > $O/enc.log 2>&1
+# the reference's own call size: 256 queries per search (one query tile -> the streaming scan, csrc/knn_small.inc)
+S="python3 $R/tools/small_batch_search.py 256 50"
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/nq256_kt --output-format csv -- $S > $O/nq256_kt.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/nq256_fetch --output-format csv -- $S > $O/nq256_fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/nq256_write --output-format csv -- $S > $O/nq256_write.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT -d $O/nq256_sq --output-format csv -- $S > $O/nq256_sq.log 2>&1
+timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/nq256_tcc --output-format csv -- $S > $O/nq256_tcc.log 2>&1
 cd $R
 timeout 900 python3 bench.py > $O/bench.json 2> $O/bench.err
 timeout 600 python3 bench.py --mode exact_f32 --no-encoders --no-other-path > $O/bench_exact.json 2>> $O/bench.err

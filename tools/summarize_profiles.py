@@ -25,6 +25,34 @@ for sub, name in (("kt", f"{tag}_kernel_stats.csv"), ("enc", f"{tag}_encoders_ke
     f = first(f"{sub}/**/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(dst, name))
+f = first("nq256_kt/**/*kernel_stats.csv")
+if f:
+    shutil.copy(f, os.path.join(dst, f"{tag}_nq256_kernel_stats.csv"))
+
+
+def collect(subs):
+    pmc = {}
+    for sub in subs:
+        f = first(f"{sub}/**/*counter_collection.csv")
+        if not f:
+            continue
+        for row in csv.DictReader(open(f)):
+            kernel = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+            if kernel.startswith("at::") or "rocclr" in kernel or "elementwise" in kernel:
+                continue
+            c = pmc.setdefault(kernel, {}).setdefault(row["Counter_Name"], {})
+            c.setdefault("by_dispatch", {}).setdefault(row["Dispatch_Id"], 0.0)
+            c["by_dispatch"][row["Dispatch_Id"]] += float(row["Counter_Value"])
+    for kernel, counters in pmc.items():
+        for name, c in counters.items():
+            vals = list(c.pop("by_dispatch").values())
+            c.update(calls=len(vals), max_per_launch=max(vals), mean=sum(vals) / len(vals))
+    return pmc
+
+
+small = collect(("nq256_fetch", "nq256_write", "nq256_sq", "nq256_tcc"))
+if small:
+    json.dump(small, open(os.path.join(dst, f"{tag}_nq256_pmc.json"), "w"), indent=1)
 pmc = {}
 for sub in ("fetch", "write", "sq", "tcc"):
     f = first(f"{sub}/**/*counter_collection.csv")
@@ -61,6 +89,12 @@ for key, kernel in (("screened_1500000x768_nq4096_k100", "screen_scan_kernel"), 
     t = traffic(kernel)
     if t:
         out[key] = t
+# the 256-query search (its own rocprofv3 passes): the streaming scan reads every row once
+c = next((v for k_, v in small.items() if k_.startswith("screen_small_kernel")), None) if small else None
+if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    out["screened_1500000x768_nq256_k100"] = {"kernel": "screen_small_kernel<12>", "profile": f"profiles/{tag}_nq256_pmc.json",
+                                              "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"]["max_per_launch"] + c["WRITE_SIZE"]["max_per_launch"]) * 1024),
+                                              "fetch_kb_raw": c["FETCH_SIZE"]["max_per_launch"], "write_kb_raw": c["WRITE_SIZE"]["max_per_launch"]}
 if len(out) > 1:
     json.dump(out, open(os.path.join(dst, "knn_traffic.json"), "w"), indent=1)
 for a, b in (("bench.json", f"{tag}_bench_screened.json"), ("bench_exact.json", f"{tag}_bench_exact_f32.json")):
