@@ -44,6 +44,8 @@ def _both_scans(idx, Q, k):
     (65549, 768, 199, 100, 0),    # ragged: N not a multiple of 32, a partial query tile
     (70000, 512, 64, 100, 0),     # CLIP width: the 8-K-block instance (ring of four tiles); one live wave
     (90000, 64, 21, 10, 0),       # one K block, ring of six
+    (70001, 32, 200, 100, 0),     # one K block, all four waves live, both query halves (a bug of the first version: the second
+    (65536, 3, 256, 1, 1),        #   half's first fragments were read from the NEXT ring slot) -- found by tools/stress_small_scan.py
     (72345, 320, 130, 128, 0),    # five K blocks, k at the limit of the fused selection
     (66666, 700, 37, 1, 0),       # d not a multiple of 64 (zero-padded columns)
     (68000, 510, 100, 100, 1),    # L2 through two extra columns: dp = 512
