@@ -119,10 +119,15 @@ def test_save_load_roundtrip(tmp_path):
     a = _index(X, 0, "L2norm,Flat")
     p = tmp_path / "idx.mq"
     a.save(p)
-    b = MI355XFlatIndex.load(p)
+    b = MI355XFlatIndex.load(p, l2norm_form=a.l2norm_form)
     Da, Ia = a.search_batch(Q, 10)
     Db, Ib = b.search_batch(Q, 10)
     assert np.array_equal(Ia, Ib) and np.array_equal(Da, Db)
+    # without the argument a stored "L2norm," index takes FAISS's query arithmetic (the file is the reference's CPU-FAISS object)
+    c = MI355XFlatIndex.load(p)
+    assert c.l2norm_form == "faiss"
+    Dc, Ic = c.search_batch(Q, 10)
+    assert np.array_equal(Ic, Ia) and np.allclose(Dc, Da, rtol=0, atol=1e-6)
 
 
 def test_shard_merge_kernel():

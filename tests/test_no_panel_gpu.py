@@ -89,7 +89,8 @@ def test_no_panel_index_saves_and_loads(tmp_path):
     a.add_vectors(X)
     f = tmp_path / "idx.mq"
     a.save(f)
-    b = MI355XFlatIndex.load(f)
+    # a loaded "L2norm," file defaults to FAISS's query arithmetic (index.py load()); ask for this index's own to compare bits
+    b = MI355XFlatIndex.load(f, l2norm_form=a.l2norm_form)
     assert b._packed is None and b.ntotal == 5003
     Da, Ia = a.search_batch(Q, 10)
     Db, Ib = b.search_batch(Q, 10)

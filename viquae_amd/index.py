@@ -276,8 +276,9 @@ class MI355XFlatIndex(BaseIndex):
                                                          self._center.data_ptr() if self._center is not None else None, stream),
                                "mq_knn_screen_prepare")
                 self.ntotal += dev.shape[0]
-                # `dev` must outlive the kernel: synchronise before it is released
-                torch.cuda.current_stream(self._torch_device).synchronize()
+                # `dev` goes back to torch's caching allocator while the kernels may still be queued: they run on torch's
+                # current stream, and the allocator only hands the block to later work of that same stream
+            torch.cuda.current_stream(self._torch_device).synchronize()
 
     def _upload(self, part):
         import torch
@@ -303,8 +304,8 @@ class MI355XFlatIndex(BaseIndex):
                     dev.data_ptr(), dev.shape[0], self.d, self.ntotal, self._l2norm_arg(), self.metric_type, self._capacity,
                     self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(), self._xmax2.data_ptr(),
                     self._center.data_ptr() if self._center is not None else None, stream), "mq_knn_screen_add_rows_f32")
-                self.ntotal += dev.shape[0]
-                torch.cuda.current_stream(self._torch_device).synchronize()  # `dev` must outlive the kernels
+                self.ntotal += dev.shape[0]  # `dev` is released stream-ordered (see add())
+            torch.cuda.current_stream(self._torch_device).synchronize()
 
     def _l2norm_arg(self):
         """The `l2norm` argument of the row-ingest entry points: 0 or the MQ_L2NORM_* code of this index's arithmetic."""
