@@ -56,6 +56,17 @@ extern "C" {
 #define MQ_KNN_FLAG_L2NORM_QUERIES 1
 #define MQ_KNN_FLAG_TIE_ID_DESC 2
 #define MQ_KNN_FLAG_L2NORM_FAISS 4 /* the query transform in FAISS's arithmetic (below); implies MQ_KNN_FLAG_L2NORM_QUERIES */
+/* mq_knn_search_screened_f32 only: one search issued as two calls with the SAME arguments and workspace, so that a caller
+ * searching several query chunks can put the short second half of chunk i (candidates -> exact re-scoring -> exact top-k ->
+ * recomputation of flagged tiles) on another stream, under the scan of chunk i+1 (which then needs its own workspace):
+ *   MQ_KNN_FLAG_PHASE_FRONT  query preparation + the screening scan only (D, I are not written yet);
+ *   MQ_KNN_FLAG_PHASE_TAIL   everything after the scan, from the workspace the FRONT call filled (the caller orders the two:
+ *                            the TAIL stream waits for an event recorded after the FRONT call).
+ * Neither bit or both: the whole search in one call.  Searches the screen does not serve (k beyond its range, FAISS's small
+ * L2 batches) run entirely in the FRONT call; their TAIL call returns MQ_OK without work.  Results are those of the
+ * one-call search, bit for bit. */
+#define MQ_KNN_FLAG_PHASE_FRONT 8
+#define MQ_KNN_FLAG_PHASE_TAIL 16
 #define MQ_MERGE_TIE_ID_DESC 0x100
 
 /* The two arithmetics of the "L2norm," prefix -- the `l2norm` argument of mq_pack_rows_f32 / mq_knn_screen_add_rows_f32 (0 = no

@@ -52,6 +52,30 @@ def test_rccl_world1_records_gather_and_merge_equal_unsharded(rccl_world1, metri
     assert (Ie == -1).all() and (De.abs() == torch.finfo(torch.float32).max).all()
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+def test_second_halves_gather_and_merge_on_the_second_stream(rccl_world1, monkeypatch, metric):
+    """Several chunks over a screened shard: only the scans stay on the caller's stream (sharded.py search_device);
+    bit-identical to the serial chunk loop (MQ_KNN_TAIL_OVERLAP=0) and to the exact scan, also twice in a row."""
+    import torch
+    from viquae_amd.index import MI355XFlatIndex
+    from viquae_amd.sharded import ShardedFlatIndex
+    g = torch.Generator(device="cuda").manual_seed(11 + metric)
+    X = torch.randn((40000, 64), generator=g, device="cuda")
+    Q = torch.randn((4096 * 3 + 77, 64), generator=g, device="cuda")
+    sh = ShardedFlatIndex(string_factory="Flat", metric_type=metric, always_gather=True)
+    sh.add_vectors(X.cpu().numpy())
+    exact = MI355XFlatIndex(string_factory="Flat", metric_type=metric, screen=False)
+    exact.add(X)
+    De, Ie = exact.search_device(Q, 30)
+    monkeypatch.setenv("MQ_KNN_TAIL_OVERLAP", "0")
+    D0, I0 = sh.search_device(Q, 30)
+    monkeypatch.setenv("MQ_KNN_TAIL_OVERLAP", "1")
+    D1, I1 = sh.search_device(Q, 30)
+    D2, I2 = sh.search_device(Q, 30)
+    for D, I in ((D0, I0), (D1, I1), (D2, I2)):
+        assert torch.equal(I, Ie) and torch.equal(D, De)
+
+
 def test_knowledge_base_builds_the_sharded_index_under_torch_distributed(rccl_world1, monkeypatch, tmp_path):
     """b2: inside a torch.distributed job add_or_load_faiss_index must build this rank's shard, not a full index."""
     from viquae_amd import sharded

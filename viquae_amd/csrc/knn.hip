@@ -1177,6 +1177,7 @@ static inline int query_l2norm_form(int flags) {
     return (flags & MQ_KNN_FLAG_L2NORM_QUERIES) ? MQ_L2NORM_NUMPY : 0;
 }
 constexpr int MQ_KNN_ALL_FLAGS = MQ_KNN_FLAG_L2NORM_QUERIES | MQ_KNN_FLAG_TIE_ID_DESC | MQ_KNN_FLAG_L2NORM_FAISS;
+constexpr int MQ_KNN_SCREENED_FLAGS = MQ_KNN_ALL_FLAGS | MQ_KNN_FLAG_PHASE_FRONT | MQ_KNN_FLAG_PHASE_TAIL;
 
 // tie order of a call: key low word = ~(row ^ flip)
 static inline unsigned tie_flip(int flags) { return (flags & MQ_KNN_FLAG_TIE_ID_DESC) ? 0xFFFFFFFFu : 0u; }
@@ -1392,7 +1393,10 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
                                void* ws_dev, size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
     if (nq == 0) return MQ_OK;
     if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
-    if (flags & ~MQ_KNN_ALL_FLAGS) return MQ_EINVAL;
+    if (flags & ~MQ_KNN_SCREENED_FLAGS) return MQ_EINVAL;
+    // the two halves of one search (MQ_KNN_FLAG_PHASE_*): neither or both bits = the whole search
+    const int phase = flags & (MQ_KNN_FLAG_PHASE_FRONT | MQ_KNN_FLAG_PHASE_TAIL);
+    const bool do_front = phase != MQ_KNN_FLAG_PHASE_TAIL, do_tail = phase != MQ_KNN_FLAG_PHASE_FRONT;
     const int l2norm_queries = query_l2norm_form(flags);
     const unsigned flip = tie_flip(flags);
     const int l2 = metric == MQ_METRIC_L2;
@@ -1407,9 +1411,13 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     const Geometry g = geometry(N, d, nq, k, num_cus(), metric);
     if (ws_bytes < g.total) return MQ_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    // searches served without the screen are one piece: the FRONT call does all of it, the TAIL call has nothing left to do
+    if ((l2 && nq < MQ_KNN_L2_DIRECT_BELOW) || k > SCREEN_MAX_K) {
+        if (!do_front) return MQ_OK;
+    }
     if (l2 && nq < MQ_KNN_L2_DIRECT_BELOW)
-        return knn_search_l2_direct(packed_dev, rowmajor_dev, N, d, queries_dev, nq, k, flags, id_offset, D_dev, I_dev, ws_dev,
-                                    g, st);
+        return knn_search_l2_direct(packed_dev, rowmajor_dev, N, d, queries_dev, nq, k, flags & MQ_KNN_ALL_FLAGS, id_offset, D_dev,
+                                    I_dev, ws_dev, g, st);
     char* ws = (char*)ws_dev;
     float* Qp = (float*)(ws + g.off_qp);
     float* qn = (float*)(ws + g.off_qn);
@@ -1427,9 +1435,11 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     // bf16 copy and the re-scoring all see the same fp32 values), then panel pack (+ ||q||^2) and bf16 copy
     const float* q_rm = queries_dev;
     if (l2norm_queries) {
-        MQ_HIP(hipMemcpyAsync(qtmp, queries_dev, (size_t)nq * d * 4, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, qtmp, (int64_t)nq, d, l2norm_queries);
-        MQ_HIP(hipGetLastError());
+        if (do_front) {
+            MQ_HIP(hipMemcpyAsync(qtmp, queries_dev, (size_t)nq * d * 4, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, qtmp, (int64_t)nq, d, l2norm_queries);
+            MQ_HIP(hipGetLastError());
+        }
         q_rm = qtmp;
     }
     if (k > SCREEN_MAX_K) {
@@ -1447,6 +1457,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         return exact_scan_rounds(metric, packed_dev == nullptr, a, g, nq, k, id_offset, D_dev, I_dev, ws, nullptr, st, ev_scan_begin,
                                  ev_scan_end);
     }
+    if (do_front) {
     // The fp32 panel copy of the queries (+ ||q||^2) serves the exact-scan fallback -- and, for the L2 metric, the
     // re-scoring (||q||^2).  With the inner product it is made after the screened pipeline, for flagged tiles only.
     if (l2) {
@@ -1489,6 +1500,8 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         MQ_HIP(hipGetLastError());
         if (ev_scan_end) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_end, st));
     }
+    }  // do_front
+    if (!do_tail) return MQ_OK;
     // 2.-4. candidates -> exact scores -> exact top-k
     hipLaunchKernelGGL(cand_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin,
                        (const unsigned*)(ws + g.off_gthr), (const unsigned*)(ws + g.off_smax), g.ms, ovf, nq, g.S, k, cand, ccount);

@@ -40,6 +40,7 @@ METRIC_L2 = 1  # faiss.METRIC_L2
 MAX_K = 2048  # MQ_KNN_MAX_K; the screened search serves k <= 224, a larger k runs ceil(k / 128) exact scans (include/meerqat_hip.h)
 FLAG_L2NORM_QUERIES, FLAG_TIE_ID_DESC, MERGE_TIE_ID_DESC = 1, 2, 0x100  # MQ_KNN_FLAG_*, MQ_MERGE_TIE_ID_DESC
 FLAG_L2NORM_FAISS = 4                            # MQ_KNN_FLAG_L2NORM_FAISS
+FLAG_PHASE_FRONT, FLAG_PHASE_TAIL = 8, 16        # MQ_KNN_FLAG_PHASE_*: the two halves of one screened search
 L2NORM_FORMS = {"numpy": 1, "faiss": 2}         # MQ_L2NORM_NUMPY, MQ_L2NORM_FAISS
 TIE_ORDERS = ("id_asc", "id_desc")
 _MAGIC = b"MQFLAT01"
@@ -360,7 +361,20 @@ class MI355XFlatIndex(BaseIndex):
         import torch
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self._torch_device)
+        self._last_ws = self._ws
         return self._ws
+
+    def _second_workspace(self, nbytes):
+        """The workspace of the odd chunks of a pipelined search (chunk i's second half reads its workspace while chunk i+1's
+        scan fills the other one) + the stream those second halves run on."""
+        import torch
+        ws = getattr(self, "_ws2", None)
+        if ws is None or ws.numel() < nbytes:
+            self._ws2 = ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self._torch_device)
+        if getattr(self, "_tail_stream", None) is None:
+            self._tail_stream = torch.cuda.Stream(device=self._torch_device)
+        self._last_ws = ws
+        return ws
 
     def search_device(self, queries, k, out=None):
         """queries: CUDA float32 [nq,d] tensor on this index's device -> (D [nq,k] f32, I [nq,k] i64)
@@ -392,15 +406,17 @@ class MI355XFlatIndex(BaseIndex):
         with torch.cuda.device(self._torch_device):
             # screened path: 16 query tiles x 16 KB slabs per call keep 256 stripe maxima per query (tightest thresholds)
             chunk = _SCREEN_QUERY_CHUNK if self.screen else _QUERY_CHUNK
-            for s, e in query_chunks(nq, chunk):
+            pieces = query_chunks(nq, chunk)
+            if self.screen and len(pieces) > 1 and os.environ.get("MQ_KNN_TAIL_OVERLAP", "0") == "1":
+                self._search_chunks_pipelined(lib, queries, pieces, k, D, I)
+                return D, I
+            for s, e in pieces:
                 q = queries[s:e]
                 self._last_call_nq = e - s  # screen_stats reads the workspace geometry of the LAST C-ABI call
                 nb = int(lib.mq_knn_workspace_bytes_metric(self.ntotal, self.d, q.shape[0], k, self.metric_type))
                 ws = self._workspace(nb)
                 Dq, Iq = D[s:e], I[s:e]
-                flags = (FLAG_L2NORM_QUERIES if self.do_l2norm else 0) | (FLAG_TIE_ID_DESC if self.tie_order == "id_desc" else 0)
-                if self.do_l2norm and self.l2norm_form == "faiss":
-                    flags |= FLAG_L2NORM_FAISS
+                flags = self._search_flags()
                 if self.screen:
                     _lib.check(lib.mq_knn_search_screened_f32(
                         self._packed.data_ptr() if self._packed is not None else None, self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(),
@@ -414,6 +430,56 @@ class MI355XFlatIndex(BaseIndex):
                                                      self.id_offset, Dq.data_ptr(), Iq.data_ptr(), ws.data_ptr(), ws.numel(),
                                                      stream), "mq_knn_search_f32")
         return D, I
+
+    def _search_flags(self):
+        flags = (FLAG_L2NORM_QUERIES if self.do_l2norm else 0) | (FLAG_TIE_ID_DESC if self.tie_order == "id_desc" else 0)
+        if self.do_l2norm and self.l2norm_form == "faiss":
+            flags |= FLAG_L2NORM_FAISS
+        return flags
+
+    def _search_chunks_pipelined(self, lib, queries, pieces, k, D, I):
+        """A screened search of several query chunks: the scans run back to back on the caller's stream, and what follows
+        the scan of chunk i (candidate selection, exact re-scoring, exact top-k, recomputation of flagged tiles: about a
+        tenth of a chunk's time, mostly latency-bound launches of one workgroup per query) runs on a second stream under the
+        scan of chunk i+1 (MQ_KNN_FLAG_PHASE_*, include/meerqat_hip.h).  Two workspaces alternate; the scan of chunk i+2 waits
+        for the second half of chunk i before it reuses that one.  Same kernels on the same data in the same order per
+        chunk: results are those of the serial loop bit for bit.  Opt-in (MQ_KNN_TAIL_OVERLAP=1): measured 34.43 -> 34.30 ms
+        on 16,384 queries x 1.5M x 768, i.e. nothing -- the scan is ONE workgroup per CU holding the whole register file (4
+        waves x 128 VGPRs per SIMD) and 138 of 160 KB LDS for its 7.8 ms, so no other workgroup becomes resident before it
+        retires (profiles/r04_notes.md section 9)."""
+        import torch
+        main = torch.cuda.current_stream(self._torch_device)
+        spaces, tail = self.pipeline_workspaces(max(e - s for s, e in pieces), k)
+        done = []
+        for c, (s, e) in enumerate(pieces):
+            q, out, ws = queries[s:e], (D[s:e], I[s:e]), spaces[c & 1]
+            if c >= 2:
+                main.wait_event(done[c - 2])
+            self.search_phase(q, k, out, ws, FLAG_PHASE_FRONT, main)
+            scanned = torch.cuda.Event()
+            scanned.record(main)
+            tail.wait_event(scanned)
+            self.search_phase(q, k, out, ws, FLAG_PHASE_TAIL, tail)
+            ev = torch.cuda.Event()
+            ev.record(tail)
+            done.append(ev)
+        for ev in done[-2:]:
+            main.wait_event(ev)
+
+    def pipeline_workspaces(self, nq, k):
+        """-> ((workspace of even chunks, workspace of odd chunks), the stream second halves run on) for chunks of <= nq queries."""
+        nb = int(_lib.load().mq_knn_workspace_bytes_metric(self.ntotal, self.d, int(nq), k, self.metric_type))
+        return (self._workspace(nb), self._second_workspace(nb)), self._tail_stream
+
+    def search_phase(self, q, k, out, ws, phase, stream):
+        """One half (FLAG_PHASE_FRONT / FLAG_PHASE_TAIL) of the screened search of ONE chunk (<= 4096 queries) on ``stream``;
+        both halves take the same q, out = (D, I) and workspace, and the caller orders TAIL after FRONT."""
+        self._last_call_nq, self._last_ws = q.shape[0], ws
+        _lib.check(_lib.load().mq_knn_search_screened_f32(
+            self._packed.data_ptr() if self._packed is not None else None, self._sqnorm.data_ptr(), self._rowmajor.data_ptr(),
+            self._bf16.data_ptr(), self._xmax2.data_ptr(), self.ntotal, self.d, q.data_ptr(), q.shape[0], k, self.metric_type,
+            self._search_flags() | phase, self.id_offset, out[0].data_ptr(), out[1].data_ptr(), ws.data_ptr(), ws.numel(),
+            stream.cuda_stream, None, None), "mq_knn_search_screened_f32")
 
     def search_batch(self, queries, k: int = 10, **kwargs) -> BatchedSearchResults:
         """FaissIndex.search_batch (datasets/search.py:369-385): numpy [nq,d] -> (scores f32 [nq,k],
@@ -464,6 +530,10 @@ class MI355XFlatIndex(BaseIndex):
         scores, indices = self.search_batch(query.reshape(1, -1), k)
         return SearchResults(scores[0], indices[0].astype(int))
 
+    def _stats_workspace(self):
+        ws = getattr(self, "_last_ws", None)
+        return self._ws if ws is None else ws
+
     def scan_kind(self, nq, k):
         """Which screening scan serves a ``search_device`` call of ``nq`` queries: "tile" (256 x 256 tiles), "stream" (one query
         tile, queries in registers: csrc/knn_small.inc) or "none" (exact rounds / FAISS's small-batch L2 form / exact index)."""
@@ -484,7 +554,7 @@ class MI355XFlatIndex(BaseIndex):
             # the size of the last piece search_device cut (query_chunks moves 40 queries into a short tail)
             nq = getattr(self, "_last_call_nq", None) or query_chunks(nq, _SCREEN_QUERY_CHUNK)[-1][1] - query_chunks(nq, _SCREEN_QUERY_CHUNK)[-1][0]
         out = (ctypes.c_int64 * 8)()
-        _lib.check(lib.mq_knn_screen_stats(self.ntotal, self.d, nq, k, self._ws.data_ptr(), out,
+        _lib.check(lib.mq_knn_screen_stats(self.ntotal, self.d, nq, k, self._stats_workspace().data_ptr(), out,
                                            __import__("torch").cuda.current_stream(self._torch_device).cuda_stream))
         return tuple(int(x) for x in out)
 

@@ -28,8 +28,8 @@ from typing import Optional
 
 import numpy as np
 
-from .index import (BatchedSearchResults, BaseIndex, SearchResults, MI355XFlatIndex, METRIC_L2, MAX_K,
-                    _SCREEN_QUERY_CHUNK, index_file_format, index_file_header, parse_string_factory, query_chunks)
+from .index import (BatchedSearchResults, BaseIndex, SearchResults, MI355XFlatIndex, METRIC_L2, MAX_K, FLAG_PHASE_FRONT,
+                    FLAG_PHASE_TAIL, _SCREEN_QUERY_CHUNK, index_file_format, index_file_header, parse_string_factory, query_chunks)
 
 
 _FLT_MAX = float(np.finfo(np.float32).max)
@@ -306,7 +306,44 @@ class ShardedFlatIndex(_ShardedBase):
             D[s:s + n].copy_(Dm)
             I[s:s + n].copy_(Im)
 
-        for ci, (s, e) in enumerate(query_chunks(nq, chunk)):
+        pieces = query_chunks(nq, chunk)
+        if (len(pieces) > 1 and chunk <= _SCREEN_QUERY_CHUNK and dev.type == "cuda" and isinstance(self.local, MI355XFlatIndex)
+                and self.local.screen and self.local.ntotal > 0 and queries.dtype == torch.float32 and queries.is_contiguous()
+                and queries.dim() == 2 and queries.shape[1] == self.local.d
+                and os.environ.get("MQ_KNN_TAIL_OVERLAP", "0") == "1"):
+            # Screened local shard: only the scans stay on the caller's stream.  What follows the scan of chunk i (candidates,
+            # exact re-scoring, top-k), its all-gather and the merge of chunk i-1 run on the index's second stream under the
+            # scan of chunk i+1 (MI355XFlatIndex.search_phase); same kernels per chunk, bit-identical results.
+            main = torch.cuda.current_stream(dev)
+            spaces, tail = self.local.pipeline_workspaces(max(e - s for s, e in pieces), k)
+            done = []
+            for ci, (s, e) in enumerate(pieces):
+                q, n, ws = queries[s:e], e - s, spaces[ci & 1]
+                record, gathered = self._chunk_buffers(n, k, dev, ci & 1)
+                out = _record_views(record, n, k)
+                if ci >= 2:
+                    main.wait_event(done[ci - 2])  # the workspace (and record) of chunk i-2 are free again
+                self.local.search_phase(q, k, out, ws, FLAG_PHASE_FRONT, main)
+                scanned = torch.cuda.Event()
+                scanned.record(main)
+                tail.wait_event(scanned)
+                with torch.cuda.stream(tail):
+                    self.local.search_phase(q, k, out, ws, FLAG_PHASE_TAIL, tail)
+                    ev = torch.cuda.Event()
+                    ev.record(tail)
+                    done.append(ev)
+                    if self.world > 1 or self.always_gather:
+                        work = dist.all_gather_into_tensor(gathered, record, group=self.group, async_op=True)
+                    else:
+                        work = None
+                    if pending is not None:
+                        finish(pending)
+                    pending = (work, gathered, s, n)
+            with torch.cuda.stream(tail):
+                finish(pending)
+            main.wait_stream(tail)
+            return D, I
+        for ci, (s, e) in enumerate(pieces):
             q = queries[s:e]
             n = e - s
             # the chunk two back has been merged (finish() below runs before the next scan is enqueued on the same stream)
