@@ -446,6 +446,29 @@ int mq_diag_mfma_bf16_dot(const uint16_t *A_dev, const uint16_t *B_dev, int dp, 
 int mq_im2col_split_f32(const float *x_dev, int B, int H, int W, int C, int nchw, int KH, int KW, int stride, int pad,
                         const float *prelu_slope_dev, const float *scale_dev, const float *shift_dev, uint16_t *Ah_dev,
                         uint16_t *Al_dev, int Kpad, void *stream);
+/* A 3 x 3 convolution (padding 1, stride 1 or 2) as an IMPLICIT GEMM: the patch matrix is never written -- the GEMM's LDS-DMA
+ * gathers its A stage from the input pair (zeros at the border) -- and the layer's elementwise operations ride on the epilogue of
+ * the convolution that PRODUCES a tensor instead of on the im2col that consumes it.  Same products in the same order as
+ * mq_im2col_split_f32 + mq_gemm_nt_bf16x3s_f32: the same bits.
+ *   Xh / Xl       the convolution's input AFTER its pre-operations, as a split pair in PAIR LAYOUT over [B * H * W, C] (NHWC; C a
+ *                 multiple of 32): what mq_im2col_split_f32 with KH = KW = 1 or a previous call of this function wrote
+ *   Wh / Wl       mq_split_bf16_tiled_f32 of W [N, 9 C], column (kh * 3 + kw) * C + c (N a multiple of 64); bias_dev [N]
+ *   prelu_slope_dev != NULL:  P = split(prelu(conv + bias))                       (Y, residual, scale, shift must be NULL)
+ *   prelu_slope_dev == NULL:  Y = conv + bias + residual (fp32 [M, N], M = B * Ho * Wo, Ho = (H - 1) / stride + 1), and, when
+ *                 scale_dev / shift_dev [N] are given, P = split(Y * scale + shift) (the BatchNorm in front of the NEXT convolution)
+ *   Ph / Pl       pair output, PAIR LAYOUT over [M, N], mq_split_bf16_tiled_elems(M, N) elements each
+ *   zeros_dev     at least 16 bytes of zeros on the device (the padded border's source)
+ *   tile          MQ_CONV_TILE_AUTO, or one of the workgroup tiles (rows x columns; the column count must divide N) */
+#define MQ_CONV_TILE_AUTO 0
+#define MQ_CONV_TILE_256x256 1
+#define MQ_CONV_TILE_512x128 2
+#define MQ_CONV_TILE_256x128 3
+#define MQ_CONV_TILE_512x64 4
+int mq_conv3x3_pair_f32(const uint16_t *Xh_dev, const uint16_t *Xl_dev, int B, int H, int W, int C, int stride,
+                        const uint16_t *Wh_dev, const uint16_t *Wl_dev, int N, const float *bias_dev,
+                        const float *prelu_slope_dev, const float *residual_dev, const float *scale_dev,
+                        const float *shift_dev, float *Y_dev, uint16_t *Ph_dev, uint16_t *Pl_dev, const void *zeros_dev,
+                        int tile, void *stream);
 int mq_warp_affine_faces_f32(const uint8_t *images_dev, const int64_t *offsets_dev, const int32_t *hw_dev,
                              const int32_t *face_image_dev, const double *minv_dev, int nfaces, int size, float *out_dev,
                              void *stream);

@@ -36,6 +36,92 @@ def test_im2col_pairs_against_numpy():
         assert not got[:, k * k * C:].any()
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])   # MQ_CONV_TILE_256x256, 512x128, 256x128, 512x64
+@pytest.mark.parametrize("B,H,W,C,N,stride", [(2, 9, 7, 32, 256, 1), (3, 8, 8, 64, 256, 2), (1, 23, 17, 96, 256, 1),
+                                               (5, 14, 14, 128, 512, 2), (2, 56, 56, 64, 256, 1)])
+def test_implicit_conv3x3_equals_im2col_plus_gemm_bit_for_bit(tile, B, H, W, C, N, stride):
+    """mq_conv3x3_pair_f32 (the GEMM's LDS-DMA gathers the patches; PReLU / residual / the next BatchNorm in the epilogue) against
+    mq_im2col_split_f32 + mq_gemm_nt_bf16x3s_f32 on the same pairs: same products, same order -> the same bits, for every tile
+    shape, ragged row counts, stride 2, odd image sizes, borders."""
+    from viquae_amd import _lib
+    from viquae_amd.arcface import ArcFaceR50
+    from viquae_amd.encoders import EPI_BIAS, EPI_BIAS_RESIDUAL, SplitAct, gemm_nt, split_bf16_tiled
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H * 10 + C + tile)
+    x = torch.randn((B, H, W, C), generator=g, device="cuda")
+    w2 = torch.randn((N, 9 * C), generator=g, device="cuda") * 0.05
+    bias = torch.randn(N, generator=g, device="cuda")
+    slope = torch.rand(N, generator=g, device="cuda") * 0.4
+    scale = torch.rand(N, generator=g, device="cuda") + 0.5
+    shift = torch.randn(N, generator=g, device="cuda")
+    ws = split_bf16_tiled(w2)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    M = B * Ho * Wo
+    res = torch.randn((M, N), generator=g, device="cuda")
+    zeros = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    # the explicit path
+    A = ArcFaceR50._im2col(x, B, H, W, C, False, 3, 3, stride, 1, 9 * C, None, None, None)
+    y_plain = gemm_nt(A, w2, bias=bias, epilogue=EPI_BIAS, wsplit=ws)
+    y_res = gemm_nt(A, w2, bias=bias, residual=res, epilogue=EPI_BIAS_RESIDUAL, wsplit=ws)
+    want_prelu = ArcFaceR50._im2col(y_plain.view(B, Ho, Wo, N), B, Ho, Wo, N, False, 1, 1, 1, 0, N, slope, None, None)
+    want_aff = ArcFaceR50._im2col(y_res.view(B, Ho, Wo, N), B, Ho, Wo, N, False, 1, 1, 1, 0, N, None, scale, shift)
+    # the implicit path, from the pair of x
+    xin = ArcFaceR50._im2col(x, B, H, W, C, False, 1, 1, 1, 0, C, None, None, None)
+    P = SplitAct.empty(M, N, x.device)
+    P.hi.zero_(), P.lo.zero_()
+    _lib.check(lib.mq_conv3x3_pair_f32(xin.hi.data_ptr(), xin.lo.data_ptr(), B, H, W, C, stride, ws[0].data_ptr(), ws[1].data_ptr(), N,
+                                       bias.data_ptr(), slope.data_ptr(), None, None, None, None, P.hi.data_ptr(), P.lo.data_ptr(),
+                                       zeros.data_ptr(), tile, st), "mq_conv3x3_pair_f32")
+    for got, want in zip(P.rowmajor(), want_prelu.rowmajor()):
+        assert torch.equal(got, want)
+    Y = torch.zeros((M, N), device="cuda")
+    P2 = SplitAct.empty(M, N, x.device)
+    _lib.check(lib.mq_conv3x3_pair_f32(xin.hi.data_ptr(), xin.lo.data_ptr(), B, H, W, C, stride, ws[0].data_ptr(), ws[1].data_ptr(), N,
+                                       bias.data_ptr(), None, res.data_ptr(), scale.data_ptr(), shift.data_ptr(), Y.data_ptr(),
+                                       P2.hi.data_ptr(), P2.lo.data_ptr(), zeros.data_ptr(), tile, st), "mq_conv3x3_pair_f32")
+    assert torch.equal(Y, y_res)
+    for got, want in zip(P2.rowmajor(), want_aff.rowmajor()):
+        assert torch.equal(got, want)
+    # no pair output requested: Y alone
+    Y3 = torch.zeros((M, N), device="cuda")
+    _lib.check(lib.mq_conv3x3_pair_f32(xin.hi.data_ptr(), xin.lo.data_ptr(), B, H, W, C, stride, ws[0].data_ptr(), ws[1].data_ptr(), N,
+                                       bias.data_ptr(), None, res.data_ptr(), None, None, Y3.data_ptr(), None, None, zeros.data_ptr(), 0, st),
+               "mq_conv3x3_pair_f32")
+    assert torch.equal(Y3, y_res)
+
+
+def test_conv3x3_argument_checks():
+    from viquae_amd import _lib
+    lib = _lib.load()
+    t = torch.zeros(1 << 18, dtype=torch.int16, device="cuda")
+    f = torch.zeros(1 << 14, device="cuda")
+    p, q = t.data_ptr(), f.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    ok = dict(B=1, H=4, W=4, C=32, stride=1, N=64)
+    call = lambda C=32, N=64, stride=1, slope=q, res=None, Y=None, tile=0: lib.mq_conv3x3_pair_f32(  # noqa: E731
+        p, p, 1, 4, 4, C, stride, p, p, N, q, slope, res, None, None, Y, p, p, p, tile, st)
+    assert call() == 0
+    assert call(C=24) != 0 and call(N=96) != 0 and call(stride=3) != 0
+    assert call(slope=None) != 0                 # neither PReLU nor residual + Y
+    assert call(res=q, Y=q) != 0                 # PReLU form takes no residual
+    assert call(tile=1) != 0 and call(tile=9) != 0  # 256-column tile on 64 channels; unknown tile
+    torch.cuda.synchronize()
+    assert ok
+
+
+def test_implicit_and_im2col_forwards_agree_bit_for_bit(monkeypatch):
+    from oracle import arcface as oa
+    from viquae_amd.arcface import ArcFaceR50
+    model = ArcFaceR50.from_state_dict(oa.seeded_state(2)).cuda()
+    x = torch.from_numpy(np.random.default_rng(3).uniform(-1, 1, (5, 3, 112, 112)).astype(np.float32)).cuda()
+    monkeypatch.setenv("MQ_ARCFACE_CONV", "im2col")
+    a = model(x)
+    monkeypatch.setenv("MQ_ARCFACE_CONV", "implicit")
+    b = model(x)
+    assert torch.equal(a, b)
+
+
 def test_arcface_r50_matches_the_oracle():
     from oracle import arcface as oa
     from viquae_amd.arcface import ArcFaceR50

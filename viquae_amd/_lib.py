@@ -45,6 +45,8 @@ SIGNATURES = {
     "mq_knn_screen_scan_kind": (c_int, [c_i64, c_int, c_int, c_int, c_int]),
     "mq_im2col_split_f32": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
     "mq_warp_affine_faces_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr]),
+    "mq_conv3x3_pair_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                    c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
     "mq_gemm_nt_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "mq_split_bf16_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     "mq_split_bf16_tiled_elems": (c_i64, [c_int, c_int]),

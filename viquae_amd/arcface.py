@@ -144,6 +144,30 @@ class ArcFaceR50(_HipEncoder):
                                                A.hi.data_ptr(), A.lo.data_ptr(), kpad, _stream(x)), "mq_im2col_split_f32")
         return A
 
+    def _conv3x3(self, name, xin, B, H, W, slope=None, residual=None, scale=None, shift=None, tile=0):
+        """The 3 x 3 convolution ``name`` as an implicit GEMM (mq_conv3x3_pair_f32) on ``xin``, the SplitAct [B * H * W, Cin] of its
+        input AFTER the pre-operations.  ``slope``: -> SplitAct of prelu(conv + bias).  Otherwise: -> (fp32 conv + bias + residual,
+        SplitAct of that * scale + shift or None)."""
+        lib = _lib.load()
+        c = self._convs[name]
+        assert c.k == 3 and c.pad == 1 and xin.shape == (B * H * W, c.cin)
+        Ho, Wo = (H - 1) // c.stride + 1, (W - 1) // c.stride + 1
+        M, dev = B * Ho * Wo, xin.device
+        wh, wl = self._wsplit(name + ".w2")
+        bias = getattr(self, (name + ".b").replace(".", "_"))
+        zeros = self.__dict__.setdefault("_zero_pages", {})
+        if dev not in zeros:
+            zeros[dev] = torch.zeros(64, dtype=torch.uint8, device=dev)
+        P = SplitAct.empty(M, c.cout, dev) if (slope is not None or scale is not None) else None
+        Y = torch.empty((M, c.cout), dtype=torch.float32, device=dev) if slope is None else None
+        p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        with torch.cuda.device(dev):
+            _lib.check(lib.mq_conv3x3_pair_f32(xin.hi.data_ptr(), xin.lo.data_ptr(), B, H, W, c.cin, c.stride, wh.data_ptr(), wl.data_ptr(),
+                                               c.cout, bias.data_ptr(), p(slope), p(residual), p(scale), p(shift), p(Y),
+                                               P.hi.data_ptr() if P is not None else None, P.lo.data_ptr() if P is not None else None,
+                                               zeros[dev].data_ptr(), int(tile), _stream(xin.hi)), "mq_conv3x3_pair_f32")
+        return (P if slope is not None else (Y, P)), Ho, Wo
+
     def forward(self, pixel_values):
         _check_cuda(pixel_values)
         x = pixel_values.to(torch.float32).contiguous()
@@ -154,6 +178,33 @@ class ArcFaceR50(_HipEncoder):
         return self._forward(x)
 
     def _forward(self, x):
+        if os.environ.get("MQ_ARCFACE_CONV", "implicit") == "im2col":
+            return self._forward_im2col(x)
+        B, H, W = x.shape[0], self.image_size, self.image_size
+        # stem (3 channels: explicit im2col + GEMM), then its PReLU and the first block's bn1 as one elementwise pass that writes the
+        # pair the first implicit convolution gathers from (a 1 x 1 "im2col")
+        y, H, W = self._conv("conv1", x, B, H, W, nchw=True)
+        blocks = [f"layer{s}.{i}" for s, n in enumerate(self.layers, start=1) for i in range(n)]
+        xin = self._im2col(y, B, H, W, self._convs[blocks[0] + ".conv1"].cin, False, 1, 1, 1, 0, self._convs[blocks[0] + ".conv1"].cin,
+                           self._v("prelu"), self._v(blocks[0] + ".pre_scale"), self._v(blocks[0] + ".pre_shift"))
+        pending = self._v("prelu")
+        for bi, p in enumerate(blocks):
+            nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
+            o1, _, _ = self._conv3x3(p + ".conv1", xin, B, H, W, slope=self._v(p + ".prelu"))
+            if (p + ".downsample.0") in self._convs:
+                identity, _, _ = self._conv(p + ".downsample.0", y, B, H, W, slope=pending)
+            else:
+                identity = y
+            (y, xin), H, W = self._conv3x3(p + ".conv2", o1, B, H, W, residual=identity,
+                                           scale=self._v(nxt + ".pre_scale") if nxt else None,
+                                           shift=self._v(nxt + ".pre_shift") if nxt else None)
+            pending = None
+        A = self._im2col(y, B, H, W, 512, False, H, W, 1, 0, H * W * 512, None, self._v("head.pre_scale"), self._v("head.pre_shift"))
+        return gemm_nt(A, self.fc_w2, bias=self.fc_b, epilogue=EPI_BIAS, wsplit=self._wsplit("fc.w2"))
+
+    def _forward_im2col(self, x):
+        """Round 4's first form, kept as the check of the implicit one (MQ_ARCFACE_CONV=im2col): every convolution an explicit
+        im2col + GEMM.  Same products in the same order: the two forwards agree bit for bit."""
         B, H, W = x.shape[0], self.image_size, self.image_size
         # stem: conv - BN (folded); its PReLU is applied where the result is read (the first block's im2cols)
         y, H, W = self._conv("conv1", x, B, H, W, nchw=True)

@@ -21,7 +21,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/meerqat_hip.h"
+#include "launch_attr.h"
 
 namespace {
 
@@ -100,6 +103,265 @@ __global__ __launch_bounds__(256) void im2col_split_kernel(const float* __restri
     const size_t at = pair_index(row, col0, Kpad);
     *reinterpret_cast<bf16x8_t*>(Ah + at) = h8;
     *reinterpret_cast<bf16x8_t*>(Al + at) = l8;
+}
+
+// ---- 3 x 3 convolution as an IMPLICIT GEMM (round 4) ----------------------------------------------------------------------
+// C[M = B Ho Wo, N = Cout] = A[M, 9 C] . W[N, 9 C]^T with A never written: the K step (tap (kh, kw), 32 channels) of an output pixel is
+// the 64 contiguous bytes [pixel (b, ho s + kh - 1, wo s + kw - 1)][32 channels] of the INPUT pair (PAIR LAYOUT over [B H W, C] keeps
+// them contiguous), so the LDS-DMA that fills the GEMM's A stage takes a per-lane source address -- the input pixel, or a page of
+// zeros at the padded border -- and everything behind it is gemm_nt_x3s_kernel (encoder.hip): 64-byte tile rows, 16-byte chunks
+// XOR-swizzled on the source, hi / lo fragments, products lo.hi, hi.lo, hi.hi per 16 k on v_mfma_f32_32x32x16_bf16, K in (kh, kw,
+// c) order -- the accumulation order of the explicit path, so the two give the same bits.
+// The input pair holds the convolution's input AFTER its elementwise pre-operations (PReLU, the BatchNorm in front): they are
+// applied by the kernel that PRODUCES the tensor -- this kernel's epilogues:
+//   EP_PRELU_PAIR      v = prelu(acc + bias)                       -> pair [M, N]            (IBasicBlock.conv1 + bn2 + prelu)
+//   EP_RESIDUAL_AFFINE v = acc + bias + R;  Y = v (fp32, the next shortcut);  pair = v * scale + shift (the next block's bn1; optional)
+// Tiles: 16 waves, each 64 rows x WN columns; RG row groups x 16 / RG column groups: 256 x 256 (RG 4, WN 64), 512 x 128 (8, 64),
+// 256 x 128 (4, 32), 512 x 64 (8, 32) -- the 64- / 128-channel stages no longer pay for 256-column tiles.
+constexpr int EP_PRELU_PAIR = 0, EP_RESIDUAL_AFFINE = 1;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(unsigned long)(lds_char*)p; }
+// one 1-KiB LDS-DMA piece, LDS destination lds_dst (wave-uniform) + lane * 16: wave-uniform base + per-lane byte offset ...
+__device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// ... or a 64-bit source address per lane (the gather)
+__device__ __forceinline__ void dma16v(const void* lane_ptr, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_ptr), "s"(lds_dst) : "memory");
+}
+
+struct ConvArgs {
+    const unsigned short *Xh, *Xl;  // input pair, PAIR LAYOUT over [B * H * W, C]
+    const unsigned short *Wh, *Wl;  // weights, tile layout [N / 256][9 C / 32][256][32] (mq_split_bf16_tiled_f32), K = (kh, kw, c)
+    const float* bias;              // [N]
+    const float* slope;             // EP_PRELU_PAIR: PReLU slope [N]
+    const float* R;                 // EP_RESIDUAL_AFFINE: residual fp32 [M, N]
+    const float *scale, *shift;     // EP_RESIDUAL_AFFINE: affine of the pair output, or null = no pair output
+    float* Y;                       // EP_RESIDUAL_AFFINE: fp32 [M, N]
+    unsigned short *Ph, *Pl;        // pair output, PAIR LAYOUT over [M, N]
+    const void* zeros;              // >= 16 bytes of zeros: the padded border
+    int H, W, C, N, stride, Ho, Wo, M, ntm, ntn;
+};
+
+template <int RG, int WN, int EP>
+__global__ __launch_bounds__(1024) void conv3x3_x3s_kernel(const ConvArgs a) {
+    constexpr int CG = 16 / RG, MT = 64 * RG, NT = WN * CG, NF = WN / 32, AP = MT / 256;
+    constexpr int A_BYTES = MT * 64, W_BYTES = NT * 64, STAGE = 2 * A_BYTES + 2 * W_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w / CG, wc = w % CG;
+    // tile b runs on XCD b & 7: the column tiles of a row block on one XCD (gemm_nt_x3s_kernel's mapping)
+    const int b = (int)blockIdx.x;
+    const int mt = __builtin_amdgcn_readfirstlane(((b >> 3) / a.ntn) * 8 + (b & 7));
+    const int nt = __builtin_amdgcn_readfirstlane((b >> 3) % a.ntn);
+    if (mt >= a.ntm) return;
+    const int m0 = mt * MT, n0 = nt * NT;
+    const int CB = a.C >> 5, nk = 9 * CB;
+
+    // ---- the gather: wave w fills rows [16 (w + 16 j), + 16) of the A stage, lane = (row, 16-byte slot)
+    unsigned tapmask[AP];
+    int pbase[AP];
+    const unsigned slot = (unsigned)(lane & 3);
+    unsigned chunk_bytes[AP];
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+        const int r = 16 * (w + 16 * j) + (lane >> 2);
+        const int m = m0 + r;
+        const unsigned hw = (unsigned)(a.Ho * a.Wo);
+        const unsigned mm = m < a.M ? (unsigned)m : 0u;
+        const unsigned bi = mm / hw, pix = mm - bi * hw;
+        const int ho = (int)(pix / (unsigned)a.Wo), wo = (int)(pix - (unsigned)ho * (unsigned)a.Wo);
+        const int ih0 = ho * a.stride - 1, iw0 = wo * a.stride - 1;
+        unsigned mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ih = ih0 + t / 3, iw = iw0 + t % 3;
+            if (m < a.M && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) mask |= 1u << t;
+        }
+        tapmask[j] = mask;
+        pbase[j] = ((int)bi * a.H + ih0) * a.W + iw0;
+        chunk_bytes[j] = (slot ^ (unsigned)((r >> 2) & 3)) * 16u;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    // weights: piece w of NT / 16 (16 rows x 64 B), rows n0 % 256 + 16 w ... of the K step's 16-KiB block
+    const int rW = 16 * w + (lane >> 2);
+    const unsigned w_voff = (unsigned)(((n0 & 255) + rW) * 64) + (slot ^ (unsigned)((rW >> 2) & 3)) * 16u;
+    const char* wh0 = reinterpret_cast<const char*>(a.Wh) + (size_t)(n0 >> 8) * (size_t)nk * 16384;
+    const char* wl0 = reinterpret_cast<const char*>(a.Wl) + (size_t)(n0 >> 8) * (size_t)nk * 16384;
+    const char* xh = reinterpret_cast<const char*>(a.Xh);
+    const char* xl = reinterpret_cast<const char*>(a.Xl);
+    const char* zp = reinterpret_cast<const char*>(a.zeros);
+
+    int tap = 0, cb = 0;  // of the NEXT K step to request
+    auto issue = [&](int kb, int stg) __attribute__((always_inline)) {
+        const unsigned so = lds0 + (unsigned)(stg * STAGE);
+        const int dp = (tap / 3) * a.W + (tap % 3);
+#pragma unroll
+        for (int j = 0; j < AP; ++j) {
+            const bool ok = (tapmask[j] >> tap) & 1u;
+            const unsigned p = (unsigned)(pbase[j] + dp);
+            const size_t off = ((size_t)(p >> 8) * (size_t)CB + (size_t)cb) * 16384 + (size_t)((p & 255u) * 64u + chunk_bytes[j]);
+            const unsigned dst = so + (unsigned)(16 * (w + 16 * j) * 64);
+            dma16v(ok ? xh + off : zp, dst);
+            dma16v(ok ? xl + off : zp, dst + A_BYTES);
+        }
+        if (w < NT / 16) {
+            const unsigned dst = so + 2 * A_BYTES + (unsigned)(16 * w * 64);
+            dma16s(wh0 + (size_t)kb * 16384, w_voff, dst);
+            dma16s(wl0 + (size_t)kb * 16384, w_voff, dst + W_BYTES);
+        }
+        if (++cb == CB) { cb = 0; ++tap; }
+    };
+
+    const int i = lane & 31, kg = lane >> 5;
+    const int sww = (i >> 2) & 3;
+    const char* ard = smem + (64 * wr + i) * 64;                   // Ah rows of this wave; Al at + A_BYTES
+    const char* wrd = smem + 2 * A_BYTES + (WN * wc + i) * 64;     // Wh rows of this wave; Wl at + W_BYTES
+    f32x16 acc[2][NF];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < NF; ++y) acc[x][y] = (f32x16){0};
+
+    issue(0, 0);
+    int stage = 0;
+    for (int kb = 0; kb < nk; ++kb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kb + 1 < nk) issue(kb + 1, stage ^ 1);
+        const char* as = ard + stage * STAGE;
+        const char* ws = wrd + stage * STAGE;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int o = ((2 * m + kg) ^ sww) * 16;
+            bf16x8_t ah[2], al[2], wh[NF], wl[NF];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                ah[x] = *reinterpret_cast<const bf16x8_t*>(as + x * 32 * 64 + o);
+                al[x] = *reinterpret_cast<const bf16x8_t*>(as + A_BYTES + x * 32 * 64 + o);
+            }
+#pragma unroll
+            for (int y = 0; y < NF; ++y) {
+                wh[y] = *reinterpret_cast<const bf16x8_t*>(ws + y * 32 * 64 + o);
+                wl[y] = *reinterpret_cast<const bf16x8_t*>(ws + W_BYTES + y * 32 * 64 + o);
+            }
+            // per accumulator: lo.hi, hi.lo, hi.hi -- the order of gemm_nt_x3s_kernel
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < NF; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[x], wh[y], acc[x][y], 0, 0, 0);
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < NF; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[x], wl[y], acc[x][y], 0, 0, 0);
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < NF; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[x], wh[y], acc[x][y], 0, 0, 0);
+        }
+        stage ^= 1;
+    }
+
+    // ---- epilogue: one 32 x 32 accumulator at a time through LDS (4 KiB per wave), so that a lane ends up with eight consecutive
+    // columns of one row: 16-byte loads and stores.  Bias (and PReLU) in the accumulator layout (one column per lane); residual,
+    // affine and split after the transposition: per element the operations of the explicit path, in its order.
+    __syncthreads();  // every wave has read its last operands
+    float* Ot = reinterpret_cast<float*>(smem) + w * 1024;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < NF; ++y) {
+            const int col = n0 + WN * wc + 32 * y + i;
+            const float bs = a.bias[col];
+            const float sl = EP == EP_PRELU_PAIR ? a.slope[col] : 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+                float v = acc[x][y][reg] + bs;
+                if (EP == EP_PRELU_PAIR) v = v >= 0.f ? v : v * sl;
+                Ot[row * 32 + ((((i >> 3) ^ (row & 3)) << 3) | (i & 7))] = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = 16 * it + (lane >> 2), g = lane & 3;
+                const float* src = Ot + row * 32 + ((g ^ (row & 3)) << 3);
+                float4 u = *reinterpret_cast<const float4*>(src), v = *reinterpret_cast<const float4*>(src + 4);
+                const int gm = m0 + 64 * wr + 32 * x + row, gn = n0 + WN * wc + 32 * y + 8 * g;
+                if (gm < a.M) {
+                    bool pair_out = true;
+                    if (EP == EP_RESIDUAL_AFFINE) {
+                        const size_t at = (size_t)gm * a.N + gn;
+                        const float4 ru = *reinterpret_cast<const float4*>(a.R + at), rv = *reinterpret_cast<const float4*>(a.R + at + 4);
+                        u.x += ru.x; u.y += ru.y; u.z += ru.z; u.w += ru.w;
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                        *reinterpret_cast<float4*>(a.Y + at) = u;
+                        *reinterpret_cast<float4*>(a.Y + at + 4) = v;
+                        pair_out = a.scale != nullptr;
+                        if (pair_out) {
+                            const float4 su = *reinterpret_cast<const float4*>(a.scale + gn), sv = *reinterpret_cast<const float4*>(a.scale + gn + 4);
+                            const float4 tu = *reinterpret_cast<const float4*>(a.shift + gn), tv = *reinterpret_cast<const float4*>(a.shift + gn + 4);
+                            u.x = __builtin_fmaf(u.x, su.x, tu.x); u.y = __builtin_fmaf(u.y, su.y, tu.y);
+                            u.z = __builtin_fmaf(u.z, su.z, tu.z); u.w = __builtin_fmaf(u.w, su.w, tu.w);
+                            v.x = __builtin_fmaf(v.x, sv.x, tv.x); v.y = __builtin_fmaf(v.y, sv.y, tv.y);
+                            v.z = __builtin_fmaf(v.z, sv.z, tv.z); v.w = __builtin_fmaf(v.w, sv.w, tv.w);
+                        }
+                    }
+                    if (pair_out) {
+                        const float t[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+                        bf16x8_t h8, l8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const __bf16 h = (__bf16)t[e];
+                            h8[e] = h;
+                            l8[e] = (__bf16)(t[e] - (float)h);
+                        }
+                        const size_t pt = pair_index((size_t)gm, gn, a.N);
+                        *reinterpret_cast<bf16x8_t*>(a.Ph + pt) = h8;
+                        *reinterpret_cast<bf16x8_t*>(a.Pl + pt) = l8;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next accumulator overwrites the scratch
+        }
+}
+
+#define CONV_HIP(call)                                  \
+    do {                                                \
+        hipError_t _e = (call);                         \
+        if (_e != hipSuccess) return MQ_EHIP;           \
+    } while (0)
+
+template <int RG, int WN, int EP>
+int launch_conv3x3(ConvArgs a, hipStream_t st) {
+    constexpr int CG = 16 / RG, MT = 64 * RG, NT = WN * CG;
+    constexpr int LDS = 2 * (2 * MT * 64 + 2 * NT * 64);
+    static_assert(LDS >= 16 * 4096, "the epilogue's scratch: 4 KiB per wave");
+    a.ntm = (a.M + MT - 1) / MT;
+    a.ntn = a.N / NT;
+    const int ntiles = ((a.ntm + 7) & ~7) * a.ntn;
+    MQ_DYNAMIC_LDS_WITH(CONV_HIP, LDS, conv3x3_x3s_kernel<RG, WN, EP>);
+    hipLaunchKernelGGL((conv3x3_x3s_kernel<RG, WN, EP>), dim3((unsigned)ntiles), dim3(1024), LDS, st, a);
+    return hipGetLastError() == hipSuccess ? MQ_OK : MQ_EHIP;
+}
+
+template <int EP>
+int launch_conv3x3_variant(const ConvArgs& a, int variant, hipStream_t st) {
+    switch (variant) {
+        case MQ_CONV_TILE_256x256: return a.N % 256 ? MQ_EINVAL : launch_conv3x3<4, 64, EP>(a, st);
+        case MQ_CONV_TILE_512x128: return a.N % 128 ? MQ_EINVAL : launch_conv3x3<8, 64, EP>(a, st);
+        case MQ_CONV_TILE_256x128: return a.N % 128 ? MQ_EINVAL : launch_conv3x3<4, 32, EP>(a, st);
+        case MQ_CONV_TILE_512x64: return a.N % 64 ? MQ_EINVAL : launch_conv3x3<8, 32, EP>(a, st);
+    }
+    return MQ_EINVAL;
 }
 
 // ---- cv2.warpAffine (INTER_LINEAR, BORDER_CONSTANT 0), as published in OpenCV's imgwarp.cpp ----
@@ -200,6 +462,35 @@ int mq_im2col_split_f32(const float* x_dev, int B, int H, int W, int C, int nchw
                        nchw, KH, KW, stride, pad, Ho, Wo, prelu_slope_dev, scale_dev, shift_dev, (unsigned short*)Ah_dev,
                        (unsigned short*)Al_dev, Kpad);
     return hipGetLastError() == hipSuccess ? MQ_OK : MQ_EHIP;
+}
+
+int mq_conv3x3_pair_f32(const uint16_t* Xh_dev, const uint16_t* Xl_dev, int B, int H, int W, int C, int stride, const uint16_t* Wh_dev,
+                        const uint16_t* Wl_dev, int N, const float* bias_dev, const float* prelu_slope_dev, const float* residual_dev,
+                        const float* scale_dev, const float* shift_dev, float* Y_dev, uint16_t* Ph_dev, uint16_t* Pl_dev,
+                        const void* zeros_dev, int tile, void* stream) {
+    if (B == 0) return MQ_OK;
+    if (!Xh_dev || !Xl_dev || !Wh_dev || !Wl_dev || !bias_dev || !zeros_dev || B < 0 || H <= 0 || W <= 0) return MQ_EINVAL;
+    if (C <= 0 || C % 32 || N <= 0 || N % 64 || (stride != 1 && stride != 2)) return MQ_EINVAL;
+    const bool prelu = prelu_slope_dev != nullptr;
+    if (prelu && (residual_dev || Y_dev || scale_dev || shift_dev || !Ph_dev || !Pl_dev)) return MQ_EINVAL;  // EP_PRELU_PAIR
+    if (!prelu && (!residual_dev || !Y_dev)) return MQ_EINVAL;                                               // EP_RESIDUAL_AFFINE
+    if ((scale_dev == nullptr) != (shift_dev == nullptr)) return MQ_EINVAL;
+    if (!prelu && scale_dev && (!Ph_dev || !Pl_dev)) return MQ_EINVAL;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const size_t M = (size_t)B * Ho * Wo, P = (size_t)B * H * W;
+    if (M >= 0x7FFFFFFFull || P >= 0x7FFFFFFFull) return MQ_EUNSUPPORTED;
+    ConvArgs a;
+    a.Xh = Xh_dev; a.Xl = Xl_dev; a.Wh = Wh_dev; a.Wl = Wl_dev; a.bias = bias_dev; a.slope = prelu_slope_dev; a.R = residual_dev;
+    a.scale = scale_dev; a.shift = shift_dev; a.Y = Y_dev; a.Ph = Ph_dev; a.Pl = Pl_dev; a.zeros = zeros_dev;
+    a.H = H; a.W = W; a.C = C; a.N = N; a.stride = stride; a.Ho = Ho; a.Wo = Wo; a.M = (int)M; a.ntm = a.ntn = 0;
+    if (tile == MQ_CONV_TILE_AUTO) {
+        // the widest tile the channel count fills; a 256-column tile only while it still gives every CU a workgroup
+        if (N % 256 == 0 && ((M + 255) / 256) * (size_t)(N / 256) >= 192) tile = MQ_CONV_TILE_256x256;
+        else if (N % 128 == 0) tile = ((M + 511) / 512) * (size_t)(N / 128) >= 192 ? MQ_CONV_TILE_512x128 : MQ_CONV_TILE_256x128;
+        else tile = MQ_CONV_TILE_512x64;
+    }
+    return prelu ? launch_conv3x3_variant<EP_PRELU_PAIR>(a, tile, (hipStream_t)stream)
+                 : launch_conv3x3_variant<EP_RESIDUAL_AFFINE>(a, tile, (hipStream_t)stream);
 }
 
 int mq_warp_affine_faces_f32(const uint8_t* images_dev, const int64_t* offsets_dev, const int32_t* hw_dev, const int32_t* face_image_dev,
