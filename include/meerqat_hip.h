@@ -318,6 +318,13 @@ int mq_clip_text_embed_packed_f32(const int64_t *input_ids_dev, const int32_t *p
 int mq_gemm_nt_bf16x3s_f32(const uint16_t *Ah_dev, const uint16_t *Al_dev, const uint16_t *Wh_dev, const uint16_t *Wl_dev,
                            const float *bias_dev, const float *residual_dev, float *C_dev, uint16_t *Ch_dev, uint16_t *Cl_dev,
                            int M, int N, int K, int epilogue, void *stream);
+/* Split-K form of mq_gemm_nt_bf16x3s_f32 for a long K over a small output (ArcFace's head: [faces, 512] over K = 25,088):
+ * `nsplit` workgroup rows each accumulate a contiguous range of K steps into fp32 partials (partials_dev: nsplit * M * N floats),
+ * then C = bias + the partials summed in split order (bias_dev may be NULL).  fp32 output only; w_tiled != 0: Wh / Wl in tile
+ * layout.  The sum order differs from the one-pass GEMM's: equal within fp32 rounding, not bit for bit. */
+int mq_gemm_nt_bf16x3s_splitk_f32(const uint16_t *Ah_dev, const uint16_t *Al_dev, const uint16_t *Wh_dev,
+                                  const uint16_t *Wl_dev, const float *bias_dev, float *C_dev, int M, int N, int K,
+                                  int w_tiled, int nsplit, float *partials_dev, void *stream);
 int mq_layernorm_split_f32(const float *X_dev, const float *gamma_dev, const float *beta_dev, float *Y_dev, uint16_t *Yh_dev,
                            uint16_t *Yl_dev, int M, int C, float eps, void *stream);
 int mq_bert_embed_ln_split_f32(const int64_t *input_ids_dev, const int64_t *token_type_ids_dev, const float *word_dev,

@@ -91,6 +91,34 @@ def test_implicit_conv3x3_equals_im2col_plus_gemm_bit_for_bit(tile, B, H, W, C, 
     assert torch.equal(Y3, y_res)
 
 
+@pytest.mark.parametrize("M,N,K,nsplit", [(256, 512, 25088, 49), (37, 512, 25088, 7), (300, 96, 1024, 5), (8, 512, 25088, 1000)])
+def test_split_k_gemm_against_the_one_pass_gemm(M, N, K, nsplit):
+    """mq_gemm_nt_bf16x3s_splitk_f32: same products, partial sums combined in split order -- equal to the one-pass GEMM within fp32
+    rounding of a K-long sum (and exactly equal with one split)."""
+    from viquae_amd import _lib
+    from viquae_amd.encoders import EPI_BIAS, SplitAct, gemm_nt, split_bf16, split_bf16_tiled
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn((M, K), generator=g, device="cuda")
+    w = torch.randn((N, K), generator=g, device="cuda") * 0.02
+    bias = torch.randn(N, generator=g, device="cuda")
+    A = SplitAct(*split_bf16(a))
+    ws = split_bf16_tiled(w)
+    want = gemm_nt(A, w, bias=bias, epilogue=EPI_BIAS, wsplit=ws)
+    st = torch.cuda.current_stream().cuda_stream
+    for ns in (nsplit, 1):
+        out = torch.zeros((M, N), device="cuda")
+        part = torch.empty((min(ns, K // 32), M, N), device="cuda")
+        _lib.check(lib.mq_gemm_nt_bf16x3s_splitk_f32(A.hi.data_ptr(), A.lo.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), bias.data_ptr(),
+                                                     out.data_ptr(), M, N, K, 1, ns, part.data_ptr(), st), "mq_gemm_nt_bf16x3s_splitk_f32")
+        if ns == 1:
+            assert torch.equal(out, want)
+        else:
+            ref = a.double() @ w.double().T + bias.double()
+            assert (out.double() - ref).abs().max() <= 2 * (want.double() - ref).abs().max() + 1e-6
+            assert torch.allclose(out, want, rtol=0, atol=2e-4 * float(want.abs().max()))
+
+
 def test_conv3x3_argument_checks():
     from viquae_amd import _lib
     lib = _lib.load()

@@ -1,16 +1,23 @@
 """ArcFace r50 (insightface `arcface_torch` IResNet-50) on MI355X -- the model behind ``meerqat.image.face_recognition``
 (meerqat/image/face_recognition.py:55-61: ``get_model('r50', fp16=True)`` + ``backbone.pth``).
 
-Every convolution runs as a GEMM on the split-bf16 matrix-pipe kernels of csrc/encoder.hip (three bf16 MFMA products per fp32
-product: fp32-class accuracy, where the reference runs fp16 autocast): activations are NHWC, so the GEMM's output
-``[B * Ho * Wo, Cout]`` IS the next layer's input; the patch matrix is written by ``mq_im2col_split_f32`` (csrc/conv.hip) directly as
-the (hi, lo) pair the GEMM streams, with the layer's elementwise pre-operations applied on the way.  BatchNorms are eval-mode
-affines: the one BEHIND a convolution is folded into its weights and bias here, at load (exact); the one IN FRONT of a
-convolution (IBasicBlock.bn1, the final bn2) and PReLU ride on the im2col.  An IBasicBlock is thus four launches:
+Every convolution is a GEMM on the split-bf16 matrix-pipe kernels (three bf16 MFMA products per fp32 product: fp32-class
+accuracy, where the reference runs fp16 autocast); activations are NHWC, so a GEMM's output ``[B * Ho * Wo, Cout]`` IS the next
+layer's input.  BatchNorms are eval-mode affines: the one BEHIND a convolution is folded into its weights and bias here, at load
+(exact); the one IN FRONT of a convolution (IBasicBlock.bn1, the final bn2) and PReLU are elementwise operations on the tensor the
+convolution reads.
 
-    A1 = im2col3x3(bn1(x));  y1 = A1 . (a2 W1)^T + b2;  A2 = im2col3x3(prelu(y1), stride);  x' = A2 . (a3 W2)^T + b3 + identity
+The 48 3 x 3 convolutions of the blocks are IMPLICIT GEMMs (``mq_conv3x3_pair_f32``, csrc/conv.hip): no patch matrix is written,
+the GEMM's LDS-DMA gathers the taps from the input's (hi, lo) pair, and the elementwise operations ride on the epilogue of the
+convolution that PRODUCES a tensor.  An IBasicBlock is two launches:
 
-(+ two for the strided 1 x 1 downsample of a stage's first block), the head one 7 x 7 "convolution" = flatten + fc + BN1d.
+    P1 = split(prelu(conv1(P0) + b2))                          # P0 = split(bn1(x)), written by the previous block
+    x' = conv2(P1) + b3 + identity;   P0' = split(bn1'(x'))    # one epilogue: the fp32 shortcut of the next block + its input pair
+
+(+ im2col and GEMM for the strided 1 x 1 downsample of a stage's first block).  The 3-channel stem and the head (bn2 - flatten - fc -
+features = one 7 x 7 "convolution", split-K) go through ``mq_im2col_split_f32`` + the encoder GEMM; ``MQ_ARCFACE_CONV=im2col`` runs
+EVERY convolution that way (round 4's first form: the same products in the same order, so the two forwards agree bit for bit --
+tests/test_arcface_gpu.py).
 
 Parity: arcface_torch is not vendored by the reference and not installable here -- ``oracle/arcface.py`` restates the PUBLISHED
 definition (parity unpinned); ``tests/test_arcface_gpu.py`` holds this module to that oracle within 1e-3."""
@@ -59,8 +66,10 @@ class ArcFaceR50(_HipEncoder):
     image_size = 112
     num_features = 512
 
-    def __init__(self, state, layers=LAYERS, chunk=256):
+    def __init__(self, state, layers=LAYERS, chunk=328):
         super().__init__()
+        # chunk = faces per forward: the 14 x 14 stage (half the FLOPs) runs ceil(faces * 196 / 256) workgroups of one 256-row tile
+        # each -- 328 faces = 252 of the 256 CUs in one round (256 faces: 196; measured 19.3 k -> 21.3 k faces/s)
         state = {k: _np(v).astype(np.float32) for k, v in state.items() if not k.endswith("num_batches_tracked")}
         self.layers, self.chunk = tuple(layers), int(chunk)
         self._convs, self._vecs = {}, {}
@@ -168,6 +177,26 @@ class ArcFaceR50(_HipEncoder):
                                                zeros[dev].data_ptr(), int(tile), _stream(xin.hi)), "mq_conv3x3_pair_f32")
         return (P if slope is not None else (Y, P)), Ho, Wo
 
+    def _head(self, y, B, H, W):
+        """bn2 - flatten - fc - features: one 7 x 7 "convolution".  [B, 512] outputs over K = 25,088: as one GEMM two workgroups would
+        walk 784 K steps (1.65 ms of a 15-ms forward), so the K range is split over 49 workgroup rows and the fp32 partials summed
+        (mq_gemm_nt_bf16x3s_splitk_f32; MQ_ARCFACE_HEAD_SPLITS=1: the one-pass GEMM)."""
+        A = self._im2col(y, B, H, W, 512, False, H, W, 1, 0, H * W * 512, None, self._v("head.pre_scale"), self._v("head.pre_shift"))
+        nsplit = int(os.environ.get("MQ_ARCFACE_HEAD_SPLITS", "49"))
+        if nsplit <= 1:
+            return gemm_nt(A, self.fc_w2, bias=self.fc_b, epilogue=EPI_BIAS, wsplit=self._wsplit("fc.w2"))
+        lib = _lib.load()
+        wh, wl = self._wsplit("fc.w2")
+        M, K = A.shape
+        N = self.fc_w2.shape[0]
+        out = torch.empty((M, N), dtype=torch.float32, device=y.device)
+        part = torch.empty((nsplit, M, N), dtype=torch.float32, device=y.device)
+        with torch.cuda.device(y.device):
+            _lib.check(lib.mq_gemm_nt_bf16x3s_splitk_f32(A.hi.data_ptr(), A.lo.data_ptr(), wh.data_ptr(), wl.data_ptr(), self.fc_b.data_ptr(),
+                                                         out.data_ptr(), M, N, K, 1, nsplit, part.data_ptr(), _stream(y)),
+                       "mq_gemm_nt_bf16x3s_splitk_f32")
+        return out
+
     def forward(self, pixel_values):
         _check_cuda(pixel_values)
         x = pixel_values.to(torch.float32).contiguous()
@@ -199,8 +228,7 @@ class ArcFaceR50(_HipEncoder):
                                            scale=self._v(nxt + ".pre_scale") if nxt else None,
                                            shift=self._v(nxt + ".pre_shift") if nxt else None)
             pending = None
-        A = self._im2col(y, B, H, W, 512, False, H, W, 1, 0, H * W * 512, None, self._v("head.pre_scale"), self._v("head.pre_shift"))
-        return gemm_nt(A, self.fc_w2, bias=self.fc_b, epilogue=EPI_BIAS, wsplit=self._wsplit("fc.w2"))
+        return self._head(y, B, H, W)
 
     def _forward_im2col(self, x):
         """Round 4's first form, kept as the check of the implicit one (MQ_ARCFACE_CONV=im2col): every convolution an explicit
@@ -220,5 +248,4 @@ class ArcFaceR50(_HipEncoder):
                     identity = y
                 y, Ho, Wo = self._conv(p + ".conv2", o1, B, H, W, slope=self._v(p + ".prelu"), residual=identity)
                 H, W, pending = Ho, Wo, None
-        A = self._im2col(y, B, H, W, 512, False, H, W, 1, 0, H * W * 512, None, self._v("head.pre_scale"), self._v("head.pre_shift"))
-        return gemm_nt(A, self.fc_w2, bias=self.fc_b, epilogue=EPI_BIAS, wsplit=self._wsplit("fc.w2"))
+        return self._head(y, B, H, W)

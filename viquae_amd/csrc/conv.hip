@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void im2col_split_kernel(const float* __restri
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            unsigned short* __restrict__ Ah, unsigned short* __restrict__ Al, int Kpad) {
     const unsigned M = (unsigned)B * Ho * Wo;
-    const unsigned row = blockIdx.y * 64u + (threadIdx.x >> 2);
+    const unsigned row = (blockIdx.z * 65535u + blockIdx.y) * 64u + (threadIdx.x >> 2);  // gridDim.y <= 65535: z carries the rest
     if (row >= M) return;
     const int col0 = (int)blockIdx.x * 32 + (int)(threadIdx.x & 3) * 8;
     const unsigned hw = (unsigned)Ho * Wo;
@@ -454,11 +454,11 @@ int mq_im2col_split_f32(const float* x_dev, int B, int H, int W, int C, int nchw
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return MQ_EINVAL;
     const size_t M = (size_t)B * Ho * Wo;
-    if (M >= 0x7FFFFFFFull || (M + 63) / 64 > 65535ull * 1024ull) return MQ_EUNSUPPORTED;
-    // x = 32-column blocks (<= 784 for the 7 x 7 x 512 head), y = 64-row tiles (gridDim.y <= 65535: y carries the rest in z ... not
-    // needed: 256 faces x 12544 pixels / 64 = 50176 tiles)
-    if ((M + 63) / 64 > 65535ull) return MQ_EUNSUPPORTED;
-    hipLaunchKernelGGL(im2col_split_kernel, dim3((unsigned)(Kpad / 32), (unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x_dev, B, H, W, C,
+    if (M >= 0x7FFFFFFFull) return MQ_EUNSUPPORTED;
+    // x = 32-column blocks (<= 784 for the 7 x 7 x 512 head), (y, z) = 64-row tiles
+    const size_t rt = (M + 63) / 64;
+    const unsigned gy = (unsigned)(rt < 65535 ? rt : 65535), gz = (unsigned)((rt + 65534) / 65535);
+    hipLaunchKernelGGL(im2col_split_kernel, dim3((unsigned)(Kpad / 32), gy, gz), dim3(256), 0, (hipStream_t)stream, x_dev, B, H, W, C,
                        nchw, KH, KW, stride, pad, Ho, Wo, prelu_slope_dev, scale_dev, shift_dev, (unsigned short*)Ah_dev,
                        (unsigned short*)Al_dev, Kpad);
     return hipGetLastError() == hipSuccess ? MQ_OK : MQ_EHIP;

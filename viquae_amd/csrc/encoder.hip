@@ -320,8 +320,11 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
                                                            const float* __restrict__ bias, const float* __restrict__ R,
                                                            float* __restrict__ C, unsigned short* __restrict__ Ch,
                                                            unsigned short* __restrict__ Cl, int M, int N, int K, int ntm, int ntn,
-                                                           int wt) {
+                                                           int wt, int nsplit) {
     // wt != 0: Wh, Wl are in tile layout (split_bf16_tiled_kernel).
+    // nsplit > 1 (split-K, gridDim.y = nsplit): workgroup row y accumulates K steps [y per, (y + 1) per) only and writes its fp32
+    // partial to C + y M N (EPI_NONE; mq_gemm_nt_bf16x3s_splitk_f32 sums them) -- for the one shape where K is long and the
+    // output tiny (ArcFace's head: 256 x 512 outputs over K = 25,088: two workgroups walking 784 K steps otherwise).
     // Each workgroup walks the output tiles blockIdx.x, + gridDim.x, ... (one tile per workgroup by default; a persistent
     // launch of ~#CU workgroups under MQ_GEMM_WGS).  The first K stage of the NEXT tile is requested during the last K step
     // of the current one, so its DMA round trip overlaps the C-store epilogue.
@@ -340,7 +343,11 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
     const int sww = (i >> 2) & 3;
     const char* ard = smem + (64 * wr + i) * 64;                    // Ah rows of this wave; Al at + X_W_BYTES
     const char* wrd = smem + 2 * X_W_BYTES + (64 * wc + i) * 64;    // Wh rows of this wave; Wl at + X_W_BYTES
-    const int nk = K / XBK;
+    const int nk_all = K / XBK;
+    const int per = (nk_all + nsplit - 1) / nsplit;
+    const int kb0 = __builtin_amdgcn_readfirstlane((int)blockIdx.y * per);
+    const int nk = __builtin_amdgcn_readfirstlane(kb0 + per < nk_all ? kb0 + per : nk_all);  // one past this split's last K step
+    if (nsplit > 1) C += (size_t)blockIdx.y * (size_t)M * (size_t)N;
 
     // operand addressing of one tile.  DMA: wave w moves rows [16w, 16w+16) of Ah, Al, Wh, Wl: one instruction of 16 rows
     // x 64 B each.  gridDim.x is a multiple of 8 whenever it is smaller than the tile count, so tile & 7 is this workgroup's XCD.
@@ -381,13 +388,13 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
     int tile = valid_from(blockIdx.x);
     if (tile >= ntiles) return;
     Tile cur = make_tile(tile);
-    issue(cur, 0, 0);
+    issue(cur, kb0, 0);
     int stage = 0;
     for (;;) {
     const int next = valid_from(tile + (int)gridDim.x);
     Tile nxt = cur;
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    for (int kb = 0; kb < nk; ++kb) {
+    for (int kb = kb0; kb < nk; ++kb) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
         else
         if (next < ntiles) {  // last step: the other stage is free -> the next tile's first K stage
             nxt = make_tile(next);
-            issue(nxt, 0, stage ^ 1);
+            issue(nxt, kb0, stage ^ 1);
         }
         const char* as = ard + stage * XS_STAGE;
         const char* ws = wrd + stage * XS_STAGE;
@@ -1198,6 +1205,16 @@ __global__ __launch_bounds__(256) void sum_groups_kernel(const float* __restrict
     out[e] = acc;
 }
 
+// out[e] = bias[e % N] + part[0][e] + part[1][e] + ... (the partial sums of a split-K GEMM, in split order)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int S, size_t mn, int N) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= mn) return;
+    float acc = part[e];
+    for (int s2 = 1; s2 < S; ++s2) acc += part[(size_t)s2 * mn + e];
+    out[e] = bias ? acc + bias[e % N] : acc;
+}
+
 // CLIP text tower input: token embedding + position embedding (no LayerNorm, no token types)
 __global__ __launch_bounds__(256) void clip_text_embed_kernel(const long long* __restrict__ ids, const float* __restrict__ tok,
                                                               const float* __restrict__ pos, float* __restrict__ out, int M,
@@ -1342,9 +1359,9 @@ int mq_gemm_nt_bf16x3_f32(const float* A_dev, const uint16_t* Wh_dev, const uint
     return MQ_OK;
 }
 
-int mq_gemm_nt_bf16x3s_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const uint16_t* Wh_dev, const uint16_t* Wl_dev,
+static int gemm_x3s_launch(const uint16_t* Ah_dev, const uint16_t* Al_dev, const uint16_t* Wh_dev, const uint16_t* Wl_dev,
                            const float* bias_dev, const float* residual_dev, float* C_dev, uint16_t* Ch_dev, uint16_t* Cl_dev,
-                           int M, int N, int K, int epilogue, void* stream) {
+                           int M, int N, int K, int epilogue, int nsplit, void* stream) {
     const int wt = (epilogue & MQ_GEMM_W_TILED) ? 1 : 0;
     epilogue &= ~MQ_GEMM_W_TILED;
     if (M == 0 || N == 0) return MQ_OK;
@@ -1359,14 +1376,14 @@ int mq_gemm_nt_bf16x3s_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const
     // MQ_GEMM_WGS=n: persistent launch, n workgroups walk the tiles (default: one workgroup per tile)
     const int persist = gemm_persistent_wgs();
     const int ntiles = ((ntm + 7) & ~7) * ntn;  // tile space padded to 8 row blocks (XCD placement, see the kernel)
-    const dim3 grid((unsigned)(persist > 0 && ntiles > persist ? persist : ntiles)), block(1024);
+    const dim3 grid((unsigned)(persist > 0 && ntiles > persist ? persist : ntiles), (unsigned)nsplit), block(1024);
     hipStream_t st = (hipStream_t)stream;
 #define MQ_LAUNCH2(E, S)                                                                                              \
     {                                                                                                                 \
         MQ_DYNAMIC_LDS_WITH(ENC_HIP, XS_LDS_BYTES, gemm_nt_x3s_kernel<E, S>); \
         hipLaunchKernelGGL((gemm_nt_x3s_kernel<E, S>), grid, block, XS_LDS_BYTES, st, (const unsigned short*)Ah_dev,    \
                            (const unsigned short*)Al_dev, (const unsigned short*)Wh_dev, (const unsigned short*)Wl_dev, \
-                           bias_dev, residual_dev, C_dev, (unsigned short*)Ch_dev, (unsigned short*)Cl_dev, M, N, K, ntm, ntn, wt); \
+                           bias_dev, residual_dev, C_dev, (unsigned short*)Ch_dev, (unsigned short*)Cl_dev, M, N, K, ntm, ntn, wt, nsplit); \
     }
 #define MQ_LAUNCH(E)                                                                                                  \
     case E:                                                                                                           \
@@ -1381,6 +1398,31 @@ int mq_gemm_nt_bf16x3s_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const
     }
 #undef MQ_LAUNCH
 #undef MQ_LAUNCH2
+    ENC_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+int mq_gemm_nt_bf16x3s_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const uint16_t* Wh_dev, const uint16_t* Wl_dev,
+                           const float* bias_dev, const float* residual_dev, float* C_dev, uint16_t* Ch_dev, uint16_t* Cl_dev,
+                           int M, int N, int K, int epilogue, void* stream) {
+    return gemm_x3s_launch(Ah_dev, Al_dev, Wh_dev, Wl_dev, bias_dev, residual_dev, C_dev, Ch_dev, Cl_dev, M, N, K, epilogue, 1, stream);
+}
+
+int mq_gemm_nt_bf16x3s_splitk_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const uint16_t* Wh_dev, const uint16_t* Wl_dev,
+                                  const float* bias_dev, float* C_dev, int M, int N, int K, int w_tiled, int nsplit,
+                                  float* partials_dev, void* stream) {
+    if (M == 0 || N == 0) return MQ_OK;
+    if (!C_dev || !partials_dev || nsplit < 1 || K <= 0 || (K % XBK) != 0 || M < 0 || N < 0) return MQ_EINVAL;
+    const int nk = K / XBK;
+    if (nsplit > nk) nsplit = nk;
+    const int per = (nk + nsplit - 1) / nsplit;
+    nsplit = (nk + per - 1) / per;  // no empty split
+    const int rc = gemm_x3s_launch(Ah_dev, Al_dev, Wh_dev, Wl_dev, nullptr, nullptr, partials_dev, nullptr, nullptr, M, N, K,
+                                   EPI_NONE | (w_tiled ? MQ_GEMM_W_TILED : 0), nsplit, stream);
+    if (rc != MQ_OK) return rc;
+    const size_t mn = (size_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials_dev, bias_dev,
+                       C_dev, nsplit, mn, N);
     ENC_HIP(hipGetLastError());
     return MQ_OK;
 }
