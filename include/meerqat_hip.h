@@ -471,6 +471,10 @@ int mq_im2col_split_f32(const float *x_dev, int B, int H, int W, int C, int nchw
 #define MQ_CONV_TILE_512x128 2
 #define MQ_CONV_TILE_256x128 3
 #define MQ_CONV_TILE_512x64 4
+/* OR into `tile`: walk K as (32-channel block, tap) instead of (tap, block) -- the nine taps of a block re-read the same input
+ * lines back to back, so a workgroup's live footprint in L2 is one block's rows instead of all C channels'.  The sum order then
+ * differs from the explicit path's (equal within fp32 rounding, not bit for bit). */
+#define MQ_CONV_K_CHANNEL_MAJOR 0x100
 int mq_conv3x3_pair_f32(const uint16_t *Xh_dev, const uint16_t *Xl_dev, int B, int H, int W, int C, int stride,
                         const uint16_t *Wh_dev, const uint16_t *Wl_dev, int N, const float *bias_dev,
                         const float *prelu_slope_dev, const float *residual_dev, const float *scale_dev,

@@ -83,6 +83,12 @@ def test_implicit_conv3x3_equals_im2col_plus_gemm_bit_for_bit(tile, B, H, W, C, 
     assert torch.equal(Y, y_res)
     for got, want in zip(P2.rowmajor(), want_aff.rowmajor()):
         assert torch.equal(got, want)
+    # K walked as (channel block, tap): the same products, another order
+    Y4 = torch.zeros((M, N), device="cuda")
+    _lib.check(lib.mq_conv3x3_pair_f32(xin.hi.data_ptr(), xin.lo.data_ptr(), B, H, W, C, stride, ws[0].data_ptr(), ws[1].data_ptr(), N,
+                                       bias.data_ptr(), None, res.data_ptr(), None, None, Y4.data_ptr(), None, None, zeros.data_ptr(),
+                                       tile | 0x100, st), "mq_conv3x3_pair_f32")
+    assert (Y4 - y_res).abs().max() <= 1e-5 * float(y_res.abs().max())
     # no pair output requested: Y alone
     Y3 = torch.zeros((M, N), device="cuda")
     _lib.check(lib.mq_conv3x3_pair_f32(xin.hi.data_ptr(), xin.lo.data_ptr(), B, H, W, C, stride, ws[0].data_ptr(), ws[1].data_ptr(), N,
@@ -146,8 +152,12 @@ def test_implicit_and_im2col_forwards_agree_bit_for_bit(monkeypatch):
     monkeypatch.setenv("MQ_ARCFACE_CONV", "im2col")
     a = model(x)
     monkeypatch.setenv("MQ_ARCFACE_CONV", "implicit")
+    monkeypatch.setenv("MQ_CONV_KORDER", "tap")       # K walked like the explicit path: the same sums in the same order
     b = model(x)
     assert torch.equal(a, b)
+    monkeypatch.delenv("MQ_CONV_KORDER")              # the default, (channel block, tap): another order of the same products
+    c = model(x)
+    assert (a - c).abs().max() <= 2e-5 * a.abs().max()
 
 
 def test_arcface_r50_matches_the_oracle():

@@ -16,8 +16,9 @@ convolution that PRODUCES a tensor.  An IBasicBlock is two launches:
 
 (+ im2col and GEMM for the strided 1 x 1 downsample of a stage's first block).  The 3-channel stem and the head (bn2 - flatten - fc -
 features = one 7 x 7 "convolution", split-K) go through ``mq_im2col_split_f32`` + the encoder GEMM; ``MQ_ARCFACE_CONV=im2col`` runs
-EVERY convolution that way (round 4's first form: the same products in the same order, so the two forwards agree bit for bit --
-tests/test_arcface_gpu.py).
+EVERY convolution that way (round 4's first form).  The implicit kernel walks K as (32-channel block, tap) -- the nine taps of a block re-read the same
+input lines back to back, +6 % from L2 hits alone; with ``MQ_CONV_KORDER=tap`` it walks K like the explicit path and the two
+forwards agree bit for bit (tests/test_arcface_gpu.py), otherwise within fp32 rounding.
 
 Parity: arcface_torch is not vendored by the reference and not installable here -- ``oracle/arcface.py`` restates the PUBLISHED
 definition (parity unpinned); ``tests/test_arcface_gpu.py`` holds this module to that oracle within 1e-3."""
@@ -174,7 +175,8 @@ class ArcFaceR50(_HipEncoder):
             _lib.check(lib.mq_conv3x3_pair_f32(xin.hi.data_ptr(), xin.lo.data_ptr(), B, H, W, c.cin, c.stride, wh.data_ptr(), wl.data_ptr(),
                                                c.cout, bias.data_ptr(), p(slope), p(residual), p(scale), p(shift), p(Y),
                                                P.hi.data_ptr() if P is not None else None, P.lo.data_ptr() if P is not None else None,
-                                               zeros[dev].data_ptr(), int(tile), _stream(xin.hi)), "mq_conv3x3_pair_f32")
+                                               zeros[dev].data_ptr(), int(tile) | (0 if os.environ.get("MQ_CONV_KORDER", "channel") == "tap" else 0x100),
+                                               _stream(xin.hi)), "mq_conv3x3_pair_f32")
         return (P if slope is not None else (Y, P)), Ho, Wo
 
     def _head(self, y, B, H, W):

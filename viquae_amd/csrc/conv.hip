@@ -147,6 +147,7 @@ struct ConvArgs {
     unsigned short *Ph, *Pl;        // pair output, PAIR LAYOUT over [M, N]
     const void* zeros;              // >= 16 bytes of zeros: the padded border
     int H, W, C, N, stride, Ho, Wo, M, ntm, ntn;
+    int cmajor;  // K steps in (channel block, tap) order instead of (tap, channel block): see mq_conv3x3_pair_f32
 };
 
 template <int RG, int WN, int EP>
@@ -157,11 +158,14 @@ __global__ __launch_bounds__(1024) void conv3x3_x3s_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w / CG, wc = w % CG;
-    // tile b runs on XCD b & 7: the column tiles of a row block on one XCD (gemm_nt_x3s_kernel's mapping)
+    // workgroup b runs on XCD b & 7.  Each XCD takes a CONTIGUOUS range of row blocks (per = ceil(ntm / 8) of them) and all
+    // column tiles of a row block: the tiles its CUs hold at one time are neighbours in the image, so the halo rows two row blocks
+    // share (2 of a 512-pixel tile's 4.6 image rows at 112 x 112) and a row block's A rows are fetched into that XCD's L2 once
     const int b = (int)blockIdx.x;
-    const int mt = __builtin_amdgcn_readfirstlane(((b >> 3) / a.ntn) * 8 + (b & 7));
+    const int per = (a.ntm + 7) >> 3;
+    const int mt = __builtin_amdgcn_readfirstlane((b & 7) * per + (b >> 3) / a.ntn);
     const int nt = __builtin_amdgcn_readfirstlane((b >> 3) % a.ntn);
-    if (mt >= a.ntm) return;
+    if ((b >> 3) / a.ntn >= per || mt >= a.ntm) return;
     const int m0 = mt * MT, n0 = nt * NT;
     const int CB = a.C >> 5, nk = 9 * CB;
 
@@ -214,10 +218,12 @@ __global__ __launch_bounds__(1024) void conv3x3_x3s_kernel(const ConvArgs a) {
         }
         if (w < NT / 16) {
             const unsigned dst = so + 2 * A_BYTES + (unsigned)(16 * w * 64);
-            dma16s(wh0 + (size_t)kb * 16384, w_voff, dst);
-            dma16s(wl0 + (size_t)kb * 16384, w_voff, dst + W_BYTES);
+            const size_t kw_ = (size_t)__builtin_amdgcn_readfirstlane(tap * CB + cb) * 16384;  // the weights' K order is (tap, channel) either way
+            dma16s(wh0 + kw_, w_voff, dst);
+            dma16s(wl0 + kw_, w_voff, dst + W_BYTES);
         }
-        if (++cb == CB) { cb = 0; ++tap; }
+        if (a.cmajor) { if (++tap == 9) { tap = 0; ++cb; } }
+        else if (++cb == CB) { cb = 0; ++tap; }
     };
 
     const int i = lane & 31, kg = lane >> 5;
@@ -347,7 +353,7 @@ int launch_conv3x3(ConvArgs a, hipStream_t st) {
     static_assert(LDS >= 16 * 4096, "the epilogue's scratch: 4 KiB per wave");
     a.ntm = (a.M + MT - 1) / MT;
     a.ntn = a.N / NT;
-    const int ntiles = ((a.ntm + 7) & ~7) * a.ntn;
+    const int ntiles = ((a.ntm + 7) >> 3) * 8 * a.ntn;
     MQ_DYNAMIC_LDS_WITH(CONV_HIP, LDS, conv3x3_x3s_kernel<RG, WN, EP>);
     hipLaunchKernelGGL((conv3x3_x3s_kernel<RG, WN, EP>), dim3((unsigned)ntiles), dim3(1024), LDS, st, a);
     return hipGetLastError() == hipSuccess ? MQ_OK : MQ_EHIP;
@@ -483,6 +489,8 @@ int mq_conv3x3_pair_f32(const uint16_t* Xh_dev, const uint16_t* Xl_dev, int B, i
     a.Xh = Xh_dev; a.Xl = Xl_dev; a.Wh = Wh_dev; a.Wl = Wl_dev; a.bias = bias_dev; a.slope = prelu_slope_dev; a.R = residual_dev;
     a.scale = scale_dev; a.shift = shift_dev; a.Y = Y_dev; a.Ph = Ph_dev; a.Pl = Pl_dev; a.zeros = zeros_dev;
     a.H = H; a.W = W; a.C = C; a.N = N; a.stride = stride; a.Ho = Ho; a.Wo = Wo; a.M = (int)M; a.ntm = a.ntn = 0;
+    a.cmajor = (tile & MQ_CONV_K_CHANNEL_MAJOR) ? 1 : 0;
+    tile &= ~MQ_CONV_K_CHANNEL_MAJOR;
     if (tile == MQ_CONV_TILE_AUTO) {
         // the widest tile the channel count fills; a 256-column tile only while it still gives every CU a workgroup
         if (N % 256 == 0 && ((M + 255) / 256) * (size_t)(N / 256) >= 192) tile = MQ_CONV_TILE_256x256;
