@@ -480,6 +480,16 @@ int mq_conv3x3_pair_f32(const uint16_t *Xh_dev, const uint16_t *Xl_dev, int B, i
                         const float *prelu_slope_dev, const float *residual_dev, const float *scale_dev,
                         const float *shift_dev, float *Y_dev, uint16_t *Ph_dev, uint16_t *Pl_dev, const void *zeros_dev,
                         int tile, void *stream);
+/* The stem of IResNet: 3 -> 64 channels, 3 x 3, stride 1, padding 1, as a direct fp32 convolution (K = 27 has no matrix-pipe shape),
+ * fused with what follows it: v = prelu(conv(x) + bias);
+ *   P = split(v * scale + shift)  PAIR LAYOUT over [B * H * W, 64]: the first block's conv1 input (its bn1 applied)
+ *   D = split(v) at even (h, w)   PAIR LAYOUT over [B * H/2 * W/2, 64]: the A operand of the first block's strided 1 x 1 downsample
+ *                                 (Dh / Dl may both be NULL)
+ * x_dev fp32 NCHW [B, 3, H, W] (W a multiple of 4, H even when D is asked for); wt_dev fp32 [27, 64]: row (kh * 3 + kw) * 3 + c,
+ * the BatchNorm behind the convolution folded in; bias / prelu_slope / scale / shift fp32 [64]. */
+int mq_stem_conv3x3_f32(const float *x_dev, int B, int H, int W, const float *wt_dev, const float *bias_dev,
+                        const float *prelu_slope_dev, const float *scale_dev, const float *shift_dev, uint16_t *Ph_dev,
+                        uint16_t *Pl_dev, uint16_t *Dh_dev, uint16_t *Dl_dev, void *stream);
 int mq_warp_affine_faces_f32(const uint8_t *images_dev, const int64_t *offsets_dev, const int32_t *hw_dev,
                              const int32_t *face_image_dev, const double *minv_dev, int nfaces, int size, float *out_dev,
                              void *stream);

@@ -14,8 +14,10 @@ convolution that PRODUCES a tensor.  An IBasicBlock is two launches:
     P1 = split(prelu(conv1(P0) + b2))                          # P0 = split(bn1(x)), written by the previous block
     x' = conv2(P1) + b3 + identity;   P0' = split(bn1'(x'))    # one epilogue: the fp32 shortcut of the next block + its input pair
 
-(+ im2col and GEMM for the strided 1 x 1 downsample of a stage's first block).  The 3-channel stem and the head (bn2 - flatten - fc -
-features = one 7 x 7 "convolution", split-K) go through ``mq_im2col_split_f32`` + the encoder GEMM; ``MQ_ARCFACE_CONV=im2col`` runs
+(+ im2col and GEMM for the strided 1 x 1 downsample of a stage's first block).  The 3-channel stem (K = 27) is a direct fp32 convolution on
+the vector ALU fused with its PReLU (``mq_stem_conv3x3_f32``: writes the first block's input pair and its downsample's operand, never
+the full-resolution fp32 tensor); the head (bn2 - flatten - fc - features = one 7 x 7 "convolution", split-K) goes through
+``mq_im2col_split_f32`` + the encoder GEMM; ``MQ_ARCFACE_CONV=im2col`` runs
 EVERY convolution that way (round 4's first form).  The implicit kernel walks K as (32-channel block, tap) -- the nine taps of a block re-read the same
 input lines back to back, +6 % from L2 hits alone; with ``MQ_CONV_KORDER=tap`` it walks K like the explicit path and the two
 forwards agree bit for bit (tests/test_arcface_gpu.py), otherwise within fp32 rounding.
@@ -87,6 +89,8 @@ class ArcFaceR50(_HipEncoder):
 
         conv("conv1", "bn1", 3, 1, 1)
         vec("prelu", state["prelu.weight"])
+        # the stem as a direct convolution (mq_stem_conv3x3_f32): weights [27, 64], row (kh * 3 + kw) * 3 + c
+        self._reg("conv1.wt", torch.from_numpy(np.ascontiguousarray(self._convs["conv1"].w2[:, :27].T)))
         for s, n in enumerate(self.layers, start=1):
             for i in range(n):
                 p = f"layer{s}.{i}"
@@ -212,24 +216,34 @@ class ArcFaceR50(_HipEncoder):
         if os.environ.get("MQ_ARCFACE_CONV", "implicit") == "im2col":
             return self._forward_im2col(x)
         B, H, W = x.shape[0], self.image_size, self.image_size
-        # stem (3 channels: explicit im2col + GEMM), then its PReLU and the first block's bn1 as one elementwise pass that writes the
-        # pair the first implicit convolution gathers from (a 1 x 1 "im2col")
-        y, H, W = self._conv("conv1", x, B, H, W, nchw=True)
         blocks = [f"layer{s}.{i}" for s, n in enumerate(self.layers, start=1) for i in range(n)]
-        xin = self._im2col(y, B, H, W, self._convs[blocks[0] + ".conv1"].cin, False, 1, 1, 1, 0, self._convs[blocks[0] + ".conv1"].cin,
-                           self._v("prelu"), self._v(blocks[0] + ".pre_scale"), self._v(blocks[0] + ".pre_shift"))
-        pending = self._v("prelu")
+        # stem: direct fp32 convolution fused with its PReLU; writes the first block's conv1 input pair (bn1 applied) and the A operand
+        # of its strided 1 x 1 downsample (the activated pixels at even coordinates) -- the full-resolution fp32 tensor is never stored
+        lib = _lib.load()
+        xin = SplitAct.empty(B * H * W, 64, x.device)
+        y = None
+        ds_in = SplitAct.empty(B * (H // 2) * (W // 2), 64, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.mq_stem_conv3x3_f32(x.data_ptr(), B, H, W, self.conv1_wt.data_ptr(), self.conv1_b.data_ptr(), self._v("prelu").data_ptr(),
+                                               self._v(blocks[0] + ".pre_scale").data_ptr(), self._v(blocks[0] + ".pre_shift").data_ptr(),
+                                               xin.hi.data_ptr(), xin.lo.data_ptr(), ds_in.hi.data_ptr(), ds_in.lo.data_ptr(), _stream(x)),
+                       "mq_stem_conv3x3_f32")
         for bi, p in enumerate(blocks):
             nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
             o1, _, _ = self._conv3x3(p + ".conv1", xin, B, H, W, slope=self._v(p + ".prelu"))
             if (p + ".downsample.0") in self._convs:
-                identity, _, _ = self._conv(p + ".downsample.0", y, B, H, W, slope=pending)
+                if ds_in is not None:   # the first block: the stem wrote the 1 x 1 stride-2 "patches"
+                    name = p + ".downsample.0"
+                    identity = gemm_nt(ds_in, getattr(self, (name + ".w2").replace(".", "_")), bias=getattr(self, (name + ".b").replace(".", "_")),
+                                       epilogue=EPI_BIAS, wsplit=self._wsplit(name + ".w2"))
+                    ds_in = None
+                else:
+                    identity, _, _ = self._conv(p + ".downsample.0", y, B, H, W)
             else:
                 identity = y
             (y, xin), H, W = self._conv3x3(p + ".conv2", o1, B, H, W, residual=identity,
                                            scale=self._v(nxt + ".pre_scale") if nxt else None,
                                            shift=self._v(nxt + ".pre_shift") if nxt else None)
-            pending = None
         return self._head(y, B, H, W)
 
     def _forward_im2col(self, x):

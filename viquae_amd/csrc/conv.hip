@@ -370,6 +370,96 @@ int launch_conv3x3_variant(const ConvArgs& a, int variant, hipStream_t st) {
     return MQ_EINVAL;
 }
 
+// ---- the stem: 3 -> 64 channels, 3 x 3, stride 1, padding 1 (K = 27: no matrix-pipe shape) -- direct fp32 convolution on the vector ALU.
+// Through im2col + GEMM + the elementwise pass that makes the first block's input pair, the stem moved 4.2 GB per 328 faces for 43
+// MFLOP per face (1.46 ms of a 15-ms forward); here the NCHW pixels are read once and only what the network reads next is written:
+//   P  = split(prelu(conv + bias) * scale + shift)   the first block's conv1 input pair (bn1 applied), PAIR LAYOUT over [B H W, 64]
+//   D  = split(prelu(conv + bias)) at even (h, w)    the A operand of the first block's strided 1 x 1 downsample, [B H/2 W/2, 64]
+// A thread = 4 horizontally adjacent pixels x 8 output channels (32 accumulators; the 27 x 64 weights sit in LDS, one 32-byte read
+// per tap serves 4 x 8 multiply-adds); fp32 fused multiply-adds in (kh, kw, c) order: fp32-exact products, one rounding per term.
+__global__ __launch_bounds__(256, 4) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                        const float* __restrict__ slope, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, unsigned short* __restrict__ Ph,
+                                                        unsigned short* __restrict__ Pl, unsigned short* __restrict__ Dh,
+                                                        unsigned short* __restrict__ Dl, int B, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float ws[27 * 64];
+    for (int e = threadIdx.x; e < 27 * 64; e += 256) ws[e] = wt[e];
+    __syncthreads();
+    const int cg = threadIdx.x & 7, ch0 = cg * 8;
+    const unsigned qpr = (unsigned)W >> 2, qpi = qpr * (unsigned)H;  // quads per row / per image
+    const unsigned q = blockIdx.x * 32u + (threadIdx.x >> 3);
+    if (q >= (unsigned)B * qpi) return;
+    const unsigned b = q / qpi, rem = q - b * qpi;
+    const int h = (int)(rem / qpr), w0 = (int)(rem - (unsigned)h * qpr) * 4;
+    float acc[4][8];
+    {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + ch0), b1 = *reinterpret_cast<const float4*>(bias + ch0 + 4);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            acc[p][0] = b0.x; acc[p][1] = b0.y; acc[p][2] = b0.z; acc[p][3] = b0.w;
+            acc[p][4] = b1.x; acc[p][5] = b1.y; acc[p][6] = b1.z; acc[p][7] = b1.w;
+        }
+    }
+    const size_t plane = (size_t)H * W;
+    const float* xb = x + (size_t)b * 3 * plane;
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = h + kh - 1;
+        const bool rok = ih >= 0 && ih < H;
+        float in[3][6];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int iw = w0 + j - 1;
+                in[c][j] = (rok && iw >= 0 && iw < W) ? xb[(size_t)c * plane + (size_t)ih * W + iw] : 0.f;
+            }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* wp = ws + ((kh * 3 + kw) * 3 + c) * 64 + ch0;
+                const float4 u = *reinterpret_cast<const float4*>(wp), v = *reinterpret_cast<const float4*>(wp + 4);
+                const float wv[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[p][j] = __builtin_fmaf(in[c][p + kw], wv[j], acc[p][j]);
+                asm volatile("" ::: "memory");  // one tap's weights live at a time (hoisted, the 27 reads need 216 registers)
+            }
+    }
+    float sl[8], sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sl[j] = slope[ch0 + j]; sc[j] = scale[ch0 + j]; sh[j] = shift[ch0 + j]; }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        bf16x8_t h8, l8, dh8, dl8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[p][j];
+            v = v >= 0.f ? v : v * sl[j];
+            const __bf16 dhi = (__bf16)v;
+            dh8[j] = dhi;
+            dl8[j] = (__bf16)(v - (float)dhi);
+            const float t = __builtin_fmaf(v, sc[j], sh[j]);
+            const __bf16 hi = (__bf16)t;
+            h8[j] = hi;
+            l8[j] = (__bf16)(t - (float)hi);
+        }
+        const int wq = w0 + p;
+        const size_t m = ((size_t)b * H + h) * W + wq;
+        const size_t at = pair_index(m, ch0, 64);
+        *reinterpret_cast<bf16x8_t*>(Ph + at) = h8;
+        *reinterpret_cast<bf16x8_t*>(Pl + at) = l8;
+        if (Dh && !(h & 1) && !(wq & 1)) {
+            const size_t md = ((size_t)b * (H >> 1) + (h >> 1)) * (W >> 1) + (wq >> 1);
+            const size_t ad = pair_index(md, ch0, 64);
+            *reinterpret_cast<bf16x8_t*>(Dh + ad) = dh8;
+            *reinterpret_cast<bf16x8_t*>(Dl + ad) = dl8;
+        }
+    }
+}
+
 // ---- cv2.warpAffine (INTER_LINEAR, BORDER_CONSTANT 0), as published in OpenCV's imgwarp.cpp ----
 constexpr int INTER_BITS = 5, INTER_TAB_SIZE = 1 << INTER_BITS, AB_BITS = 10, AB_SCALE = 1 << AB_BITS;
 constexpr int INTER_REMAP_COEF_BITS = 15, INTER_REMAP_COEF_SCALE = 1 << INTER_REMAP_COEF_BITS;
@@ -499,6 +589,21 @@ int mq_conv3x3_pair_f32(const uint16_t* Xh_dev, const uint16_t* Xl_dev, int B, i
     }
     return prelu ? launch_conv3x3_variant<EP_PRELU_PAIR>(a, tile, (hipStream_t)stream)
                  : launch_conv3x3_variant<EP_RESIDUAL_AFFINE>(a, tile, (hipStream_t)stream);
+}
+
+int mq_stem_conv3x3_f32(const float* x_dev, int B, int H, int W, const float* wt_dev, const float* bias_dev, const float* prelu_slope_dev,
+                        const float* scale_dev, const float* shift_dev, uint16_t* Ph_dev, uint16_t* Pl_dev, uint16_t* Dh_dev,
+                        uint16_t* Dl_dev, void* stream) {
+    if (B == 0) return MQ_OK;
+    if (!x_dev || !wt_dev || !bias_dev || !prelu_slope_dev || !scale_dev || !shift_dev || !Ph_dev || !Pl_dev) return MQ_EINVAL;
+    if ((Dh_dev == nullptr) != (Dl_dev == nullptr) || B < 0 || H <= 0 || W <= 0) return MQ_EINVAL;
+    if ((W & 3) || (Dh_dev && (H & 1))) return MQ_EUNSUPPORTED;
+    const size_t quads = (size_t)B * H * (W / 4);
+    if ((quads + 31) / 32 > 0x7FFFFFFFull) return MQ_EUNSUPPORTED;
+    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((quads + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x_dev, wt_dev, bias_dev,
+                       prelu_slope_dev, scale_dev, shift_dev, (unsigned short*)Ph_dev, (unsigned short*)Pl_dev, (unsigned short*)Dh_dev,
+                       (unsigned short*)Dl_dev, B, H, W);
+    return hipGetLastError() == hipSuccess ? MQ_OK : MQ_EHIP;
 }
 
 int mq_warp_affine_faces_f32(const uint8_t* images_dev, const int64_t* offsets_dev, const int32_t* hw_dev, const int32_t* face_image_dev,
