@@ -14,10 +14,13 @@
 //   warp_affine_kernel    cv2.warpAffine(image, M, (112, 112), borderValue=0) -- OpenCV's fixed-point bilinear remap as
 //                         published (INTER_BITS = 5, AB_BITS = 10, weights scaled to 2^15) -- fused with ToTensor + Normalize(0.5,
 //                         0.5): uint8 H x W x 3 -> fp32 [3, 112, 112] in [-1, 1].
-// An explicit im2col costs HBM traffic the implicit form would not (9x the activation for a 3 x 3 kernel): ~150 MB per face
-// over the 50 convolutions, about as long as the 12.6 GFLOP of matrix work at the GEMM's rate (next step = the
-// gather inside the GEMM's LDS-DMA addresses).  Neither OpenCV, scikit-image nor arcface_torch is vendored by the reference or
-// installable here: this path is "parity unpinned" (oracle/arcface.py restates the published algorithms).
+//   conv3x3_x3s_kernel    (round 4, second half) the 3 x 3 convolutions of the blocks as IMPLICIT GEMMs: the patch matrix is never
+//                         written, the GEMM's LDS-DMA gathers the taps from the input's pair; PReLU / shortcut / the next BatchNorm in the
+//                         epilogue.  The explicit path (im2col + GEMM: ~150 MB of patches per face, as long as the 12.6 GFLOP of matrix
+//                         work) remains for the strided 1 x 1 downsamples and the head, and as the check of the implicit one.
+//   stem_conv_kernel      the 3 -> 64 stem (K = 27) as a direct fp32 convolution fused with PReLU.
+// Neither OpenCV, scikit-image nor arcface_torch is vendored by the reference or installable here: this path is "parity unpinned"
+// (oracle/arcface.py restates the published algorithms).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
