@@ -721,7 +721,7 @@ def main():
                 try:
                     af = bench_encoders.arcface_throughput()
                     arc = {"workload": f"ArcFace r50 (IResNet-50), {af['batch']} aligned 112x112 faces per batch, seeded weights; 3x3 convolutions = "
-                                       "implicit split-bf16 GEMMs (mq_conv3x3_pair_f32, csrc/conv.hip), stem / downsample / head = im2col + GEMM",
+                                       "implicit split-bf16 GEMMs (mq_conv3x3_pair_f32, csrc/conv.hip), stem = direct fp32 convolution, downsamples / head = im2col + GEMM",
                            "faces_per_s": round(af["faces_per_s"], 1), "ms_per_batch": round(af["ms_per_batch"], 2),
                            "algorithmic_tflops": round(af["tflops"], 2),
                            "executed_bf16_mfma_frac": round(3 * af["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)}

@@ -318,6 +318,12 @@ int mq_clip_text_embed_packed_f32(const int64_t *input_ids_dev, const int32_t *p
 int mq_gemm_nt_bf16x3s_f32(const uint16_t *Ah_dev, const uint16_t *Al_dev, const uint16_t *Wh_dev, const uint16_t *Wl_dev,
                            const float *bias_dev, const float *residual_dev, float *C_dev, uint16_t *Ch_dev, uint16_t *Cl_dev,
                            int M, int N, int K, int epilogue, void *stream);
+/* mq_gemm_nt_bf16x3s_f32 with epilogue MQ_EPI_BIAS_RESIDUAL whose residual [M, N] is given as a split pair in PAIR LAYOUT (value
+ * hi + lo, exact in fp32; N a multiple of 32): a LayerNorm output that only feeds GEMMs and shortcuts then needs no fp32 copy. */
+int mq_gemm_nt_bf16x3s_respair_f32(const uint16_t *Ah_dev, const uint16_t *Al_dev, const uint16_t *Wh_dev,
+                                   const uint16_t *Wl_dev, const float *bias_dev, const uint16_t *Rh_dev, const uint16_t *Rl_dev,
+                                   float *C_dev, uint16_t *Ch_dev, uint16_t *Cl_dev, int M, int N, int K, int epilogue,
+                                   void *stream);
 /* Split-K form of mq_gemm_nt_bf16x3s_f32 for a long K over a small output (ArcFace's head: [faces, 512] over K = 25,088):
  * `nsplit` workgroup rows each accumulate a contiguous range of K steps into fp32 partials (partials_dev: nsplit * M * N floats),
  * then C = bias + the partials summed in split order (bias_dev may be NULL).  fp32 output only; w_tiled != 0: Wh / Wl in tile

@@ -45,6 +45,7 @@ SIGNATURES = {
     "mq_knn_screen_scan_kind": (c_int, [c_i64, c_int, c_int, c_int, c_int]),
     "mq_im2col_split_f32": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
     "mq_warp_affine_faces_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr]),
+    "mq_gemm_nt_bf16x3s_respair_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "mq_gemm_nt_bf16x3s_splitk_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "mq_stem_conv3x3_f32": (c_int, [c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mq_conv3x3_pair_f32": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,

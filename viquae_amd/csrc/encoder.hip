@@ -320,8 +320,10 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
                                                            const float* __restrict__ bias, const float* __restrict__ R,
                                                            float* __restrict__ C, unsigned short* __restrict__ Ch,
                                                            unsigned short* __restrict__ Cl, int M, int N, int K, int ntm, int ntn,
-                                                           int wt, int nsplit) {
+                                                           int wt, int nsplit, const unsigned short* __restrict__ Rl) {
     // wt != 0: Wh, Wl are in tile layout (split_bf16_tiled_kernel).
+    // Rl != null (EPI_BIAS_RESIDUAL): the residual is given as a split PAIR in pair layout, R = its hi array, Rl its lo array, value
+    // hi + lo (exact in fp32) -- a LayerNorm output that only feeds GEMMs and shortcuts then never exists in fp32 (round 4).
     // nsplit > 1 (split-K, gridDim.y = nsplit): workgroup row y accumulates K steps [y per, (y + 1) per) only and writes its fp32
     // partial to C + y M N (EPI_NONE; mq_gemm_nt_bf16x3s_splitk_f32 sums them) -- for the one shape where K is long and the
     // output tiny (ArcFace's head: 256 x 512 outputs over K = 25,088: two workgroups walking 784 K steps otherwise).
@@ -456,6 +458,21 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
             const bool in00 = FULL || (mr0 < M && nb0 < N), in01 = FULL || (mr0 < M && nb1 < N);
             const bool in10 = FULL || (mr1 < M && nb0 < N), in11 = FULL || (mr1 < M && nb1 < N);
             if (EPI == EPI_BIAS_RESIDUAL && (reg & 3) == 0) {  // (a second group in flight ahead of the stores spills: slower)
+                if (Rl) {
+                    const unsigned short* Rh = reinterpret_cast<const unsigned short*>(R);
+                    auto pr = [&](int m_, int n_) __attribute__((always_inline)) {
+                        const size_t at = pair_index((size_t)m_, n_, N);
+                        return __uint_as_float((unsigned)Rh[at] << 16) + __uint_as_float((unsigned)Rl[at] << 16);
+                    };
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ma = mbase + u + 8 * (reg >> 2), mb = ma + 32;
+                        rres[4 * u + 0] = (FULL || (ma < M && nb0 < N)) ? pr(ma, nb0) : 0.f;
+                        rres[4 * u + 1] = (FULL || (ma < M && nb1 < N)) ? pr(ma, nb1) : 0.f;
+                        rres[4 * u + 2] = (FULL || (mb < M && nb0 < N)) ? pr(mb, nb0) : 0.f;
+                        rres[4 * u + 3] = (FULL || (mb < M && nb1 < N)) ? pr(mb, nb1) : 0.f;
+                    }
+                } else
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int ma = mbase + u + 8 * (reg >> 2), mb = ma + 32;
@@ -521,7 +538,21 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
                 float4 u = *reinterpret_cast<const float4*>(src), v = *reinterpret_cast<const float4*>(src + 4);
                 const size_t at = (size_t)(m0 + 64 * wr + 32 * (a >> 1) + row) * N + (n0 + 64 * wc + 32 * (a & 1) + 8 * g);
                 if (EPI == EPI_BIAS_RESIDUAL) {
-                    const float4 ru = *reinterpret_cast<const float4*>(R + at), rv = *reinterpret_cast<const float4*>(R + at + 4);
+                    float4 ru, rv;
+                    if (Rl) {
+                        const size_t rp = pair_index((size_t)(m0 + 64 * wr + 32 * (a >> 1) + row), n0 + 64 * wc + 32 * (a & 1) + 8 * g, N);
+                        const uint4 h4 = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(R) + rp);
+                        const uint4 l4 = *reinterpret_cast<const uint4*>(Rl + rp);
+                        auto two = [](unsigned hw, unsigned lw, float& e0, float& e1) __attribute__((always_inline)) {
+                            e0 = __uint_as_float(hw << 16) + __uint_as_float(lw << 16);
+                            e1 = __uint_as_float(hw & 0xFFFF0000u) + __uint_as_float(lw & 0xFFFF0000u);
+                        };
+                        two(h4.x, l4.x, ru.x, ru.y); two(h4.y, l4.y, ru.z, ru.w);
+                        two(h4.z, l4.z, rv.x, rv.y); two(h4.w, l4.w, rv.z, rv.w);
+                    } else {
+                        ru = *reinterpret_cast<const float4*>(R + at);
+                        rv = *reinterpret_cast<const float4*>(R + at + 4);
+                    }
                     u.x += ru.x; u.y += ru.y; u.z += ru.z; u.w += ru.w;
                     v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                 }
@@ -1361,7 +1392,7 @@ int mq_gemm_nt_bf16x3_f32(const float* A_dev, const uint16_t* Wh_dev, const uint
 
 static int gemm_x3s_launch(const uint16_t* Ah_dev, const uint16_t* Al_dev, const uint16_t* Wh_dev, const uint16_t* Wl_dev,
                            const float* bias_dev, const float* residual_dev, float* C_dev, uint16_t* Ch_dev, uint16_t* Cl_dev,
-                           int M, int N, int K, int epilogue, int nsplit, void* stream) {
+                           int M, int N, int K, int epilogue, int nsplit, void* stream, const uint16_t* residual_lo_dev = nullptr) {
     const int wt = (epilogue & MQ_GEMM_W_TILED) ? 1 : 0;
     epilogue &= ~MQ_GEMM_W_TILED;
     if (M == 0 || N == 0) return MQ_OK;
@@ -1383,7 +1414,8 @@ static int gemm_x3s_launch(const uint16_t* Ah_dev, const uint16_t* Al_dev, const
         MQ_DYNAMIC_LDS_WITH(ENC_HIP, XS_LDS_BYTES, gemm_nt_x3s_kernel<E, S>); \
         hipLaunchKernelGGL((gemm_nt_x3s_kernel<E, S>), grid, block, XS_LDS_BYTES, st, (const unsigned short*)Ah_dev,    \
                            (const unsigned short*)Al_dev, (const unsigned short*)Wh_dev, (const unsigned short*)Wl_dev, \
-                           bias_dev, residual_dev, C_dev, (unsigned short*)Ch_dev, (unsigned short*)Cl_dev, M, N, K, ntm, ntn, wt, nsplit); \
+                           bias_dev, residual_dev, C_dev, (unsigned short*)Ch_dev, (unsigned short*)Cl_dev, M, N, K, ntm, ntn, wt, nsplit, \
+                           (const unsigned short*)residual_lo_dev); \
     }
 #define MQ_LAUNCH(E)                                                                                                  \
     case E:                                                                                                           \
@@ -1406,6 +1438,15 @@ int mq_gemm_nt_bf16x3s_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const
                            const float* bias_dev, const float* residual_dev, float* C_dev, uint16_t* Ch_dev, uint16_t* Cl_dev,
                            int M, int N, int K, int epilogue, void* stream) {
     return gemm_x3s_launch(Ah_dev, Al_dev, Wh_dev, Wl_dev, bias_dev, residual_dev, C_dev, Ch_dev, Cl_dev, M, N, K, epilogue, 1, stream);
+}
+
+int mq_gemm_nt_bf16x3s_respair_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const uint16_t* Wh_dev, const uint16_t* Wl_dev,
+                                   const float* bias_dev, const uint16_t* Rh_dev, const uint16_t* Rl_dev, float* C_dev, uint16_t* Ch_dev,
+                                   uint16_t* Cl_dev, int M, int N, int K, int epilogue, void* stream) {
+    if ((epilogue & ~MQ_GEMM_W_TILED) != EPI_BIAS_RESIDUAL || !Rh_dev || !Rl_dev || (N & 31)) return MQ_EINVAL;
+    if (((uintptr_t)Rh_dev | (uintptr_t)Rl_dev) & 15) return MQ_EINVAL;
+    return gemm_x3s_launch(Ah_dev, Al_dev, Wh_dev, Wl_dev, bias_dev, reinterpret_cast<const float*>(Rh_dev), C_dev, Ch_dev, Cl_dev, M, N, K,
+                           epilogue, 1, stream, Rl_dev);
 }
 
 int mq_gemm_nt_bf16x3s_splitk_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const uint16_t* Wh_dev, const uint16_t* Wl_dev,

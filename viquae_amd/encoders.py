@@ -164,10 +164,19 @@ def gemm_nt(a, w, bias=None, residual=None, epilogue=EPI_NONE, out=None, wsplit=
         M, K = a.shape
         N = w.shape[0]
         b = bias.data_ptr() if bias is not None else None
-        r = residual.data_ptr() if residual is not None else None
         res = SplitAct.empty(M, N, a.device) if out_split else (
             out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device))
         flags = GEMM_W_TILED if getattr(wsplit, "tiled", False) else 0
+        if isinstance(residual, SplitAct):  # the shortcut read from a pair (hi + lo): no fp32 copy of that tensor needed
+            if residual.shape != (M, N):
+                raise ValueError(f"residual pair of shape {residual.shape} for a [{M}, {N}] product")
+            with torch.cuda.device(a.device):
+                _lib.check(lib.mq_gemm_nt_bf16x3s_respair_f32(
+                    a.hi.data_ptr(), a.lo.data_ptr(), wsplit[0].data_ptr(), wsplit[1].data_ptr(), b, residual.hi.data_ptr(),
+                    residual.lo.data_ptr(), None if out_split else res.data_ptr(), res.hi.data_ptr() if out_split else None,
+                    res.lo.data_ptr() if out_split else None, M, N, K, epilogue | flags, _stream(a.hi)), "mq_gemm_nt_bf16x3s_respair_f32")
+            return res
+        r = residual.data_ptr() if residual is not None else None
         with torch.cuda.device(a.device):
             _lib.check(lib.mq_gemm_nt_bf16x3s_f32(
                 a.hi.data_ptr(), a.lo.data_ptr(), wsplit[0].data_ptr(), wsplit[1].data_ptr(), b, r,
@@ -197,6 +206,11 @@ def gemm_nt(a, w, bias=None, residual=None, epilogue=EPI_NONE, out=None, wsplit=
 def _gemm_mode():
     """MQ_ENC_GEMM = split_bf16 (default) | f32"""
     return os.environ.get("MQ_ENC_GEMM", "split_bf16")
+
+
+def _pair_residual():
+    """MQ_ENC_RESIDUAL = pair (default) | f32: where the post-LayerNorm shortcuts of the BERT stacks are read from"""
+    return os.environ.get("MQ_ENC_RESIDUAL", "pair") != "f32"
 
 
 def layernorm(x, g, b, eps, out=None):
@@ -414,13 +428,15 @@ class BertEncoderHIP(_HipEncoder):
             if split:
                 qkv = gemm_nt(hs, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
                 ctx = attention_packed(qkv, cu, classes, self.heads, scale, split=True)
+                pair_res = _pair_residual()  # see _layers
                 if last:  # everything after the last attention is row-wise: only the [CLS] rows go on
-                    ctx, h = ctx.rows(cls_rows), h.index_select(0, cls_rows).contiguous()
-                a = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, wsplit=sp("wo"))
-                h1, h1s = layernorm_split(a, w("g1"), w("b1"), self.eps, f32_out=a)
+                    ctx, h = ctx.rows(cls_rows), (h.index_select(0, cls_rows).contiguous() if h is not None else None)
+                    hs = hs.rows(cls_rows)
+                a = gemm_nt(ctx, w("wo"), w("bo"), hs if pair_res else h, EPI_BIAS_RESIDUAL, wsplit=sp("wo"))
+                h1, h1s = layernorm_split(a, w("g1"), w("b1"), self.eps, f32_out=a, want_f32=not pair_res)
                 f = gemm_nt(h1s, w("wi"), w("bi"), None, EPI_BIAS_GELU, wsplit=sp("wi"), out_split=True)
-                o = gemm_nt(f, w("w2"), w("b2"), h1, EPI_BIAS_RESIDUAL, wsplit=sp("w2"))
-                h, hs = layernorm_split(o, w("g2"), w("b2n"), self.eps, f32_out=o)
+                o = gemm_nt(f, w("w2"), w("b2"), h1s if pair_res else h1, EPI_BIAS_RESIDUAL, wsplit=sp("w2"))
+                h, hs = layernorm_split(o, w("g2"), w("b2n"), self.eps, f32_out=o, want_f32=not pair_res or last)
             else:
                 qkv = gemm_nt(h, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
                 ctx = attention_packed(qkv, cu, classes, self.heads, scale)
@@ -454,12 +470,17 @@ class BertEncoderHIP(_HipEncoder):
                     # DPR reads only last_hidden_state[:, 0]: after the last attention, the output projection, both
                     # LayerNorms and the FFN are row-wise, so run them on the [CLS] rows alone (same numbers, 1/L of the rows)
                     ctx = ctx.first_rows(B, L)
-                    h = h.view(B, L, H)[:, 0, :].contiguous()
-                a = gemm_nt(ctx, w("wo"), w("bo"), h, EPI_BIAS_RESIDUAL, wsplit=sp("wo"))
-                h1, h1s = layernorm_split(a, w("g1"), w("b1"), self.eps, f32_out=a)
+                    h = h.view(B, L, H)[:, 0, :].contiguous() if h is not None else None
+                    hs = hs.first_rows(B, L)
+                # Shortcuts read the LayerNorm outputs from their (hi, lo) pairs (value hi + lo: 16 mantissa bits, 2^-17 relative),
+                # so a LayerNorm writes the pair only -- a third less traffic per LayerNorm (MQ_ENC_RESIDUAL=f32: the fp32 copies)
+                pair_res = _pair_residual()
+                a = gemm_nt(ctx, w("wo"), w("bo"), hs if pair_res else h, EPI_BIAS_RESIDUAL, wsplit=sp("wo"))
+                h1, h1s = layernorm_split(a, w("g1"), w("b1"), self.eps, f32_out=a, want_f32=not pair_res)
                 f = gemm_nt(h1s, w("wi"), w("bi"), None, EPI_BIAS_GELU, wsplit=sp("wi"), out_split=True)
-                o = gemm_nt(f, w("w2"), w("b2"), h1, EPI_BIAS_RESIDUAL, wsplit=sp("w2"))
-                h, hs = layernorm_split(o, w("g2"), w("b2n"), self.eps, f32_out=o)
+                o = gemm_nt(f, w("w2"), w("b2"), h1s if pair_res else h1, EPI_BIAS_RESIDUAL, wsplit=sp("w2"))
+                need_f32 = not pair_res or output_hidden_states or i == self.layers - 1
+                h, hs = layernorm_split(o, w("g2"), w("b2n"), self.eps, f32_out=o, want_f32=need_f32)
             else:
                 qkv = gemm_nt(h, w("wqkv"), w("bqkv"), None, EPI_BIAS, wsplit=sp("wqkv"))
                 ctx = attention(qkv, mask, B, L, self.heads, scale)
