@@ -1139,14 +1139,105 @@ int mq_l2norm_rows_f32(float* rows_dev, int64_t n, int d, void* stream) {
     return mq_l2norm_rows_form_f32(rows_dev, n, d, MQ_L2NORM_NUMPY, stream);
 }
 
+// ---- k beyond the screen's own range (SCREEN_MAX_K) ------------------------------------------------------------------------
+// The screen's bounded buffers serve k <= 224 (256 stripe maxima per query, 256 keys in the final sort).  A larger k is served by
+// PARTITIONS: the rows are cut into P contiguous ranges, each range is searched for its exact top-224 by the screened pipeline, the
+// P lists are merged, and the merge PROVES the result: the top-k of the union is the top-k of the lists unless some range delivered
+// its whole list into it (it might have held a 225th) -- then that query tile is recomputed by the exact rounds, like a tile whose
+// screening buffers overflowed.  P = ceil(k / 112): on exchangeable data a range holds ~k / P <= 112 of the top k, half of what it
+// can deliver; a KB sorted by similarity to the query defeats it and pays the exact rounds for those tiles.  Cost: one pass of the
+// scan over all rows + P tails, instead of ceil(k / 128) exact fp32 scans (k = 256 at 1.5M x 768, 4096 queries: 146 ms).
+constexpr int PART_K = SCREEN_MAX_K;       // neighbours asked of each range
+constexpr int PART_SHARE = 112;            // expected neighbours per range at most
+constexpr int PART_MAX = 16;               // ranges at most: k <= 1792
+constexpr int PART_MIN_ROWS = 16384;       // ranges smaller than this: the exact rounds are as fast
+
+struct PartPlan { int P; int64_t per; };
+static PartPlan partition_plan(int64_t N, int k) {
+    PartPlan pl{0, 0};
+    static const int off = [] { const char* e = getenv("MQ_KNN_PARTITIONS"); return e && atoi(e) == 0; }();
+    if (off || k <= SCREEN_MAX_K) return pl;
+    const int P = (k + PART_SHARE - 1) / PART_SHARE;
+    if (P > PART_MAX) return pl;
+    const int64_t per = round_up((N + P - 1) / P, TQ);  // the bf16 copy is stored in 256-row tiles
+    if (per < PART_MIN_ROWS || (int64_t)(P - 1) * per >= N) return pl;
+    pl.P = P; pl.per = per;
+    return pl;
+}
+static size_t partition_extra_bytes(int64_t N, int nq, int k) {
+    const PartPlan pl = partition_plan(N, k);
+    if (!pl.P) return 0;
+    const size_t e = (size_t)pl.P * (size_t)(nq > 0 ? nq : 1) * PART_K;
+    return round_up((int64_t)(e * 4), 256) + round_up((int64_t)(e * 8), 256) + round_up((int64_t)((nq + TQ - 1) / TQ + 1) * 4, 256);
+}
+
+// One workgroup per query: the P lists (PART_K entries each, best first) -> the k best of their union, best first, and the proof
+// obligation: a range all of whose PART_K entries are inside the answer (and which holds more rows than that) flags the query's tile.
+__global__ __launch_bounds__(256) void partition_merge_kernel(const float* __restrict__ Dp, const long long* __restrict__ Ip, int P, int nq,
+                                                              int k, int l2, unsigned flip, long long id_offset, long long per,
+                                                              long long N, float* __restrict__ D, long long* __restrict__ I,
+                                                              int* __restrict__ flags) {
+    __shared__ u64 keys[PART_MAX * 256];
+    __shared__ int cnt[PART_MAX];
+    const int q = blockIdx.x, t = threadIdx.x;
+    const int total = P * PART_K;
+    int n2 = 256;
+    while (n2 < total) n2 <<= 1;
+    if (t < PART_MAX) cnt[t] = 0;
+    for (int e = t; e < n2; e += 256) {
+        u64 key = 0ull;
+        if (e < total) {
+            const int p = e / PART_K, j = e - p * PART_K;
+            const size_t at = ((size_t)p * nq + q) * PART_K + j;
+            const long long id = Ip[at];
+            if (id >= 0) {
+                const float sc = Dp[at];
+                key = make_key(l2 ? -sc : sc, (unsigned)id ^ flip);
+            }
+        }
+        keys[e] = key;
+    }
+    __syncthreads();
+    // bitonic sort, descending
+    for (int sz = 2; sz <= n2; sz <<= 1)
+        for (int j = sz >> 1; j > 0; j >>= 1) {
+            for (int e = t; e < n2 / 2; e += 256) {
+                const int lo = ((e & ~(j - 1)) << 1) | (e & (j - 1)), hi = lo | j;
+                const bool desc = (lo & sz) == 0;
+                const u64 x = keys[lo], y = keys[hi];
+                if ((x < y) == desc) { keys[lo] = y; keys[hi] = x; }
+            }
+            __syncthreads();
+        }
+    for (int e = t; e < k; e += 256) {
+        const u64 key = keys[e];
+        float sc = l2 ? FLT_MAX : -FLT_MAX;  // FAISS's heap neutral values in unfilled slots
+        long long id = -1;
+        if (key) {
+            const unsigned row = key_row(key) ^ flip;
+            const float g = key_score(key);
+            sc = l2 ? -g : g;
+            id = (long long)row + id_offset;
+            atomicAdd(&cnt[(int)(row / (unsigned long long)per)], 1);
+        }
+        D[(size_t)q * k + e] = sc;
+        I[(size_t)q * k + e] = id;
+    }
+    __syncthreads();
+    if (t < P) {
+        const long long rows = (t + 1) * per <= N ? per : N - t * per;
+        if (cnt[t] >= PART_K && rows > PART_K) flags[q / TQ] = 1;
+    }
+}
+
 size_t mq_knn_workspace_bytes(int64_t N, int d, int nq, int k) {
     if (N < 0 || d <= 0 || nq < 0 || k <= 0 || k > MQ_KNN_MAX_K) return 0;
-    return geometry(N, d, nq, k, num_cus()).total;
+    return geometry(N, d, nq, k, num_cus()).total + partition_extra_bytes(N, nq, k);
 }
 
 size_t mq_knn_workspace_bytes_metric(int64_t N, int d, int nq, int k, int metric) {
     if (N < 0 || d <= 0 || nq < 0 || k <= 0 || k > MQ_KNN_MAX_K || (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2)) return 0;
-    return geometry(N, d, nq, k, num_cus(), metric).total;
+    return geometry(N, d, nq, k, num_cus(), metric).total + partition_extra_bytes(N, nq, k);
 }
 
 int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[8]) {
@@ -1166,7 +1257,9 @@ int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[8]) {
 int mq_knn_screen_scan_kind(int64_t N, int d, int nq, int k, int metric) {
     if (N <= 0 || d <= 0 || nq <= 0 || k <= 0 || k > MQ_KNN_MAX_K) return MQ_EINVAL;
     if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
-    if (k > SCREEN_MAX_K || (metric == MQ_METRIC_L2 && nq < MQ_KNN_L2_DIRECT_BELOW)) return MQ_SCAN_KIND_NONE;
+    if (metric == MQ_METRIC_L2 && nq < MQ_KNN_L2_DIRECT_BELOW) return MQ_SCAN_KIND_NONE;
+    if (const PartPlan pl = partition_plan(N, k); pl.P) { N = pl.per; k = PART_K; }  // the scan of each row range
+    if (k > SCREEN_MAX_K) return MQ_SCAN_KIND_NONE;
     const Geometry g = geometry(N, d, nq, k, num_cus(), metric);
     return small_scan_serves(g, N, screen_dp(d, metric), k) ? MQ_SCAN_KIND_STREAM : MQ_SCAN_KIND_TILE;
 }
@@ -1441,6 +1534,40 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
             MQ_HIP(hipGetLastError());
         }
         q_rm = qtmp;
+    }
+    if (const PartPlan pl = partition_plan(N, k); pl.P) {
+        // SCREEN_MAX_K < k <= 1792: P contiguous row ranges, each searched for its exact top-224 by this same function, then merged
+        // and proved (partition_merge_kernel); flagged query tiles are recomputed by the exact rounds below
+        char* extra = ws + g.total;
+        const size_t e = (size_t)pl.P * (size_t)nq * PART_K;
+        float* Dp = (float*)extra;
+        long long* Ip = (long long*)(extra + round_up((int64_t)(e * 4), 256));
+        int* pflags = (int*)((char*)Ip + round_up((int64_t)(e * 8), 256));
+        if (ws_bytes < g.total + partition_extra_bytes(N, nq, k)) return MQ_EWORKSPACE;
+        const int dpb = screen_dp(d, metric);
+        for (int p_ = 0; p_ < pl.P; ++p_) {
+            const int64_t r0 = (int64_t)p_ * pl.per, rows = r0 + pl.per <= N ? pl.per : N - r0;
+            const int rc = mq_knn_search_screened_f32(nullptr, sqnorm_dev + r0, rowmajor_dev + (size_t)r0 * d, bf16_dev + (size_t)r0 * dpb,
+                                                      xstats_dev, rows, d, queries_dev, nq, PART_K, metric, flags & MQ_KNN_ALL_FLAGS, r0,
+                                                      Dp + (size_t)p_ * nq * PART_K, (int64_t*)Ip + (size_t)p_ * nq * PART_K, ws_dev,
+                                                      g.total, stream, p_ == 0 ? ev_scan_begin : nullptr,
+                                                      p_ == pl.P - 1 ? ev_scan_end : nullptr);
+            if (rc != MQ_OK) return rc;
+        }
+        MQ_HIP(hipMemsetAsync(pflags, 0, (size_t)g.nqt * 4, st));
+        hipLaunchKernelGGL(partition_merge_kernel, dim3((unsigned)nq), dim3(256), 0, st, Dp, Ip, pl.P, nq, k, l2, flip, (long long)id_offset,
+                           (long long)pl.per, (long long)N, D_dev, (long long*)I_dev, pflags);
+        MQ_HIP(hipGetLastError());
+        // flagged tiles: the exact rounds (no-op otherwise: every workgroup of an unflagged tile returns at once)
+        MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
+        hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((nq + PANEL - 1) / PANEL)), dim3(256), 0, st, q_rm, (int64_t)nq, d,
+                           g.dpad, (int64_t)0, 0, Qp, qn, (const int*)pflags);
+        MQ_HIP(hipGetLastError());
+        ScanArgs a;
+        a.Xp = packed_dev ? packed_dev : rowmajor_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = pools; a.d = d;
+        a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = nullptr; a.only = pflags;
+        a.flip = flip; a.ceil = nullptr;
+        return exact_scan_rounds(metric, packed_dev == nullptr, a, g, nq, k, id_offset, D_dev, I_dev, ws, pflags, st, nullptr, nullptr);
     }
     if (k > SCREEN_MAX_K) {
         // More than SCREEN_MAX_K neighbours: the bounded screening buffers are sized for the reference's k = 100 (the pools hold
