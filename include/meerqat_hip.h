@@ -41,7 +41,9 @@ extern "C" {
  * fused scan keeps up to MQ_KNN_FUSED_K neighbours; a larger k (up to MQ_KNN_MAX_K, FAISS-GPU's own limit) is served by
  * ceil(k / 128) scans, round r + 1 admitting only candidates strictly below the last (score, id) key of round r -- the
  * rounds' results concatenate into the exact sorted top-k.  The rounds are exact fp32 scans; mq_knn_search_screened_f32 serves
- * k <= 224 through its screen (same results) and takes the rounds beyond. */
+ * k <= 224 through its screen and 225 <= k <= 1792 through the screen over ceil(k / 112) contiguous ROW RANGES whose top-224 lists
+ * are merged -- the merge proves the union's top-k (no range delivered its whole list into it) or hands the query tile to the
+ * rounds -- same results either way; it takes the rounds beyond 1792 and on shards too small for ranges (< 16,384 rows each). */
 #define MQ_KNN_FUSED_K 128
 #define MQ_KNN_MAX_K 2048
 
@@ -173,8 +175,10 @@ int mq_knn_search_f32_ev(const float *packed_dev, const float *sqnorm_dev, int64
  * Query tiles whose bounded candidate buffers overflow are recomputed by the exact scan inside the
  * same call (from the panel copy, or from the row-major copy when packed_dev is NULL: same MFMA sequence, same bits, a
  * slower operand path); FAISS's small-batch L2 form (MQ_KNN_L2_DIRECT_BELOW) likewise reads whichever copy exists.
- * Workspace: mq_knn_workspace_bytes (covers both paths).  k > 224: the call is served by the exact scan in
- * ceil(k / 128) rounds (the bounded screening buffers are sized for the reference's k = 100; up to 224 they still hold).
+ * Workspace: mq_knn_workspace_bytes (covers all paths).  The bounded screening buffers are sized for the reference's k = 100 and hold
+ * up to k = 224; 225 <= k <= 1792 runs the screen per row range and merges (above; 1.5M x 768, 4096 queries: k = 100 / 224 / 256 / 512 /
+ * 1024 / 1792 = 8.6 / 10.4 / 14.3 / 17.7 / 25.6 / 32.8 ms, where ceil(k / 128) exact rounds took 147 ms at k = 256 and 294 ms at 512);
+ * MQ_KNN_PARTITIONS=0 or k > 1792: the exact rounds.
  * ------------------------------------------------------------------------------------------- */
 size_t mq_knn_screen_bytes(int64_t n_rows, int d, int metric);
 int mq_knn_screen_prepare(const float *packed_dev, const float *sqnorm_dev, int64_t capacity_rows, int d, int metric,
@@ -196,8 +200,9 @@ int mq_knn_screen_stats(int64_t N, int d, int nq, int k, const void *ws_dev, int
  * (screen_scan_kernel) or, for ONE query tile (nq <= 256 -- the reference's Dataset.map batch,
  * experiments/ir/viquae/dpr/search/config.json:25 -> meerqat/ir/search.py:146) over a shard of at least 65,536 rows with at
  * most 768 bf16 columns and k <= 128, the streaming kernel that keeps the queries in registers (csrc/knn_small.inc).
- * MQ_SCAN_KIND_NONE: the call is not served by a screening scan at all (k > 224: exact rounds; fewer than 20 L2 queries:
- * FAISS's direct form).  Negative: MQ_EINVAL.  Environment: MQ_KNN_SMALL=0 switches the streaming kernel off,
+ * For 225 <= k <= 1792 the answer describes the scan of one row range.
+ * MQ_SCAN_KIND_NONE: the call is not served by a screening scan at all (k > 1792 or row ranges too small: exact rounds; fewer
+ * than 20 L2 queries: FAISS's direct form).  Negative: MQ_EINVAL.  Environment: MQ_KNN_SMALL=0 switches the streaming kernel off,
  * MQ_KNN_SMALL_MIN_TILES=<n> sets its floor of 32-row tiles per workgroup (default 8). */
 #define MQ_SCAN_KIND_NONE 0
 #define MQ_SCAN_KIND_TILE 1

@@ -37,7 +37,7 @@ from . import _lib
 
 METRIC_INNER_PRODUCT = 0  # faiss.METRIC_INNER_PRODUCT
 METRIC_L2 = 1  # faiss.METRIC_L2
-MAX_K = 2048  # MQ_KNN_MAX_K; the screened search serves k <= 224, a larger k runs ceil(k / 128) exact scans (include/meerqat_hip.h)
+MAX_K = 2048  # MQ_KNN_MAX_K; the screened search serves k <= 224 itself, k <= 1792 over row ranges, beyond: ceil(k / 128) exact scans (include/meerqat_hip.h)
 FLAG_L2NORM_QUERIES, FLAG_TIE_ID_DESC, MERGE_TIE_ID_DESC = 1, 2, 0x100  # MQ_KNN_FLAG_*, MQ_MERGE_TIE_ID_DESC
 FLAG_L2NORM_FAISS = 4                            # MQ_KNN_FLAG_L2NORM_FAISS
 FLAG_PHASE_FRONT, FLAG_PHASE_TAIL = 8, 16        # MQ_KNN_FLAG_PHASE_*: the two halves of one screened search
