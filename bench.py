@@ -586,6 +586,27 @@ def main():
             }
         except Exception as e:  # never a reason to lose the line
             small_batch = {"error": repr(e)}
+    # k beyond the screen's own range (`--k` is a user option of the reference, meerqat/ir/search.py:12): the same 4096 queries at
+    # k = 256 and 512, served over row ranges (csrc/knn.hip partition_plan) where round 3 ran ceil(k / 128) exact scans
+    big_k = None
+    if world == 1 and mode == "screened" and not args.no_other_path:
+        try:
+            big_k = {"workload": f"{nqc} queries x {rows}x{DIM} KB, exact IP top-k through MI355XFlatIndex.search_device", "ms": {}}
+            keep_ws = local._ws
+            for kk in (256, 512):
+                local.search_device(Q[:nqc], kk)
+                torch.cuda.synchronize()
+                tb0 = time.perf_counter()
+                for _ in range(3):
+                    local.search_device(Q[:nqc], kk)
+                torch.cuda.synchronize()
+                big_k["ms"][str(kk)] = round((time.perf_counter() - tb0) / 3 * 1e3, 3)
+                big_k.setdefault("scan_kind", {})[str(kk)] = local.scan_kind(nqc, kk)
+            big_k["x_k100_step"] = {kk: None for kk in big_k["ms"]}
+            local._ws = keep_ws
+            torch.cuda.empty_cache()
+        except Exception as e:
+            big_k = {"error": repr(e)}
     other = None
     if world == 1 and not args.no_other_path:
         which = "exact_f32" if mode == "screened" else "screened"
@@ -687,6 +708,10 @@ def main():
                                        "max_candidates_of_a_query": st[2]}
         if small_batch is not None:
             rec.setdefault("secondary", {})["small_batch"] = small_batch
+        if big_k is not None:
+            if "ms" in big_k:
+                big_k["x_k100_step"] = {kk: round(v / rec["ms_per_step"], 2) for kk, v in big_k["ms"].items()}
+            rec.setdefault("secondary", {})["big_k"] = big_k
         if other is not None:
             rec["other_exact_path"] = other
             if other["path"] == "exact_f32":
