@@ -60,8 +60,14 @@ def parse():
     ap.add_argument("--no-other-path", action="store_true", help="do not time the other exact path next to the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encoders", action="store_true", help="skip the secondary encoder throughput figures")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed headline steps (no CPU baseline, encoders, other path, small-batch / big-k legs): the command "
+                         "tools/profile_round.sh profiles, so that the rocprofv3 average of the scan kernel is the headline launch's")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline = args.no_encoders = args.no_other_path = True
+    return args
 
 
 def build_shard(idx, rows, seed, device):
@@ -540,7 +546,7 @@ def main():
     # (experiments/ir/viquae/dpr/search/config.json:25 -> meerqat/ir/search.py:146).  One query tile = the KB is streamed once per
     # search: the regime north_star's "HBM-read roofline" is about.  Same shard, same C-ABI call, HIP events around the scan.
     small_batch = None
-    if world == 1 and mode == "screened":
+    if world == 1 and mode == "screened" and not args.headline_only:
         try:
             nqs, reps = 256, 30
             qs = Q[:nqs].contiguous()
@@ -589,7 +595,7 @@ def main():
     # k beyond the screen's own range (`--k` is a user option of the reference, meerqat/ir/search.py:12): the same 4096 queries at
     # k = 256 and 512, served over row ranges (csrc/knn.hip partition_plan) where round 3 ran ceil(k / 128) exact scans
     big_k = None
-    if world == 1 and mode == "screened" and not args.no_other_path:
+    if world == 1 and mode == "screened" and not args.no_other_path and not args.headline_only:
         try:
             big_k = {"workload": f"{nqc} queries x {rows}x{DIM} KB, exact IP top-k through MI355XFlatIndex.search_device", "ms": {}}
             keep_ws = local._ws

@@ -142,7 +142,7 @@ def clip_throughput(B=3072, steps=2, device="cuda"):
     return {"images_per_s": B / t, "ms_per_batch": t * 1e3, "batch": B, "tflops": 8.82e9 * B / t / 1e12}
 
 
-def arcface_throughput(B=328, steps=3, device="cuda"):
+def arcface_throughput(B=656, steps=3, device="cuda"):
     """ArcFace r50 (meerqat/image/face_recognition.py:55-61) on aligned 112 x 112 faces: seeded weights (oracle/arcface.py's
     layout), fp32-class arithmetic.  Algorithmic work: 12.63 GFLOP per face (6.31 G multiply-adds: the 50 convolutions + fc)."""
     import os, sys

@@ -69,10 +69,11 @@ class ArcFaceR50(_HipEncoder):
     image_size = 112
     num_features = 512
 
-    def __init__(self, state, layers=LAYERS, chunk=328):
+    def __init__(self, state, layers=LAYERS, chunk=656):
         super().__init__()
         # chunk = faces per forward: the 14 x 14 stage (half the FLOPs) runs ceil(faces * 196 / 256) workgroups of one 256-row tile
-        # each -- 328 faces = 252 of the 256 CUs in one round (256 faces: 196; measured 19.3 k -> 21.3 k faces/s)
+        # each -- 328 faces = 252 of the 256 CUs in one round, 656 = 503 in two (256 faces: 196 of 256; measured 19.3 k -> 21.3 k
+        # faces/s at 328 with the first implicit kernel; 23.8 k / 24.7 k at 328 / 656 with the final one)
         state = {k: _np(v).astype(np.float32) for k, v in state.items() if not k.endswith("num_batches_tracked")}
         self.layers, self.chunk = tuple(layers), int(chunk)
         self._convs, self._vecs = {}, {}
