@@ -686,8 +686,8 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4),
                 "kernel_ms": round(scan_ms, 3),
-                "kernel_ms_profile": profile_kernel_ms(kernel.split("<")[0].split(" ")[0])[0],
-                "kernel_ms_profile_from": profile_kernel_ms(kernel.split("<")[0].split(" ")[0])[1],
+                "kernel_ms_profile": profile_kernel_ms(kernel.split("<")[0].split(" ")[0], "_kernel_stats.csv" if mode == "screened" else "_exact_kernel_stats.csv")[0],
+                "kernel_ms_profile_from": profile_kernel_ms(kernel.split("<")[0].split(" ")[0], "_kernel_stats.csv" if mode == "screened" else "_exact_kernel_stats.csv")[1],
                 "algorithmic_flops_per_launch": flops,
                 "algorithmic_hbm_bytes_per_launch": alg_bytes,
                 "hbm_frac_at_one_pass": round(alg_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),

@@ -28,6 +28,9 @@ for sub, name in (("kt", f"{tag}_kernel_stats.csv"), ("enc", f"{tag}_encoders_ke
 f = first("nq256_kt/**/*kernel_stats.csv")
 if f:
     shutil.copy(f, os.path.join(dst, f"{tag}_nq256_kernel_stats.csv"))
+f = first("exact_kt/**/*kernel_stats.csv")
+if f:
+    shutil.copy(f, os.path.join(dst, f"{tag}_exact_kernel_stats.csv"))
 
 
 def collect(subs):
@@ -54,7 +57,7 @@ small = collect(("nq256_fetch", "nq256_write", "nq256_sq", "nq256_tcc"))
 if small:
     json.dump(small, open(os.path.join(dst, f"{tag}_nq256_pmc.json"), "w"), indent=1)
 pmc = {}
-for sub in ("fetch", "write", "sq", "tcc"):
+for sub in ("fetch", "write", "sq", "tcc", "exact_fetch", "exact_write"):
     f = first(f"{sub}/**/*counter_collection.csv")
     if not f:
         continue
@@ -97,9 +100,30 @@ if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                                               "fetch_kb_raw": c["FETCH_SIZE"]["max_per_launch"], "write_kb_raw": c["WRITE_SIZE"]["max_per_launch"]}
 if len(out) > 1:
     json.dump(out, open(os.path.join(dst, "knn_traffic.json"), "w"), indent=1)
-for a, b in (("bench.json", f"{tag}_bench_screened.json"), ("bench_exact.json", f"{tag}_bench_exact_f32.json")):
+def stats_avg_ms(path, prefix):
+    """average launch duration of the real (> 0.1 ms) launches of a kernel in a rocprofv3 kernel_stats.csv"""
+    if not os.path.exists(path):
+        return None
+    best = None
+    for row in csv.DictReader(open(path)):
+        name = row["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        if name.startswith(prefix) and float(row["AverageNs"]) > 1e5 and (best is None or float(row["TotalDurationNs"]) > float(best["TotalDurationNs"])):
+            best = row
+    return round(float(best["AverageNs"]) / 1e6, 4) if best else None
+
+
+for a, b, stats, prefix in (("bench.json", f"{tag}_bench_screened.json", f"{tag}_kernel_stats.csv", "screen_scan_kernel"),
+                            ("bench_exact.json", f"{tag}_bench_exact_f32.json", f"{tag}_exact_kernel_stats.csv", "knn_scan_kernel")):
     f = os.path.join(src, a)
     if os.path.exists(f) and os.path.getsize(f):
-        shutil.copy(f, os.path.join(dst, b))
+        rec = json.load(open(f))
+        # the bench ran on the box BEFORE these summaries existed: it quoted the previous tracked file; point it at this round's
+        ms = stats_avg_ms(os.path.join(dst, stats), prefix)
+        if ms is not None and "roofline" in rec:
+            rec["roofline"]["kernel_ms_profile"], rec["roofline"]["kernel_ms_profile_from"] = ms, f"profiles/{stats}"
+            t = out.get(("screened" if prefix.startswith("screen") else "exact_f32") + "_1500000x768_nq4096_k100")
+            if t:
+                rec["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+        json.dump(rec, open(os.path.join(dst, b), "w"))
 print(json.dumps({k: {n: round(c["max_per_launch"], 1) for n, c in v.items()} for k, v in pmc.items()
                   if k.startswith(("screen_scan_kernel", "knn_scan_kernel<0", "rescore_kernel", "cand_select_kernel"))}, indent=1))
