@@ -70,7 +70,8 @@ def test_not_served_cases_keep_the_tile_kernel():
     X = rng.standard_normal((66000, 768), dtype=np.float32)
     ip, l2 = _index(X, 0), _index(X, 1)
     assert ip.scan_kind(256, 100) == "stream" and ip.scan_kind(257, 100) == "tile"    # more than one query tile
-    assert ip.scan_kind(256, 129) == "tile" and ip.scan_kind(10, 300) == "none"        # k beyond the fused selection / the screen
+    assert ip.scan_kind(256, 129) == "tile"                                            # k beyond the fused selection
+    assert ip.scan_kind(10, 300) == "tile" and ip.scan_kind(10, 1800) == "none"        # k beyond the screen: row ranges (round 4) / exact rounds
     assert l2.scan_kind(256, 100) == "tile"                                            # d = 768 + the two L2 columns: 13 K blocks
     assert l2.scan_kind(19, 100) == "none"                                             # FAISS's small-batch L2 form
     small = _index(X[:60000], 0)
