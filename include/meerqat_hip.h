@@ -482,6 +482,8 @@ int mq_im2col_split_f32(const float *x_dev, int B, int H, int W, int C, int nchw
 #define MQ_CONV_TILE_512x128 2
 #define MQ_CONV_TILE_256x128 3
 #define MQ_CONV_TILE_512x64 4
+#define MQ_CONV_TILE_PATCH_256x64 5 /* stride 1, W <= 127, with MQ_CONV_K_CHANNEL_MAJOR: the nine taps of a channel block read one
+                                     * LDS-resident input patch (256 + 2 W + 2 pixels) instead of nine gathers; same bits */
 /* OR into `tile`: walk K as (32-channel block, tap) instead of (tap, block) -- the nine taps of a block re-read the same input
  * lines back to back, so a workgroup's live footprint in L2 is one block's rows instead of all C channels'.  The sum order then
  * differs from the explicit path's (equal within fp32 rounding, not bit for bit). */

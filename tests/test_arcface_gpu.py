@@ -89,6 +89,24 @@ def test_implicit_conv3x3_equals_im2col_plus_gemm_bit_for_bit(tile, B, H, W, C, 
                                        bias.data_ptr(), None, res.data_ptr(), None, None, Y4.data_ptr(), None, None, zeros.data_ptr(),
                                        tile | 0x100, st), "mq_conv3x3_pair_f32")
     assert (Y4 - y_res).abs().max() <= 1e-5 * float(y_res.abs().max())
+    # the patch kernel (stride 1): the taps of a channel block read one LDS-resident patch -- the bits of the channel-major gather
+    if stride == 1 and W <= 127:
+        Y5 = torch.zeros((M, N), device="cuda")
+        P5 = SplitAct.empty(M, N, x.device)
+        _lib.check(lib.mq_conv3x3_pair_f32(xin.hi.data_ptr(), xin.lo.data_ptr(), B, H, W, C, stride, ws[0].data_ptr(), ws[1].data_ptr(), N,
+                                           bias.data_ptr(), None, res.data_ptr(), scale.data_ptr(), shift.data_ptr(), Y5.data_ptr(),
+                                           P5.hi.data_ptr(), P5.lo.data_ptr(), zeros.data_ptr(), 5 | 0x100, st), "mq_conv3x3_pair_f32")
+        assert torch.equal(Y5, Y4)
+        P6 = SplitAct.empty(M, N, x.device)
+        _lib.check(lib.mq_conv3x3_pair_f32(xin.hi.data_ptr(), xin.lo.data_ptr(), B, H, W, C, stride, ws[0].data_ptr(), ws[1].data_ptr(), N,
+                                           bias.data_ptr(), slope.data_ptr(), None, None, None, None, P6.hi.data_ptr(), P6.lo.data_ptr(),
+                                           zeros.data_ptr(), 5 | 0x100, st), "mq_conv3x3_pair_f32")
+        P7 = SplitAct.empty(M, N, x.device)
+        _lib.check(lib.mq_conv3x3_pair_f32(xin.hi.data_ptr(), xin.lo.data_ptr(), B, H, W, C, stride, ws[0].data_ptr(), ws[1].data_ptr(), N,
+                                           bias.data_ptr(), slope.data_ptr(), None, None, None, None, P7.hi.data_ptr(), P7.lo.data_ptr(),
+                                           zeros.data_ptr(), tile | 0x100, st), "mq_conv3x3_pair_f32")
+        for got, want in zip(P6.rowmajor(), P7.rowmajor()):
+            assert torch.equal(got, want)
     # no pair output requested: Y alone
     Y3 = torch.zeros((M, N), device="cuda")
     _lib.check(lib.mq_conv3x3_pair_f32(xin.hi.data_ptr(), xin.lo.data_ptr(), B, H, W, C, stride, ws[0].data_ptr(), ws[1].data_ptr(), N,

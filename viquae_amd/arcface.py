@@ -168,6 +168,9 @@ class ArcFaceR50(_HipEncoder):
         assert c.k == 3 and c.pad == 1 and xin.shape == (B * H * W, c.cin)
         Ho, Wo = (H - 1) // c.stride + 1, (W - 1) // c.stride + 1
         M, dev = B * Ho * Wo, xin.device
+        if (tile == 0 and c.stride == 1 and W <= 127 and str(c.cout) in os.environ.get("MQ_CONV_PATCH", "64").split(",")
+                and os.environ.get("MQ_CONV_KORDER", "channel") != "tap"):
+            tile = 5  # MQ_CONV_TILE_PATCH_256x64: few output channels -- the nine taps read one LDS-resident input patch
         wh, wl = self._wsplit(name + ".w2")
         bias = getattr(self, (name + ".b").replace(".", "_"))
         zeros = self.__dict__.setdefault("_zero_pages", {})

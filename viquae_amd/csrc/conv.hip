@@ -343,6 +343,192 @@ __global__ __launch_bounds__(1024) void conv3x3_x3s_kernel(const ConvArgs a) {
         }
 }
 
+// ---- stride-1 3 x 3 convolution with the taps served from ONE LDS-resident input patch (round 4, last) ---------------------------------
+// conv3x3_x3s_kernel gathers, for each of the nine taps of a channel block, the tile's rows again -- nine passes of A through L2 -> LDS.
+// With few output channels there is little work per pass: a 512 x 64 tile moves 73.7 KB per K step for 0.88 us of MFMA work, and
+// the 64-channel stage runs at the rate those bytes arrive (750 / 580 executed TFLOP/s against 1216 at 14 x 14 x 256).  Here a tile
+// is 256 CONSECUTIVE output pixels x 64 channels and the pixels its nine taps read are 256 + 2 W + 2 consecutive input pixels (stride
+// 1: input pixel = output pixel + (kh - 1) W + (kw - 1)): that patch is loaded ONCE per 32-channel block (two LDS buffers, the next
+// block's patch arriving while this one is used) and tap (kh, kw) reads its A fragments kh W + kw rows further down -- the 64-byte rows and
+// their XOR swizzle (keyed by the patch row) make any row offset conflict-free.  Pixels a tap must not see (image borders: the patch is
+// linear in the pixel index, so w = 0 / W - 1 wrap into the neighbouring image row) are zeroed in the fragment registers from a 9-bit
+// mask per lane.  Weights: one 8-KiB stage per tap in a four-stage ring, requested three taps ahead; every wave's DMA count per
+// step is constant (zero-page requests past the end), so the in-order vmcnt immediates are compile-time.  16 waves of 32 x 32.
+// Same products in the same order as conv3x3_x3s_kernel with MQ_CONV_K_CHANNEL_MAJOR: the same bits.
+constexpr int PT_MT = 256, PT_NT = 64, PT_PR = 512, PT_WS = 4;
+constexpr int PT_PATCH = PT_PR * 128;            // one patch buffer: hi rows then lo rows, 64 bytes each
+constexpr int PT_WSTAGE = PT_NT * 128;           // one weight stage: hi rows then lo rows
+constexpr int PT_LDS = 2 * PT_PATCH + PT_WS * PT_WSTAGE;   // 160 KiB
+
+template <int EP>
+__global__ __launch_bounds__(1024) void conv3x3_patch_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const int b = (int)blockIdx.x;
+    const int per = (a.ntm + 7) >> 3;
+    const int mt = __builtin_amdgcn_readfirstlane((b & 7) * per + (b >> 3) / a.ntn);
+    const int nt = __builtin_amdgcn_readfirstlane((b >> 3) % a.ntn);
+    if ((b >> 3) / a.ntn >= per || mt >= a.ntm) return;
+    const int m0 = mt * PT_MT, n0 = nt * PT_NT;
+    const int CB = a.C >> 5, nk = 9 * CB, W = a.W;
+    const int P = a.M;                       // stride 1: as many input pixels as output pixels
+    const int prows = PT_MT + 2 * W + 2;     // patch rows in use
+    const int i = lane & 31, kg = lane >> 5;
+
+    // this lane's output pixel (MFMA row i of the wave's 32 rows) and the taps it may read
+    unsigned mask = 0;
+    {
+        const int m = m0 + 32 * wr + i;
+        const unsigned hw = (unsigned)(a.H * W), mm = m < a.M ? (unsigned)m : 0u;
+        const unsigned pix = mm % hw;
+        const int h = (int)(pix / (unsigned)W), wq = (int)(pix - (unsigned)h * (unsigned)W);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ih = h + t / 3 - 1, iw = wq + t % 3 - 1;
+            if (m < a.M && ih >= 0 && ih < a.H && iw >= 0 && iw < W) mask |= 1u << t;
+        }
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const char* xh = reinterpret_cast<const char*>(a.Xh);
+    const char* xl = reinterpret_cast<const char*>(a.Xl);
+    const char* zp = reinterpret_cast<const char*>(a.zeros);
+    // patch pieces of this wave: rows 16 (w + 16 j) + (lane >> 2), j = 0, 1; slot lane & 3 takes source chunk slot ^ key(row)
+    auto issue_patch = [&](int cb, bool real, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rho = 16 * (w + 16 * j) + (lane >> 2);
+            const int p = m0 - W - 1 + rho;
+            const bool ok = real && rho < prows && p >= 0 && p < P;
+            const unsigned pu = (unsigned)p;
+            const size_t off = ((size_t)(pu >> 8) * (size_t)CB + (size_t)cb) * 16384 +
+                               (size_t)((pu & 255u) * 64u + (((unsigned)(lane & 3) ^ (unsigned)((rho >> 2) & 3)) * 16u));
+            const unsigned dst = lds0 + (unsigned)(buf * PT_PATCH + 16 * (w + 16 * j) * 64);
+            dma16v(ok ? xh + off : zp, dst);
+            dma16v(ok ? xl + off : zp, dst + PT_PR * 64);
+        }
+    };
+    // weight piece of waves 0-7: array w >> 2 (hi, lo), rows 16 (w & 3) ... of the tap's 64-row stage
+    const int wrow = 16 * (w & 3) + (lane >> 2);
+    const unsigned w_voff = (unsigned)(((n0 & 255) + wrow) * 64) + (((unsigned)(lane & 3) ^ (unsigned)((wrow >> 2) & 3)) * 16u);
+    const char* wbase = reinterpret_cast<const char*>((w >> 2) ? a.Wl : a.Wh) + (size_t)(n0 >> 8) * (size_t)nk * 16384;
+    auto issue_w = [&](int step) __attribute__((always_inline)) {  // step = cb * 9 + tap; weights' K order is (tap, channel block)
+        const unsigned dst = lds0 + (unsigned)(2 * PT_PATCH + (step & (PT_WS - 1)) * PT_WSTAGE + (w >> 2) * (PT_NT * 64) + (w & 3) * 1024);
+        if (step < nk) {
+            const int cb = step / 9, tap = step - cb * 9;
+            dma16s(wbase + (size_t)__builtin_amdgcn_readfirstlane(tap * CB + cb) * 16384, w_voff, dst);
+        } else {
+            dma16v(zp, dst);
+        }
+    };
+
+    f32x16 acc = {0};
+    issue_patch(0, true, 0);
+    if (w < 8) { issue_w(0); issue_w(1); issue_w(2); }
+    const int sww = (i >> 2) & 3;
+    const char* wrd0 = smem + 2 * PT_PATCH + (32 * wc + i) * 64;
+    for (int cb = 0; cb < CB; ++cb) {
+        const char* pbuf = smem + (cb & 1) * PT_PATCH;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int step = cb * 9 + tap;
+            // in-order counter: everything up to this step's weight stage (and, at tap 0, this block's patch) has landed when at
+            // most the younger requests are outstanding: two weight pieces, plus the next patch's four between taps 0 and 3
+            if (w < 8) {
+                if (tap == 1 || tap == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else if (tap == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (tap == 0) issue_patch(cb + 1, cb + 1 < CB, (cb + 1) & 1);
+            if (w < 8) issue_w(step + 3);
+            const int off = (tap / 3) * W + (tap % 3);
+            const int rho = 32 * wr + i + off;
+            const int key = (rho >> 2) & 3;
+            const char* ap = pbuf + rho * 64;
+            const char* wp = wrd0 + (step & (PT_WS - 1)) * PT_WSTAGE;
+            const bool ok = (mask >> tap) & 1u;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int c = 2 * m + kg;
+                bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(ap + ((c ^ key) << 4));
+                bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(ap + PT_PR * 64 + ((c ^ key) << 4));
+                const bf16x8_t wh = *reinterpret_cast<const bf16x8_t*>(wp + ((c ^ sww) << 4));
+                const bf16x8_t wl = *reinterpret_cast<const bf16x8_t*>(wp + PT_NT * 64 + ((c ^ sww) << 4));
+                if (!ok) {
+                    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                    ah = __builtin_bit_cast(bf16x8_t, z);
+                    al = __builtin_bit_cast(bf16x8_t, z);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero-page requests past the end still target LDS
+    __syncthreads();
+
+    // ---- epilogue: conv3x3_x3s_kernel's, for one 32 x 32 accumulator
+    float* Ot = reinterpret_cast<float*>(smem) + w * 1024;
+    {
+        const int col = n0 + 32 * wc + i;
+        const float bs = a.bias[col];
+        const float sl = EP == EP_PRELU_PAIR ? a.slope[col] : 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+            float v = acc[reg] + bs;
+            if (EP == EP_PRELU_PAIR) v = v >= 0.f ? v : v * sl;
+            Ot[row * 32 + ((((i >> 3) ^ (row & 3)) << 3) | (i & 7))] = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = 16 * it + (lane >> 2), g = lane & 3;
+            const float* src = Ot + row * 32 + ((g ^ (row & 3)) << 3);
+            float4 u = *reinterpret_cast<const float4*>(src), v = *reinterpret_cast<const float4*>(src + 4);
+            const int gm = m0 + 32 * wr + row, gn = n0 + 32 * wc + 8 * g;
+            if (gm < a.M) {
+                bool pair_out = true;
+                if (EP == EP_RESIDUAL_AFFINE) {
+                    const size_t at = (size_t)gm * a.N + gn;
+                    const float4 ru = *reinterpret_cast<const float4*>(a.R + at), rv = *reinterpret_cast<const float4*>(a.R + at + 4);
+                    u.x += ru.x; u.y += ru.y; u.z += ru.z; u.w += ru.w;
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    *reinterpret_cast<float4*>(a.Y + at) = u;
+                    *reinterpret_cast<float4*>(a.Y + at + 4) = v;
+                    pair_out = a.scale != nullptr;
+                    if (pair_out) {
+                        const float4 su = *reinterpret_cast<const float4*>(a.scale + gn), sv = *reinterpret_cast<const float4*>(a.scale + gn + 4);
+                        const float4 tu = *reinterpret_cast<const float4*>(a.shift + gn), tv = *reinterpret_cast<const float4*>(a.shift + gn + 4);
+                        u.x = __builtin_fmaf(u.x, su.x, tu.x); u.y = __builtin_fmaf(u.y, su.y, tu.y);
+                        u.z = __builtin_fmaf(u.z, su.z, tu.z); u.w = __builtin_fmaf(u.w, su.w, tu.w);
+                        v.x = __builtin_fmaf(v.x, sv.x, tv.x); v.y = __builtin_fmaf(v.y, sv.y, tv.y);
+                        v.z = __builtin_fmaf(v.z, sv.z, tv.z); v.w = __builtin_fmaf(v.w, sv.w, tv.w);
+                    }
+                }
+                if (pair_out) {
+                    const float t[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+                    bf16x8_t h8, l8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const __bf16 hb = (__bf16)t[e];
+                        h8[e] = hb;
+                        l8[e] = (__bf16)(t[e] - (float)hb);
+                    }
+                    const size_t pt = pair_index((size_t)gm, gn, a.N);
+                    *reinterpret_cast<bf16x8_t*>(a.Ph + pt) = h8;
+                    *reinterpret_cast<bf16x8_t*>(a.Pl + pt) = l8;
+                }
+            }
+        }
+    }
+}
+
 #define CONV_HIP(call)                                  \
     do {                                                \
         hipError_t _e = (call);                         \
@@ -363,8 +549,21 @@ int launch_conv3x3(ConvArgs a, hipStream_t st) {
 }
 
 template <int EP>
+int launch_conv3x3_patch(ConvArgs a, hipStream_t st) {
+    a.ntm = (a.M + PT_MT - 1) / PT_MT;
+    a.ntn = a.N / PT_NT;
+    const int ntiles = ((a.ntm + 7) >> 3) * 8 * a.ntn;
+    MQ_DYNAMIC_LDS_WITH(CONV_HIP, PT_LDS, conv3x3_patch_kernel<EP>);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<EP>), dim3((unsigned)ntiles), dim3(1024), PT_LDS, st, a);
+    return hipGetLastError() == hipSuccess ? MQ_OK : MQ_EHIP;
+}
+
+template <int EP>
 int launch_conv3x3_variant(const ConvArgs& a, int variant, hipStream_t st) {
     switch (variant) {
+        case MQ_CONV_TILE_PATCH_256x64:
+            // the patch is linear in the pixel index: stride 1, and 256 + 2 W + 2 rows must fit the 512-row buffer
+            return (a.stride != 1 || a.N % 64 || 2 * a.W + 2 > PT_PR - PT_MT || !a.cmajor) ? MQ_EINVAL : launch_conv3x3_patch<EP>(a, st);
         case MQ_CONV_TILE_256x256: return a.N % 256 ? MQ_EINVAL : launch_conv3x3<4, 64, EP>(a, st);
         case MQ_CONV_TILE_512x128: return a.N % 128 ? MQ_EINVAL : launch_conv3x3<8, 64, EP>(a, st);
         case MQ_CONV_TILE_256x128: return a.N % 128 ? MQ_EINVAL : launch_conv3x3<4, 32, EP>(a, st);
