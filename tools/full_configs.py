@@ -4,7 +4,7 @@ batches; this runs the whole job, so clock droop over a minute of MFMA work and 
   configs[2]  DPR bert-base passage encoder over 1,500,000 synthetic 100-token passages (fresh ids per batch, generated on
               the device before the batch's clock starts; 768-d pooler outputs written into one [1.5M, 768] f32 matrix)
   configs[3]  CLIP ViT-B/32 over 524,288 synthetic 224x224 images (fresh ~N(0,1) pixels per batch), then those 524,288
-              512-d vectors as queries, 4096 at a time, top-100 over a 1.5M x 512 matrix
+              512-d vectors as queries, 4096 at a time, top-100 over a 1.5M x 512 "L2norm,Flat" inner-product index
 
 Every encoder output is produced by the product path and kept (nothing cached, nothing skipped); the search leg checks
 its first chunk against the exact fp32 scan.  usage: python tools/full_configs.py [passages] [images]  -> one JSON line"""
@@ -73,14 +73,14 @@ def search_job(queries, n_rows=1_500_000, k=100, chunk=4096, device="cuda"):
     d = queries.shape[1]
     g = torch.Generator(device=device).manual_seed(3)
     X = torch.randn((n_rows, d), generator=g, device=device)
-    index = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
+    # SURVEY 8d configs[3]: "L2norm,Flat" + inner product (the reference's CLIP index): rows and queries normalised by the index
+    index = MI355XFlatIndex(string_factory="L2norm,Flat", metric_type=0, screen=True)
     index.add(X)
-    # CLIP outputs of random pixels share one large common component: centre and scale them like embeddings of distinct
+    # CLIP outputs of random pixels through random weights share one large common component: centre them like embeddings of distinct
     # images would be, or every query asks the same question
     q = queries - queries.mean(dim=0, keepdim=True)
-    q = q / q.norm(dim=1, keepdim=True).clamp_min(1e-20)
     D0, I0 = index.search_device(q[:chunk], k)
-    exact = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=False)
+    exact = MI355XFlatIndex(string_factory="L2norm,Flat", metric_type=0, screen=False)
     exact.add(X)
     D1, I1 = exact.search_device(q[:chunk], k)
     same = bool(torch.equal(I0, I1) and torch.equal(D0, D1))
