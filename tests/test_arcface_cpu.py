@@ -48,3 +48,32 @@ def test_iresnet_oracle_shapes_and_determinism():
     full = oa.seeded_state(0)
     assert {"conv1.weight", "prelu.weight", "layer3.13.conv2.weight", "layer4.0.downsample.1.running_var", "fc.bias", "features.weight"} <= set(full)
     assert "layer3.14.conv1.weight" not in full and full["fc.weight"].shape == (512, 25088)
+
+
+def _golden():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "arcface_r50_8.npz"))
+    u8 = g["faces_u8"]
+    x = ((u8.transpose(0, 3, 1, 2).astype(np.float32) / np.float32(255.0)) - np.float32(0.5)) / np.float32(0.5)
+    return g, u8, np.ascontiguousarray(x)
+
+
+def test_iresnet_oracle_equals_the_torch_statement():
+    """tests/golden/arcface_r50_8.npz = IResNet-50 built from torch-CPU's conv2d / batch_norm / prelu / linear
+    (tools/make_golden_arcface.py, run in the build container): a second statement of the published network, independent of
+    the numpy arithmetic of oracle/arcface.py (im2col + sgemm, broadcast BN).  The restatement must agree with it to fp32
+    rounding -- 2e-5 absolute on outputs of magnitude up to 6.8 (3e-6 relative; the two differ in summation order over up to
+    25,088-term sums, and the torch statement itself is 8e-6 from its float64 twin)."""
+    from oracle import arcface as oa
+    g, u8, x = _golden()
+    st = oa.seeded_state(int(g["seed_weights"]))
+    got = oa.iresnet_forward(st, x)
+    assert got.shape == g["embeddings"].shape == (8, 512)
+    assert np.abs(got - g["embeddings"]).max() <= 2e-5, np.abs(got - g["embeddings"]).max()
+    assert np.abs(got - g["embeddings_f64"]).max() <= 2e-5, np.abs(got - g["embeddings_f64"]).max()
+    # the preprocessing of the golden's bytes is the oracle's own ToTensor + Normalize, bit for bit
+    assert np.array_equal(np.stack([oa.preprocess(f) for f in u8]), x)
+    # what the reference's fp16 autocast (meerqat/image/face_recognition.py:55-56, fp16=True) deviates by on the same faces:
+    # two orders of magnitude above the fp32 statements' mutual distance, and above this build's 1e-3 gate
+    dev = float(g["fp16_autocast_max_abs_dev"])
+    assert 1e-3 < dev < 5e-2 and np.isclose(np.abs(g["embeddings_fp16_autocast"] - g["embeddings"]).max(), dev)

@@ -234,6 +234,23 @@ def test_arcface_r50_matches_the_oracle():
         model(torch.zeros((1, 3, 64, 64), device="cuda"))
 
 
+def test_arcface_r50_matches_the_torch_statement_golden():
+    """The HIP forward against tests/golden/arcface_r50_8.npz -- IResNet-50 stated with torch-CPU's own conv2d / batch_norm /
+    prelu / linear (tools/make_golden_arcface.py), NOT the numpy oracle: within 1e-3 (north_star's encoder tolerance) of the
+    fp32 statement and of its float64 twin, and an order of magnitude closer to them than the reference's own fp16-autocast
+    forward is (meerqat/image/face_recognition.py:55-56)."""
+    import os
+    from oracle import arcface as oa
+    from viquae_amd.arcface import ArcFaceR50
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "arcface_r50_8.npz"))
+    x = np.stack([oa.preprocess(f) for f in g["faces_u8"]])
+    model = ArcFaceR50.from_state_dict(oa.seeded_state(int(g["seed_weights"]))).cuda()
+    got = model(torch.from_numpy(x).cuda()).cpu().numpy()
+    err32, err64 = np.abs(got - g["embeddings"]).max(), np.abs(got - g["embeddings_f64"]).max()
+    assert err32 <= 1e-3 and err64 <= 1e-3, (err32, err64)
+    assert err64 < 0.1 * float(g["fp16_autocast_max_abs_dev"]), (err64, float(g["fp16_autocast_max_abs_dev"]))
+
+
 def test_face_alignment_kernel_is_the_oracles_warp_bit_for_bit():
     """mq_warp_affine_faces_f32 = cv2.warpAffine's published fixed-point bilinear arithmetic + ToTensor + Normalize: against
     oracle.arcface.warp_affine / preprocess on random images, faces near and across the image border (constant border 0)."""

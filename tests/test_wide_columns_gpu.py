@@ -1,0 +1,172 @@
+"""GPU: searches over the reference's WIDE columns -- 1024-d (``clip-RN50``) and 2048-d (``imagenet-RN50``), both indexed with
+``"L2norm,Flat"``, ``metric_type`` 0 and searched in 256-query batches by the paper's headline fusion run
+(experiments/ir/viquae/dpr+arcface+clip+imagenet/config_test.json:18-41, batch_size at :60) -- and over a ragged width above
+768 (d = 1000), through the index boundary against the CPU oracle (oracle/knn_oracle.c), BIT-EXACT in scores and ids.
+
+No kNN test exceeded d = 768 before round 5 ("What's missing" 1): the streaming kernel of one query tile serves
+at most 12 K blocks of 64 bf16 columns, so these widths run on the 256 x 256 tile kernel (screened index), the exact fp32 scan
+(``screen=False``), FAISS's direct L2 form (fewer than 20 L2 queries) and the row-range path (k beyond the screen).  The
+screening margin grows with dp (the fp32-accumulation term is linear in it): the worst case of the rounding is measured at
+dp = 2048 below."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WIDTHS = [1000, 1024, 2048]
+
+
+def _data(n, d, nq, seed, kind="normal"):
+    rng = np.random.default_rng(seed)
+    if kind == "lattice":
+        # integers in [-64, 64]: products <= 2^12, so every partial sum of a 2048-term inner product stays <= 2^23 and every
+        # fp32 summation order is exact (the [-128, 128] range of the d = 768 lattice would reach 2^25 here)
+        return (rng.integers(-64, 65, (n, d)).astype(np.float32), rng.integers(-64, 65, (nq, d)).astype(np.float32))
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    if kind == "shared":   # image embeddings: a large common component + noise (what ResNet / CLIP features look like)
+        mu = rng.standard_normal((1, d)).astype(np.float32)
+        X = 3 * mu + 0.5 * X
+        Q = 3 * mu + 0.5 * Q
+    return X, Q
+
+
+def _index(X, metric, factory, screen, form=None, tie_order=None):
+    from viquae_amd.index import MI355XFlatIndex
+    idx = MI355XFlatIndex(string_factory=factory, metric_type=metric, screen=screen, l2norm_form=form, tie_order=tie_order)
+    half = (len(X) // 2) // 64 * 64 + 7          # ragged second add: both ingest paths at this width
+    idx.add(X[:half])
+    idx.add(X[half:])
+    return idx
+
+
+def _check(X, Q, k, metric, factory, screen, form=None):
+    from oracle import knn as ok
+    idx = _index(X, metric, factory, screen, form)
+    D, I = idx.search_batch(Q, k)
+    Do, Io = ok.knn(X, Q, k, metric=metric, l2norm="L2norm" in factory, l2norm_form=form or "numpy")
+    bad = np.nonzero((I != Io).any(axis=1))[0]
+    assert bad.size == 0, f"ids differ in {bad.size} queries, first {bad[:5]}: {I[bad[0]][:8]} vs {Io[bad[0]][:8]}"
+    assert np.array_equal(D, Do), f"scores differ: max abs {np.nanmax(np.abs(D - Do))}"
+    return idx
+
+
+@pytest.mark.parametrize("screen", [True, False])
+@pytest.mark.parametrize("nq", [7, 256, 600])
+@pytest.mark.parametrize("factory,metric,form", [
+    ("L2norm,Flat", 0, "faiss"),    # the shipped configuration (device: null -> FAISS's own NormalizationTransform)
+    ("L2norm,Flat", 0, "numpy"),    # the same with a `device` (the reference's numpy work-around)
+    ("Flat", 0, None),
+    ("Flat", 1, None),              # nq = 7: FAISS's direct form; 256 / 600: the BLAS form
+    ("L2norm,Flat", 1, "faiss"),
+])
+@pytest.mark.parametrize("d", WIDTHS)
+def test_wide_columns_equal_the_oracle(d, factory, metric, form, nq, screen):
+    X, Q = _data(9000 if d == 2048 else 12000, d, nq, seed=d + nq + metric)
+    _check(X, Q, 100, metric, factory, screen, form)
+
+
+@pytest.mark.parametrize("screen", [True, False])
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("d", WIDTHS)
+def test_wide_integer_lattice(d, metric, screen):
+    # exact in every summation order, so the SCORES are any correct IndexFlat's; many exact ties at the k-th boundary
+    X, Q = _data(6000, d, 37, seed=d, kind="lattice")
+    _check(X, Q, 100, metric, "Flat", screen)
+    Xs, Qs = X[:, :], Q[:7]
+    _check(Xs, Qs, 100, metric, "Flat", screen)      # both L2 forms on the lattice
+
+
+@pytest.mark.parametrize("d", [1024, 2048])
+@pytest.mark.parametrize("factory,metric", [("L2norm,Flat", 0), ("Flat", 1)])
+def test_wide_embeddings_with_a_shared_component(d, factory, metric):
+    """The screen centres its bf16 copy on the mean of the first rows; at these widths the centre carries most of every
+    vector's norm.  Screened == exact scan == oracle, and the screen (not the fallback) does the work."""
+    X, Q = _data(30000, d, 256, seed=3 * d, kind="shared")
+    idx = _check(X, Q, 100, metric, factory, True, "faiss" if "L2norm" in factory else None)
+    assert idx.scan_kind(256, 100) == "tile"
+    stats = idx.screen_stats(256, 100)
+    assert stats[0] == 0 and stats[1] >= 256 * 100, stats[:3]
+    _check(X, Q, 100, metric, factory, False, "faiss" if "L2norm" in factory else None)
+
+
+@pytest.mark.parametrize("d,metric", [(2048, 0), (1024, 0), (1000, 1), (768, 1)])
+def test_the_streaming_kernel_refuses_more_than_twelve_k_blocks(d, metric):
+    """The reference's 256-query batch over a shard large enough for the streaming kernel: beyond 768 bf16 columns (and for L2
+    at d = 768: two more columns -> 832) the tile kernel serves it -- same results, bit for bit, as the exact scan and the oracle."""
+    from oracle import knn as ok
+    n = 66000
+    X, Q = _data(n, d, 256, seed=d + 11)
+    idx = _index(X, metric, "Flat", True)
+    assert idx.scan_kind(256, 100) == "tile"
+    D, I = idx.search_batch(Q, 100)
+    Do, Io = ok.knn(X, Q, 100, metric=metric)
+    assert np.array_equal(I, Io) and np.array_equal(D, Do)
+    narrow = _index(np.ascontiguousarray(X[:, :768 if metric == 0 else 766]), metric, "Flat", True)
+    assert narrow.scan_kind(256, 100) == "stream"    # ... while the widest served width still streams
+
+
+@pytest.mark.parametrize("d", [1024, 2048])
+@pytest.mark.parametrize("k", [1, 129, 300])
+def test_wide_other_k(d, k):
+    """k = 1, k beyond the fused selection (129) and k beyond the screen (300: row ranges) at the wide widths."""
+    X, Q = _data(8000, d, 40, seed=d + k)
+    _check(X, Q, k, 0, "L2norm,Flat", True, "faiss")
+    _check(X, Q, k, 1, "Flat", True)
+
+
+@pytest.mark.parametrize("d", [1024, 2048])
+def test_wide_tie_orders(d):
+    """Duplicated rows at the wide widths: both tie policies, on both index kinds."""
+    from oracle import knn as ok
+    rng = np.random.default_rng(d)
+    X = rng.standard_normal((5000, d), dtype=np.float32)
+    X[rng.integers(0, 5000, 2500)] = X[rng.integers(0, 5000, 2500)]
+    Q = rng.standard_normal((33, d), dtype=np.float32)
+    for order in ("id_asc", "id_desc"):
+        Do, Io = ok.knn(X, Q, 100, metric=0, tie_order=order)
+        for screen in (True, False):
+            D, I = _index(X, 0, "Flat", screen, tie_order=order).search_batch(Q, 100)
+            assert np.array_equal(I, Io) and np.array_equal(D, Do), (order, screen)
+
+
+@pytest.mark.parametrize("kind", ["midpoints", "gauss"])
+@pytest.mark.parametrize("d", [2048, 1000])
+def test_margin_dominates_the_measured_screening_error_at_wide_dp(d, kind):
+    """tests/test_screened_gpu.py::test_margin_dominates_the_measured_screening_error at dp = 2048 / 1024: the lossless argument
+    needs |S~ - S| <= margin / 2 for every (query, row); S~ = float64 product of the bf16-rounded operands, S = float64 product
+    of the fp32 operands.  "midpoints" = every element half way between two bf16 values, the worst case of the rounding; the
+    fp32-accumulation term of the margin (dp * 2.98e-7 * ||q|| max||x||) is 2.7 x its d = 768 value here."""
+    import torch
+    from viquae_amd.index import MI355XFlatIndex
+    g = torch.Generator(device="cuda").manual_seed(d)
+    n, nq, k = 5000, 300, 10
+    if kind == "gauss":
+        X = torch.randn((n, d), generator=g, device="cuda")
+        Q = torch.randn((nq, d), generator=g, device="cuda")
+    else:
+        m = torch.randint(128, 256, (n, d), generator=g, device="cuda").float()
+        X = (m + 0.5) / 128.0 * torch.where(torch.rand((n, d), generator=g, device="cuda") < 0.5, -1.0, 1.0)
+        Q = (torch.randint(128, 256, (nq, d), generator=g, device="cuda").float() + 0.5) / 128.0
+    idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
+    idx.add(X)
+    D, I = idx.search_device(Q, k)
+    ex = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=False)
+    ex.add(X)
+    D2, I2 = ex.search_device(Q, k)
+    assert torch.equal(D, D2) and torch.equal(I, I2)
+    stats = idx.screen_stats(nq, k)
+    c = idx._center if idx._center is not None else torch.zeros(d, device="cuda")
+    Xc = X - c
+    Xb, Qb = Xc.to(torch.bfloat16).double(), Q.to(torch.bfloat16).double()
+    dev = ((Q.double() @ Xc.double().T) - (Qb @ Xb.T)).abs().amax(dim=1)
+    qn, dqn = Q.double().norm(dim=1), (Q.double() - Qb).norm(dim=1)
+    xn = torch.maximum(X.double().norm(dim=1).max(), Xc.double().norm(dim=1).max())
+    dxn = (Xc.double() - Xb).norm(dim=1).max()
+    dp = (d + 63) // 64 * 64
+    eps = qn * dxn + dqn * Xb.norm(dim=1).max() + dp * 2.98e-7 * qn * xn
+    assert torch.all(dev <= eps), float((dev / eps).max())
+    kernel_max_margin = stats[5] * 1e-6
+    assert kernel_max_margin >= 2 * float(dev.max()) * 0.999
+    assert 2 * float(eps.max()) * 0.99 <= kernel_max_margin * (1 + 1e-3) + 1e-6
+    assert kernel_max_margin <= 2 * float(eps.max()) * 1.02 + 2e-6
