@@ -815,7 +815,13 @@ def main():
                     encode_surface = bench_encode_surface.main()
                 except Exception as e:
                     encode_surface = {"error": repr(e)}
+                try:
+                    import fusion_config_search
+                    fusion_search = fusion_config_search.main(rows=rows)
+                except Exception as e:
+                    fusion_search = {"error": repr(e)}
                 rec.setdefault("secondary", {}).update({
+                    "fusion_config_search": fusion_search,
                     "reference_call_surface": surface,
                     "encode_call_surface": encode_surface,
                     "dpr_like_data": dpr_like,

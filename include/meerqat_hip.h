@@ -396,6 +396,26 @@ int mq_fuse_wsum_f64(const int64_t *ids_dev, const double *scores_dev, int n_run
                      int32_t *out_count_dev, void *ws_dev, size_t ws_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Run files -- HOST function, no device work: replaces the per-hit Python objects behind
+ * `run.save(metric_save_path / f"{index_name}.json")` (meerqat/ir/search.py:485-498) over the dicts of :413-440.  Formats the
+ * rows of a result block kept as arrays into the text `json.dump({q_id: {str(doc): float(score)}})` writes, byte for byte
+ * (", " and ": " separators, CPython's float repr of the score widened to double, NaN / Infinity spelled as json does),
+ * WITHOUT the enclosing braces:   "<q0>": {"<id>": <score>, ...}, "<q1>": {...}
+ *   qid_json / qid_off [nq + 1]: the already JSON-encoded question ids (quotes included), concatenated, and their offsets;
+ *   ids [nq, stride] int64, scores [nq, stride] fp32 (scores_f64 = 0) or f64 (= 1), host memory; a row ends at counts[q]
+ *   entries (counts NULL: stride) or at its first negative id (FAISS's -1 padding);
+ *   out / out_cap: destination, at least nq * (8 + 52 * stride) + the length of qid_json bytes (the worst case);
+ *   n_threads: 0 = all host cores (at most MQ_RUN_JSON_MAX_PARTS); parts [2 * MQ_RUN_JSON_MAX_PARTS] int64 (host).
+ * The rows are cut into P contiguous parts formatted concurrently, each into its own region of `out`; returns P and sets
+ * parts[2 * p] / parts[2 * p + 1] to the offset / length of part p: the run text is the parts in order, joined by ", " (written
+ * one after the other by the caller: no second copy of a 50 MB run is made).  0 for nq = 0.  If out_cap is too small nothing
+ * is written and the return value r < -16 encodes the size needed as -(r + 16); MQ_EINVAL for bad arguments. */
+#define MQ_RUN_JSON_MAX_PARTS 32
+int64_t mq_format_run_json(const char *qid_json, const int64_t *qid_off, int64_t nq, const int64_t *ids, const void *scores,
+                           int scores_f64, int64_t stride, const int32_t *counts, char *out, int64_t out_cap, int n_threads,
+                           int64_t *parts);
+
+/* ---------------------------------------------------------------------------------------------
  * Image preprocessing in front of the CLIP tower: replaces
  * `transform(images, return_tensors="pt")` in `embed` (meerqat/image/embedding.py:141-152), the transform being the
  * `CLIPFeatureExtractor` of experiments/image_embedding/clip/vit_config.json:13-17 -- Pillow's 8-bit

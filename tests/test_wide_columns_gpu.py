@@ -24,10 +24,10 @@ def _data(n, d, nq, seed, kind="normal"):
         return (rng.integers(-64, 65, (n, d)).astype(np.float32), rng.integers(-64, 65, (nq, d)).astype(np.float32))
     X = rng.standard_normal((n, d), dtype=np.float32)
     Q = rng.standard_normal((nq, d), dtype=np.float32)
-    if kind == "shared":   # image embeddings: a large common component + noise (what ResNet / CLIP features look like)
+    if kind == "shared":   # image embeddings are not centred: a common component as large as the isotropic part
         mu = rng.standard_normal((1, d)).astype(np.float32)
-        X = 3 * mu + 0.5 * X
-        Q = 3 * mu + 0.5 * Q
+        X = mu + X
+        Q = mu + Q
     return X, Q
 
 

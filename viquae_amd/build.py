@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libmeerqat_hip.so")
-SOURCES = ["knn.hip", "encoder.hip", "conv.hip", "fuse.hip", "image.hip", "diag.hip"]
+SOURCES = ["knn.hip", "encoder.hip", "conv.hip", "fuse.hip", "image.hip", "diag.hip", "runfmt.cpp"]
 ARCH = "gfx950"
 
 
@@ -32,13 +32,41 @@ def needs_build():
     return any(os.path.getmtime(d) > so_m for d in deps)
 
 
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off", "-Wno-unused-result"]
+OBJ = os.path.join(CSRC, "_obj")
+
+
+def _stale(target, deps):
+    return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link one shared library. Returns its path."""
+    """Compile every source for gfx950 (one object per source, rebuilt only when that source, an include of csrc/ or the C-ABI
+    header changed) and link one shared library. Returns its path."""
     if not force and not needs_build():
         return SO
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-fno-fast-math", "-ffp-contract=off", "-Wno-unused-result"] + srcs + ["-o", SO + ".tmp"]
+    os.makedirs(OBJ, exist_ok=True)
+    shared = [os.path.join(HERE, "..", "include", "meerqat_hip.h")]
+    shared += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc"))]
+    objs, jobs = [], []
+    for name in SOURCES:
+        src = os.path.join(CSRC, name)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(OBJ, name + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + shared):
+            cmd = [_hipcc(), f"--offload-arch={ARCH}"] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((obj, subprocess.Popen(cmd)))
+    failed = [obj for obj, p in jobs if p.wait() != 0]
+    if failed:
+        for obj in failed:
+            if os.path.exists(obj):
+                os.remove(obj)
+        raise subprocess.CalledProcessError(1, f"hipcc -c ({', '.join(os.path.basename(o) for o in failed)})")
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-lpthread", "-o", SO + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from .runs import ArrayRun, dump_run
 
 NORM_CODES = {None: 0, "gzmuv": 1, "zmuv": 2}
 MAX_ENTRIES = 4096  # n_runs * K limit of the kernel (include/meerqat_hip.h)
@@ -61,6 +62,8 @@ def fuse_tables(ids, scores, weights, norm="gzmuv", defmin=False):
 
 
 def _as_dict(run):
+    if isinstance(run, ArrayRun):
+        return run   # a mapping already; its rows go to the device as arrays (runs_to_tables)
     if isinstance(run, (str, Path)):
         with open(run, "rt") as file:
             return json.load(file)
@@ -79,6 +82,19 @@ def runs_to_tables(runs, device="cuda:0"):
     for run in runs[1:]:
         if run.keys() != runs[0].keys():
             raise ValueError("all runs must hold the same queries (Searcher fills every index for every question)")
+    if all(isinstance(run, ArrayRun) for run in runs):
+        # runs kept as arrays since the search (viquae_amd/ir/runs.py): no dict is built on the way to the device
+        tabs = [run.tables(q_ids) for run in runs]
+        if all(t is not None for t in tabs):
+            K = max([1] + [t[1].shape[1] for t in tabs])
+            if len(runs) * K > MAX_ENTRIES:
+                raise ValueError(f"{len(runs)} runs x {K} results per query exceed the kernel's {MAX_ENTRIES} entries")
+            ids = np.full((len(runs), len(q_ids), K), -1, dtype=np.int64)
+            scores = np.zeros((len(runs), len(q_ids), K), dtype=np.float64)
+            for r, (_, ti, ts) in enumerate(tabs):
+                ids[r, :, :ti.shape[1]] = ti
+                scores[r, :, :ti.shape[1]] = ts
+            return q_ids, None, torch.from_numpy(ids).to(device), torch.from_numpy(scores).to(device)
     docs = set()
     for run in runs:
         for results in run.values():
@@ -106,8 +122,14 @@ def runs_to_tables(runs, device="cuda:0"):
     return q_ids, doc_names, torch.from_numpy(ids).to(device), torch.from_numpy(scores).to(device)
 
 
-def tables_to_run(q_ids, doc_names, fused_ids, fused_scores, counts):
+def tables_to_run(q_ids, doc_names, fused_ids, fused_scores, counts, as_arrays=False):
     fused_ids, fused_scores, counts = fused_ids.cpu().numpy(), fused_scores.cpu().numpy(), counts.cpu().numpy()
+    if as_arrays and len(set(q_ids)) == len(q_ids):
+        # the fused run stays rows of the fused tables (an ArrayRun: dicts on demand, run file straight from the arrays)
+        ids = np.where(np.arange(fused_ids.shape[1])[None, :] < counts[:, None], fused_ids, -1)
+        run = ArrayRun()
+        run.add_block(list(q_ids), ids, fused_scores, doc_names)
+        return run
     run = {}
     for q, q_id in enumerate(q_ids):
         n = int(counts[q])
@@ -118,10 +140,12 @@ def tables_to_run(q_ids, doc_names, fused_ids, fused_scores, counts):
 
 
 def fuse_runs(runs, weights, norm="gzmuv", defmin=False, device="cuda:0"):
-    """dict runs in, fused dict run out; the arithmetic happens in ``fuse_tables``."""
+    """dict runs in, fused dict run out; the arithmetic happens in ``fuse_tables``.  Runs that are still arrays
+    (``ArrayRun``) go in as arrays and the fused run comes back as one."""
     runs = [_as_dict(run) for run in runs]
     q_ids, doc_names, ids, scores = runs_to_tables(runs, device)
-    return tables_to_run(q_ids, doc_names, *fuse_tables(ids, scores, weights, norm=norm, defmin=defmin))
+    as_arrays = all(isinstance(run, ArrayRun) for run in runs)
+    return tables_to_run(q_ids, doc_names, *fuse_tables(ids, scores, weights, norm=norm, defmin=defmin), as_arrays=as_arrays)
 
 
 class Fusion:
@@ -154,13 +178,12 @@ class Fusion:
         weights = best_params["weights"]
         fused = fuse_runs(self.runs, weights, norm=self.norm, defmin=self.defmin, device=self.device)
         if self.output is not None:
-            with open(self.output / "test_run.json", "wt") as file:
-                json.dump(fused, file)
+            dump_run(fused, self.output / "test_run.json")
         try:
             import ranx
         except ImportError:
             return fused
-        combined = ranx.Run(fused, name="fusion")
+        combined = ranx.Run(fused.to_dict() if isinstance(fused, ArrayRun) else fused, name="fusion")
         if self.qrels is not None:
             if metrics is None:
                 metrics = ["mrr@100", "precision@1", "precision@20", "hit_rate@20"]

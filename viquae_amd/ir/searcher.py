@@ -13,10 +13,11 @@ optional -- without it ``dataset_search`` returns plain dicts and skips the metr
 does (:514-524) through ``viquae_amd.ir.fuse.Fusion`` (HIP kernels); the fused run is ``searcher.fusion``.
 
 The reference builds the run with a Python triple loop per batch (256 x 100 dict inserts).  Here a batch's [nq, k]
-result arrays are KEPT AS ARRAYS while the dataset is mapped and the ``{q_id: {str(doc): score}}`` dicts are built once,
-when somebody reads ``searcher.runs`` (``dataset_search`` does, before ranx / JSON): per-batch bookkeeping is then an
-append, and the one conversion is vectorised per block.  Only the on-the-fly relevance judgement (a reference KB is given:
-it needs each query's run at once) fills the dicts batch by batch as before.  With an ``index_mapping`` the hits are
+result arrays are KEPT AS ARRAYS to the end of the job: ``searcher.runs[index_name]`` is an ``ArrayRun``
+(viquae_amd/ir/runs.py), the same ``{q_id: {str(doc): score}}`` mapping whose entries stay rows of the result arrays until
+somebody indexes them; the run files are written from the arrays (``mq_format_run_json``, byte for byte what ``json.dump``
+of the dicts writes) and the late fusion takes its tables from them.  Only the on-the-fly relevance judgement (a reference
+KB is given: it needs each query's run at once) fills the dicts batch by batch as before.  With an ``index_mapping`` the hits are
 expanded with numpy (CSR gather) before the pass that applies the reference's insertion rules.
 """
 import json
@@ -29,6 +30,7 @@ from pathlib import Path
 import numpy as np
 
 from ..index import L2_DIRECT_BELOW
+from .runs import ArrayRun, dump_run
 from .search import KnowledgeBase
 
 
@@ -112,7 +114,7 @@ class Searcher:
             self.kbs[kb_path] = kb
             assert not (kb.indexes.keys() & self._runs.keys()), "All KBs should have unique index names"
             for index_name in kb.indexes:
-                self._runs[index_name] = {}
+                self._runs[index_name] = ArrayRun()
         assert not ({"search", "fusion"} & self._runs.keys()), "'search', 'fusion' are reserved names"
         self.do_fusion = True if (do_fusion is None and len(self._runs) > 1) else do_fusion
         if self.do_fusion:
@@ -136,8 +138,9 @@ class Searcher:
 
     @property
     def runs(self):
-        """``runs[index_name][q_id][doc_id] = score`` (meerqat/ir/search.py:386,413-440): reading it turns the result
-        blocks kept as arrays since the last read into dicts, in arrival order."""
+        """``runs[index_name][q_id][doc_id] = score`` (meerqat/ir/search.py:386,413-440).  Each run is an ``ArrayRun``
+        (viquae_amd/ir/runs.py): a mapping whose entries stay rows of the [nq, k] result arrays until they are indexed; reading
+        ``runs`` files the result blocks kept since the last read into it, in arrival order."""
         self._flush()
         return self._runs
 
@@ -148,6 +151,14 @@ class Searcher:
 
     def _flush(self):
         pending, self._pending = self._pending, []
+        waiting = {}   # index_name -> (q_ids, set(q_ids), [ids blocks], [score blocks]): consecutive plain blocks filed as ONE
+
+        def file_waiting(index_name):
+            w = waiting.pop(index_name, None)
+            if w is not None:
+                self._runs[index_name].add_block(w[0], np.concatenate(w[2]) if len(w[2]) > 1 else w[2][0],
+                                                 np.concatenate(w[3]) if len(w[3]) > 1 else w[3][0])
+
         for kb, index_name, q_ids, scores, indices in pending:
             run = self._runs[index_name]
             indices = np.asarray(indices)
@@ -158,16 +169,23 @@ class Searcher:
             if plain:
                 srt = np.sort(indices[:, :cut], axis=1)
                 plain = bool((srt[:, 0] >= 0).all() and (srt[:, 1:] != srt[:, :-1]).all())
-            if plain and len(set(q_ids)) == nq and not any(run.get(q) for q in q_ids):
-                # distinct hits into empty runs: the reference's loop keeps exactly the first k of them, in order.  ONE
-                # str() pass and ONE float pass over the block, then a dict per query from two list slices.
-                keys = list(map(str, indices[:, :cut].ravel().tolist()))
-                vals = scores[:, :cut].ravel().tolist()
-                for n, q_id in enumerate(q_ids):
-                    run[q_id] = dict(zip(keys[n * cut:(n + 1) * cut], vals[n * cut:(n + 1) * cut]))
+            w = waiting.get(index_name)
+            if plain and isinstance(run, ArrayRun) and len(set(q_ids)) == nq and not any(q in run for q in q_ids) \
+                    and (w is None or (w[1].isdisjoint(q_ids) and w[2][0].shape[1] == cut)):
+                # distinct hits of new questions: the reference's loop keeps exactly the first k of them, in order -- the block
+                # stays a block of rows (viquae_amd/ir/runs.py); dicts are built when somebody indexes the run
+                if w is None:
+                    w = waiting[index_name] = ([], set(), [], [])
+                w[0].extend(q_ids)
+                w[1].update(q_ids)
+                w[2].append(indices[:, :cut])
+                w[3].append(scores[:, :cut])
                 continue
+            file_waiting(index_name)
             for q_id, sc, idx in zip(q_ids, scores.tolist(), indices.tolist()):
                 self._fill_run(kb, run.setdefault(q_id, {}), sc, idx)
+        for index_name in list(waiting):
+            file_waiting(index_name)
 
     def _fill_run(self, kb, run_q, scores, indices):
         """One query's hits -> run dict, cut at k entries (reference: search.py:413-440)."""
@@ -384,15 +402,14 @@ def dataset_search(dataset, k=100, metric_save_path=None, map_kwargs={}, **kwarg
         with open(metric_save_path / "qnonrels.json", "wt") as file:
             json.dump(searcher.qnonrels, file)
         for index_name, run in searcher.runs.items():
-            with open(metric_save_path / f"{index_name}.json", "wt") as file:
-                json.dump(run, file)
+            dump_run(run, metric_save_path / f"{index_name}.json")  # straight from the result arrays (mq_format_run_json)
     try:
         import ranx
     except ImportError:
         ranx = None
     if ranx is not None:
         qrels = ranx.Qrels(searcher.qrels)
-        runs = [ranx.Run(run, name=name) for name, run in searcher.runs.items()]
+        runs = [ranx.Run(run.to_dict() if isinstance(run, ArrayRun) else run, name=name) for name, run in searcher.runs.items()]
         report = ranx.compare(qrels, runs=runs, **searcher.metrics_kwargs)
         print(report)
         if metric_save_path is not None:
