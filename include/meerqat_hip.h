@@ -202,12 +202,25 @@ int mq_knn_screen_stats(int64_t N, int d, int nq, int k, const void *ws_dev, int
  * most 768 bf16 columns and k <= 128, the streaming kernel that keeps the queries in registers (csrc/knn_small.inc).
  * For 225 <= k <= 1792 the answer describes the scan of one row range.
  * MQ_SCAN_KIND_NONE: the call is not served by a screening scan at all (k > 1792 or row ranges too small: exact rounds; fewer
- * than 20 L2 queries: FAISS's direct form).  Negative: MQ_EINVAL.  Environment: MQ_KNN_SMALL=0 switches the streaming kernel off,
- * MQ_KNN_SMALL_MIN_TILES=<n> sets its floor of 32-row tiles per workgroup (default 8). */
+ * than 20 L2 queries: FAISS's direct form).  Negative: MQ_EINVAL.  MQ_KNN_OPT_SMALL_SCAN = 0 (below) switches the streaming kernel
+ * off, MQ_KNN_OPT_SMALL_MIN_TILES = <n> sets its floor of 32-row tiles per workgroup (default 8). */
 #define MQ_SCAN_KIND_NONE 0
 #define MQ_SCAN_KIND_TILE 1
 #define MQ_SCAN_KIND_STREAM 2
 int mq_knn_screen_scan_kind(int64_t N, int d, int nq, int k, int metric);
+/* Process-wide A/B switches of the search paths.  Their first values come from the environment, read ONCE (MQ_KNN_SMALL,
+ * MQ_KNN_SMALL_MIN_TILES, MQ_KNN_PARTITIONS); a running process flips them with mq_knn_set_option (atomic; a search already in
+ * its planning step may still see the old value), never by editing the environment.  Values are >= 0.
+ *   MQ_KNN_OPT_SMALL_SCAN        1 (default): one query tile may be served by the streaming kernel; 0: always the tile kernel
+ *   MQ_KNN_OPT_SMALL_MIN_TILES   the streaming kernel's floor of 32-row tiles per workgroup; 0 (default) = the built-in 8
+ *   MQ_KNN_OPT_PARTITIONS        1 (default): 225 <= k <= 1792 is served over row ranges; 0: exact rounds
+ * mq_knn_set_option returns the previous value, mq_knn_get_option the current one; MQ_EINVAL for an unknown key / negative value. */
+#define MQ_KNN_OPT_SMALL_SCAN 0
+#define MQ_KNN_OPT_SMALL_MIN_TILES 1
+#define MQ_KNN_OPT_PARTITIONS 2
+#define MQ_KNN_OPT_COUNT 3
+int mq_knn_set_option(int key, int value);
+int mq_knn_get_option(int key);
 
 /* Name and launch geometry of the scan kernel for the given problem (for bench.py / profiles):
  * out[0]=workgroups, out[1]=threads per workgroup, out[2]=LDS bytes (exact scan), out[3]=query tiles,

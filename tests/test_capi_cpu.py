@@ -50,3 +50,19 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_search_path_switches_are_set_through_the_abi(hip_lib):
+    """the A/B switches are process-wide atomics behind mq_knn_set_option / mq_knn_get_option (first values from the
+    environment, read once) -- not getenv() on the search path."""
+    from viquae_amd import _lib
+    assert hip_lib.mq_knn_get_option(_lib.KNN_OPT_SMALL_SCAN) in (0, 1)
+    before = hip_lib.mq_knn_get_option(_lib.KNN_OPT_PARTITIONS)
+    with _lib.knn_option(_lib.KNN_OPT_PARTITIONS, 0) as o:
+        assert o.previous == before and hip_lib.mq_knn_get_option(_lib.KNN_OPT_PARTITIONS) == 0
+        # the planner follows the switch at once: k = 300 over 1.5M rows is served over row ranges, or by exact rounds
+        assert hip_lib.mq_knn_screen_scan_kind(1_500_000, 768, 4096, 300, 0) == 0
+    assert hip_lib.mq_knn_get_option(_lib.KNN_OPT_PARTITIONS) == before
+    if before:
+        assert hip_lib.mq_knn_screen_scan_kind(1_500_000, 768, 4096, 300, 0) == 1
+    assert hip_lib.mq_knn_set_option(99, 1) == -1 and hip_lib.mq_knn_set_option(0, -5) == -1 and hip_lib.mq_knn_get_option(-1) == -1

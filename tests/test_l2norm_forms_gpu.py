@@ -89,6 +89,16 @@ def test_knowledge_base_picks_the_form_from_the_device_key():
         D, I = kb.search_batch("idx", X[20:25], k=3)
         assert (I[:, 0] == np.arange(20, 25)).all()
     assert got == {"none": "faiss", "zero": "numpy", "forced": "faiss"}
+    # a LOADED "L2norm,Flat" file is FAISS's IndexPreTransform whatever device it is loaded onto (the reference's work-around
+    # only strips the transform when it BUILDS, meerqat/ir/search.py:238-244): the device key does not choose the form then
+    import tempfile, os
+    path = os.path.join(tempfile.mkdtemp(), "idx.faiss")
+    kb = KnowledgeBase(dataset=ds(), index_kwargs={"idx": dict(base, device=None, save_path=path)})
+    for extra, want in (({"device": 0}, "faiss"), ({"device": None}, "faiss"), ({"device": 0, "l2norm_form": "numpy"}, "numpy")):
+        kb2 = KnowledgeBase(dataset=ds(), index_kwargs={"idx": dict(base, load=True, file=path, **extra)})
+        assert kb2.dataset._indexes["idx"].l2norm_form == want, extra
+        D2, I2 = kb2.search_batch("idx", X[20:25], k=3)
+        assert (I2[:, 0] == np.arange(20, 25)).all()
     assert MI355XFlatIndex(string_factory="L2norm,Flat").l2norm_form == "numpy"
     with pytest.raises(ValueError):
         MI355XFlatIndex(string_factory="L2norm,Flat", l2norm_form="blas")

@@ -199,3 +199,30 @@ def test_decode_pool_writes_rgb_bytes_into_the_shared_slots(tmp_path):
                 assert np.array_equal(buf[offs[i]:offs[i] + h * w * 3].reshape(h, w, 3), want[i]), i
     finally:
         pool.close()
+
+
+def test_job_fingerprint_is_deterministic_and_sees_every_part():
+    """viquae_amd.utils.job_fingerprint: the deterministic `new_fingerprint` of the pipelined embedding jobs."""
+    import datasets
+    import torch
+    from viquae_amd.utils import job_fingerprint
+    ds = datasets.Dataset.from_dict({"passage": ["a", "b"]})
+    torch.manual_seed(0)
+    m1 = torch.nn.Linear(8, 4)
+    m2 = torch.nn.Linear(8, 4)
+    m2.load_state_dict(m1.state_dict())
+    kw = dict(key="passage", save_as="emb", tokenization_kwargs={"max_length": 16, "padding": "max_length"}, layers=None)
+    f1 = job_fingerprint(ds, "job", model=m1, **kw)
+    assert f1 == job_fingerprint(ds, "job", model=m2, **kw) and len(f1) == 16     # same weights in another object: same job
+    with torch.no_grad():
+        m2.weight[1, 2] += 1e-3
+    assert job_fingerprint(ds, "job", model=m2, **kw) != f1                       # one weight
+    with torch.no_grad():                                                          # two weights swapped: same sum, other order
+        m2.load_state_dict(m1.state_dict())
+        a, b = m2.weight[0, 0].clone(), m2.weight[0, 1].clone()
+        m2.weight[0, 0], m2.weight[0, 1] = b, a
+    assert job_fingerprint(ds, "job", model=m2, **kw) != f1
+    assert job_fingerprint(ds, "other job", model=m1, **kw) != f1
+    assert job_fingerprint(ds, "job", model=m1, **dict(kw, save_as="emb2")) != f1
+    assert job_fingerprint(ds, "job", model=m1, **dict(kw, tokenization_kwargs={"max_length": 32, "padding": "max_length"})) != f1
+    assert job_fingerprint(datasets.Dataset.from_dict({"passage": ["a", "c"]}), "job", model=m1, **kw) != f1

@@ -62,6 +62,32 @@ def test_pipelined_text_embed_is_bit_identical_to_the_serial_embed(tmp_path, mon
     assert np.abs(b[:64] - ref).max() < 1e-3
 
 
+def test_pipelined_job_fingerprint_is_deterministic_so_the_map_cache_hits(tmp_path, monkeypatch):
+    """the pipelined job named a RANDOM new_fingerprint, so `Dataset.map` could never find its cache file; the
+    reference's `dataset.map(embed, fn_kwargs=...)` hashes deterministically (meerqat/ir/embedding.py:272).  Same data + same
+    model + same arguments -> the same fingerprint (and the second run's forward is skipped: the cache file is reused);
+    another model -> another fingerprint."""
+    import datasets
+    from safetensors.torch import load_file, save_file
+    from viquae_amd.ir import embedding as E
+    _text_job(tmp_path, n=300)
+    monkeypatch.setenv("MQ_EMBED_PIPELINE", "1")
+    datasets.enable_caching()
+    a = E.main(str(tmp_path / "kb"), str(tmp_path / "config.json"), output_path=str(tmp_path / "a"))
+    batches = E.dataset_embed.last_pipeline_stats["batches"]
+    b = E.main(str(tmp_path / "kb"), str(tmp_path / "config.json"), output_path=str(tmp_path / "b"))
+    assert batches == 3 and a._fingerprint == b._fingerprint
+    assert E.dataset_embed.last_pipeline_stats["batches"] == 0          # served from the map cache: no batch went through the model
+    assert np.array_equal(np.asarray(a["DPR_few_shot"], np.float32), np.asarray(b["DPR_few_shot"], np.float32))
+    st = load_file(str(tmp_path / "model" / "model.safetensors"))
+    key = next(k for k in st if k.endswith("word_embeddings.weight"))
+    st[key] = st[key].clone()
+    st[key][7, 3] += 0.5                                                # one weight changed: another job
+    save_file(st, str(tmp_path / "model" / "model.safetensors"))
+    c = E.main(str(tmp_path / "kb"), str(tmp_path / "config.json"), output_path=str(tmp_path / "c"))
+    assert c._fingerprint != a._fingerprint and E.dataset_embed.last_pipeline_stats["batches"] == 3
+
+
 def test_pipelined_text_embed_with_a_tokenizer_the_fast_path_declines(tmp_path, monkeypatch):
     """`padding: longest` + no truncation is understood; an unknown tokenization kwarg is not: the tokenizer itself then runs
     in the prefetch thread (still pipelined, still identical)."""

@@ -76,6 +76,27 @@ def test_second_halves_gather_and_merge_on_the_second_stream(rccl_world1, monkey
         assert torch.equal(I, Ie) and torch.equal(D, De)
 
 
+def test_pipelined_chunks_beyond_the_screen_keep_their_records_until_gathered(rccl_world1, monkeypatch):
+    """for k beyond the screen (> 224) the FRONT half writes D / I straight into the chunk's record; with two records
+    alternating, chunk i may only be scanned once chunk i-2's all-gather has finished reading the same record (the wait is on an
+    event recorded after finish(i-2), not after its second half).  Five chunks, k = 300, collective forced, several times over."""
+    import torch
+    from viquae_amd.index import MI355XFlatIndex
+    from viquae_amd.sharded import ShardedFlatIndex
+    g = torch.Generator(device="cuda").manual_seed(21)
+    X = torch.randn((20000, 48), generator=g, device="cuda")
+    Q = torch.randn((4096 * 4 + 300, 48), generator=g, device="cuda")
+    sh = ShardedFlatIndex(string_factory="Flat", metric_type=0, always_gather=True)
+    sh.add_vectors(X.cpu().numpy())
+    exact = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=False)
+    exact.add(X)
+    De, Ie = exact.search_device(Q, 300)
+    monkeypatch.setenv("MQ_KNN_TAIL_OVERLAP", "1")
+    for _ in range(3):
+        D, I = sh.search_device(Q, 300)
+        assert torch.equal(I, Ie) and torch.equal(D, De)
+
+
 def test_knowledge_base_builds_the_sharded_index_under_torch_distributed(rccl_world1, monkeypatch, tmp_path):
     """b2: inside a torch.distributed job add_or_load_faiss_index must build this rank's shard, not a full index."""
     from viquae_amd import sharded

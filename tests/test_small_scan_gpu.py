@@ -13,9 +13,15 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def _default_switches(monkeypatch):
-    monkeypatch.delenv("MQ_KNN_SMALL", raising=False)
-    monkeypatch.delenv("MQ_KNN_SMALL_MIN_TILES", raising=False)
+def _default_switches():
+    # the A/B switches are set through the C ABI (mq_knn_set_option), never through the environment of a running process
+    from viquae_amd import _lib
+    lib = _lib.load()
+    lib.mq_knn_set_option(_lib.KNN_OPT_SMALL_SCAN, 1)
+    lib.mq_knn_set_option(_lib.KNN_OPT_SMALL_MIN_TILES, 0)
+    yield
+    lib.mq_knn_set_option(_lib.KNN_OPT_SMALL_SCAN, 1)
+    lib.mq_knn_set_option(_lib.KNN_OPT_SMALL_MIN_TILES, 0)
 
 
 def _index(X, metric=0, factory="Flat", screen=True, tie_order=None):
@@ -30,12 +36,10 @@ def _both_scans(idx, Q, k):
     assert idx.scan_kind(len(Q), k) == "stream"
     D1, I1 = idx.search_batch(Q, k)
     stats = idx.screen_stats(len(Q), k)
-    os.environ["MQ_KNN_SMALL"] = "0"
-    try:
+    from viquae_amd import _lib
+    with _lib.knn_option(_lib.KNN_OPT_SMALL_SCAN, 0):
         assert idx.scan_kind(len(Q), k) == "tile"
         D0, I0 = idx.search_batch(Q, k)
-    finally:
-        del os.environ["MQ_KNN_SMALL"]
     return (D1, I1), (D0, I0), stats
 
 

@@ -19,7 +19,8 @@ for s in range(0, rows, 1 << 16):
 
 
 def run(Q, small, steps):
-    os.environ["MQ_KNN_SMALL"] = "1" if small else "0"
+    from viquae_amd import _lib
+    _lib.load().mq_knn_set_option(_lib.KNN_OPT_SMALL_SCAN, 1 if small else 0)
     D, I = idx.search_device(Q, k)
     torch.cuda.synchronize()
     st = idx.screen_stats(Q.shape[0], k)

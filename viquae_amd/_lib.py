@@ -43,6 +43,8 @@ SIGNATURES = {
     "mq_knn_screen_stats": (c_int, [c_i64, c_int, c_int, c_int, c_ptr, ctypes.POINTER(c_i64), c_ptr]),
     "mq_knn_launch_info": (c_int, [c_i64, c_int, c_int, c_int, ctypes.POINTER(c_i64)]),
     "mq_knn_screen_scan_kind": (c_int, [c_i64, c_int, c_int, c_int, c_int]),
+    "mq_knn_set_option": (c_int, [c_int, c_int]),
+    "mq_knn_get_option": (c_int, [c_int]),
     "mq_im2col_split_f32": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
     "mq_warp_affine_faces_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr]),
     "mq_gemm_nt_bf16x3s_respair_f32": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
@@ -90,6 +92,26 @@ SIGNATURES = {
                                  c_ptr]),
     "mq_format_run_json": (c_i64, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
 }
+
+
+KNN_OPT_SMALL_SCAN, KNN_OPT_SMALL_MIN_TILES, KNN_OPT_PARTITIONS = 0, 1, 2  # MQ_KNN_OPT_* (include/meerqat_hip.h)
+
+
+class knn_option:
+    """``with _lib.knn_option(KNN_OPT_SMALL_SCAN, 0): ...`` -- an A/B switch of the search paths set for the block through the C
+    ABI (mq_knn_set_option), restored afterwards; the environment is only read once, when the library first needs a switch."""
+
+    def __init__(self, key, value):
+        self.key, self.value = int(key), int(value)
+
+    def __enter__(self):
+        self.previous = load().mq_knn_set_option(self.key, self.value)
+        check(min(self.previous, 0), "mq_knn_set_option")
+        return self
+
+    def __exit__(self, *exc):
+        load().mq_knn_set_option(self.key, self.previous)
+        return False
 
 
 class MeerqatHipError(RuntimeError):

@@ -22,6 +22,8 @@
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 
 #include "../../include/meerqat_hip.h"
 #include "launch_attr.h"
@@ -36,6 +38,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 
 namespace {
+
+// A/B switches of the search paths (mq_knn_set_option, include/meerqat_hip.h): process-wide atomics whose FIRST values come
+// from the environment (MQ_KNN_SMALL, MQ_KNN_SMALL_MIN_TILES, MQ_KNN_PARTITIONS), read once.  Tests and bench.py flip them
+// through the setter: no getenv() on the search path (it races with a putenv from another thread), one rule for all three.
+std::atomic<int> g_knn_opt[MQ_KNN_OPT_COUNT];
+std::once_flag g_knn_opt_once;
+void knn_opt_init() {
+    std::call_once(g_knn_opt_once, [] {
+        const char* e;
+        g_knn_opt[MQ_KNN_OPT_SMALL_SCAN].store((e = getenv("MQ_KNN_SMALL")) ? (atoi(e) != 0) : 1);
+        g_knn_opt[MQ_KNN_OPT_SMALL_MIN_TILES].store((e = getenv("MQ_KNN_SMALL_MIN_TILES")) ? atoi(e) : 0);  // 0: the built-in floor
+        g_knn_opt[MQ_KNN_OPT_PARTITIONS].store((e = getenv("MQ_KNN_PARTITIONS")) ? (atoi(e) != 0) : 1);
+    });
+}
+inline int knn_opt(int key) {
+    knn_opt_init();
+    return g_knn_opt[key].load(std::memory_order_relaxed);
+}
 
 constexpr int PANEL = 64;   // KB rows per panel
 constexpr int BK = 16;      // k-depth of one LDS stage
@@ -1039,12 +1059,11 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus, int metric = -1) {
 
 // The streaming kernel for one query tile (knn_small.inc) serves a screened search when its geometry holds: one query tile,
 // one slab per stripe slot (S = 256 = TQ: the workgroup of slab s owns query s), at most 12 K blocks of queries in registers,
-// k within the stripe bound, and enough 32-row tiles per slab for the ring to pay.  MQ_KNN_SMALL=0 switches it off,
-// MQ_KNN_SMALL_MIN_TILES=<n> lowers the tiles-per-slab floor (tests).
+// k within the stripe bound, and enough 32-row tiles per slab for the ring to pay.  MQ_KNN_OPT_SMALL_SCAN = 0 switches it off,
+// MQ_KNN_OPT_SMALL_MIN_TILES = <n> lowers the tiles-per-slab floor (tests) -- mq_knn_set_option.
 bool small_scan_serves(const Geometry& g, int64_t N, int dp, int k) {
-    const char* const e0 = getenv("MQ_KNN_SMALL");  // read per call: tests and A/B runs flip it inside one process
-    const char* const e1 = getenv("MQ_KNN_SMALL_MIN_TILES");
-    const int enabled = e0 ? atoi(e0) : 1, min_tiles = e1 ? atoi(e1) : SM_MIN_TILES_PER_SLAB;
+    const int enabled = knn_opt(MQ_KNN_OPT_SMALL_SCAN), floor_opt = knn_opt(MQ_KNN_OPT_SMALL_MIN_TILES);
+    const int min_tiles = floor_opt > 0 ? floor_opt : SM_MIN_TILES_PER_SLAB;
     if (!enabled || g.nqt != 1 || g.S != TQ || g.ms != SMAX_SLOTS || g.sps != 1) return false;
     if (dp / SBK > SM_MAX_NKB || k > KF) return false;
     return (N + SM_ROWS - 1) / SM_ROWS >= (int64_t)g.S * (min_tiles > 1 ? min_tiles : 1);
@@ -1091,6 +1110,16 @@ const char* mq_strerror(int code) {
         case MQ_EUNSUPPORTED: return "unsupported configuration";
         default: return "unknown error";
     }
+}
+
+int mq_knn_set_option(int key, int value) {
+    if (key < 0 || key >= MQ_KNN_OPT_COUNT || value < 0) return MQ_EINVAL;
+    knn_opt_init();
+    return g_knn_opt[key].exchange(value);
+}
+int mq_knn_get_option(int key) {
+    if (key < 0 || key >= MQ_KNN_OPT_COUNT) return MQ_EINVAL;
+    return knn_opt(key);
 }
 
 int mq_last_hip_error(void) { return g_last_hip_error; }
@@ -1155,8 +1184,7 @@ constexpr int PART_MIN_ROWS = 16384;       // ranges smaller than this: the exac
 struct PartPlan { int P; int64_t per; };
 static PartPlan partition_plan(int64_t N, int k) {
     PartPlan pl{0, 0};
-    static const int off = [] { const char* e = getenv("MQ_KNN_PARTITIONS"); return e && atoi(e) == 0; }();
-    if (off || k <= SCREEN_MAX_K) return pl;
+    if (!knn_opt(MQ_KNN_OPT_PARTITIONS) || k <= SCREEN_MAX_K) return pl;
     const int P = (k + PART_SHARE - 1) / PART_SHARE;
     if (P > PART_MAX) return pl;
     const int64_t per = round_up((N + P - 1) / P, TQ);  // the bf16 copy is stored in 256-row tiles

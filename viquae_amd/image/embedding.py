@@ -82,8 +82,8 @@ def dataset_embed(dataset_path, map_kwargs={}, model_kwargs={}, transform_kwargs
     if pipe is not None:
         map_kwargs = dict(map_kwargs)
         if "new_fingerprint" not in map_kwargs:  # see viquae_amd/ir/embedding.py: never pickle the pipeline (model + column) for a hash
-            from datasets.fingerprint import generate_random_fingerprint
-            map_kwargs["new_fingerprint"] = generate_random_fingerprint()
+            from ..utils import job_fingerprint
+            map_kwargs["new_fingerprint"] = job_fingerprint(dataset, "image.embedding.dataset_embed", **fn_kwargs)
         try:
             dataset = dataset.map(pipe.embed, batched=True, with_indices=True, **map_kwargs)
         finally:

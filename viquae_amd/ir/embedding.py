@@ -176,12 +176,14 @@ def dataset_embed(dataset_path, map_kwargs={}, output_path=None, keep_columns=No
     pipe = text_pipeline_or_none(dataset, map_kwargs, **fn_kwargs)
     if pipe is not None:
         # `datasets` fingerprints the mapped function by pickling it: for the bound method of the pipeline that is the model's
-        # weights AND the whole text column (seconds and gigabytes for a passage KB), and the hash would depend on run state,
-        # so the map cache could never hit anyway.  A fresh fingerprint instead, unless the caller names one.
+        # weights AND the whole text column (seconds and gigabytes for a passage KB), and the hash would depend on run state.
+        # A deterministic fingerprint of the JOB instead (utils.job_fingerprint: input fingerprint, model checksums, tokenizer
+        # identity, keyword arguments), so that an identical second run hits the map cache like the reference's
+        # `dataset.map(embed, fn_kwargs=...)` does -- unless the caller names one.
         map_kwargs = dict(map_kwargs)
         if "new_fingerprint" not in map_kwargs:
-            from datasets.fingerprint import generate_random_fingerprint
-            map_kwargs["new_fingerprint"] = generate_random_fingerprint()
+            from ..utils import job_fingerprint
+            map_kwargs["new_fingerprint"] = job_fingerprint(dataset, "ir.embedding.dataset_embed", **fn_kwargs)
         try:
             dataset = dataset.map(pipe.embed, batched=True, with_indices=True, **map_kwargs)
         finally:

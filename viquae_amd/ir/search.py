@@ -150,7 +150,10 @@ class KnowledgeBase:
         # which index class serves `device` (one GPU, all GPUs of this process, or this rank's shard of a
         # torch.distributed job): viquae_amd.sharded.make_flat_index
         from ..sharded import ShardedFlatIndex, make_flat_index
-        if l2norm_form is None and do_L2norm:
+        if l2norm_form is None and do_L2norm and not load:
+            # only a BUILD follows the `device` key (the reference strips the transform when it builds for a GPU, :238-244); a
+            # stored "L2norm,Flat" file is FAISS's IndexPreTransform whatever it is loaded onto: None lets the loaders choose
+            # FAISS's arithmetic for such a file
             l2norm_form = "faiss" if device is None else "numpy"
         if load:
             if file is None:

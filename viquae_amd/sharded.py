@@ -316,28 +316,32 @@ class ShardedFlatIndex(_ShardedBase):
             # scan of chunk i+1 (MI355XFlatIndex.search_phase); same kernels per chunk, bit-identical results.
             main = torch.cuda.current_stream(dev)
             spaces, tail = self.local.pipeline_workspaces(max(e - s for s, e in pieces), k)
-            done = []
+            freed = []  # freed[j]: recorded on `tail` once chunk j's all-gather has been waited for and its merge enqueued
             for ci, (s, e) in enumerate(pieces):
                 q, n, ws = queries[s:e], e - s, spaces[ci & 1]
                 record, gathered = self._chunk_buffers(n, k, dev, ci & 1)
                 out = _record_views(record, n, k)
                 if ci >= 2:
-                    main.wait_event(done[ci - 2])  # the workspace (and record) of chunk i-2 are free again
+                    # the workspace AND the record / gather buffers of chunk i-2 are free again: its second half has run, its
+                    # collective has finished reading the record (work.wait() in finish()) and its merge has read `gathered`.
+                    # (Round 4 waited only for the second half: for k beyond the screen FRONT writes D / I straight into the
+                    # record, which RCCL could still have been reading -- ADVICE r4.)
+                    main.wait_event(freed[ci - 2])
                 self.local.search_phase(q, k, out, ws, FLAG_PHASE_FRONT, main)
                 scanned = torch.cuda.Event()
                 scanned.record(main)
                 tail.wait_event(scanned)
                 with torch.cuda.stream(tail):
                     self.local.search_phase(q, k, out, ws, FLAG_PHASE_TAIL, tail)
-                    ev = torch.cuda.Event()
-                    ev.record(tail)
-                    done.append(ev)
                     if self.world > 1 or self.always_gather:
                         work = dist.all_gather_into_tensor(gathered, record, group=self.group, async_op=True)
                     else:
                         work = None
                     if pending is not None:
                         finish(pending)
+                        ev = torch.cuda.Event()
+                        ev.record(tail)
+                        freed.append(ev)
                     pending = (work, gathered, s, n)
             with torch.cuda.stream(tail):
                 finish(pending)
