@@ -214,11 +214,14 @@ int mq_knn_screen_scan_kind(int64_t N, int d, int nq, int k, int metric);
  *   MQ_KNN_OPT_SMALL_SCAN        1 (default): one query tile may be served by the streaming kernel; 0: always the tile kernel
  *   MQ_KNN_OPT_SMALL_MIN_TILES   the streaming kernel's floor of 32-row tiles per workgroup; 0 (default) = the built-in 8
  *   MQ_KNN_OPT_PARTITIONS        1 (default): 225 <= k <= 1792 is served over row ranges; 0: exact rounds
+ *   MQ_KNN_OPT_SMALL_WAVES       8 (default): the streaming kernel with two waves per SIMD (csrc/knn_small8.inc, round 5);
+ *                                4: round 4's one wave per SIMD (csrc/knn_small.inc).  Environment: MQ_KNN_SMALL_WAVES
  * mq_knn_set_option returns the previous value, mq_knn_get_option the current one; MQ_EINVAL for an unknown key / negative value. */
 #define MQ_KNN_OPT_SMALL_SCAN 0
 #define MQ_KNN_OPT_SMALL_MIN_TILES 1
 #define MQ_KNN_OPT_PARTITIONS 2
-#define MQ_KNN_OPT_COUNT 3
+#define MQ_KNN_OPT_SMALL_WAVES 3
+#define MQ_KNN_OPT_COUNT 4
 int mq_knn_set_option(int key, int value);
 int mq_knn_get_option(int key);
 

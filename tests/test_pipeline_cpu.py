@@ -226,3 +226,26 @@ def test_job_fingerprint_is_deterministic_and_sees_every_part():
     assert job_fingerprint(ds, "job", model=m1, **dict(kw, save_as="emb2")) != f1
     assert job_fingerprint(ds, "job", model=m1, **dict(kw, tokenization_kwargs={"max_length": 32, "padding": "max_length"})) != f1
     assert job_fingerprint(datasets.Dataset.from_dict({"passage": ["a", "c"]}), "job", model=m1, **kw) != f1
+
+
+def test_job_fingerprint_takes_every_kind_of_model_config():
+    import datasets
+    import torch
+    from viquae_amd.utils import job_fingerprint
+    ds = datasets.Dataset.from_dict({"passage": ["a"]})
+
+    class M(torch.nn.Module):
+        def __init__(self, config):
+            super().__init__()
+            self.config = config
+            self.register_buffer("w", torch.arange(6.0).reshape(2, 3), persistent=False)   # the HIP encoders' weights are such buffers
+
+    class Cfg:
+        def __init__(self):
+            self.hidden = 8
+
+    fps = {job_fingerprint(ds, "job", model=M(c)) for c in ({"hidden_size": 8}, {"hidden_size": 16}, Cfg(), None, 3)}
+    assert len(fps) == 5
+    m = M({"hidden_size": 8})
+    m.w[0, 0] = 1.0
+    assert job_fingerprint(ds, "job", model=m) not in fps     # non-persistent buffers are part of the model's identity

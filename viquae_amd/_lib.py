@@ -94,7 +94,7 @@ SIGNATURES = {
 }
 
 
-KNN_OPT_SMALL_SCAN, KNN_OPT_SMALL_MIN_TILES, KNN_OPT_PARTITIONS = 0, 1, 2  # MQ_KNN_OPT_* (include/meerqat_hip.h)
+KNN_OPT_SMALL_SCAN, KNN_OPT_SMALL_MIN_TILES, KNN_OPT_PARTITIONS, KNN_OPT_SMALL_WAVES = 0, 1, 2, 3  # MQ_KNN_OPT_* (include/meerqat_hip.h)
 
 
 class knn_option:

@@ -50,6 +50,7 @@ void knn_opt_init() {
         g_knn_opt[MQ_KNN_OPT_SMALL_SCAN].store((e = getenv("MQ_KNN_SMALL")) ? (atoi(e) != 0) : 1);
         g_knn_opt[MQ_KNN_OPT_SMALL_MIN_TILES].store((e = getenv("MQ_KNN_SMALL_MIN_TILES")) ? atoi(e) : 0);  // 0: the built-in floor
         g_knn_opt[MQ_KNN_OPT_PARTITIONS].store((e = getenv("MQ_KNN_PARTITIONS")) ? (atoi(e) != 0) : 1);
+        g_knn_opt[MQ_KNN_OPT_SMALL_WAVES].store((e = getenv("MQ_KNN_SMALL_WAVES")) ? (atoi(e) == 4 ? 4 : 8) : 8);
     });
 }
 inline int knn_opt(int key) {
@@ -931,6 +932,7 @@ __global__ __launch_bounds__(256) void shard_merge_big_kernel(const float* __res
 
 #include "knn_screen.inc"
 #include "knn_small.inc"
+#include "knn_small8.inc"
 #include "knn_direct.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -1072,6 +1074,11 @@ bool small_scan_serves(const Geometry& g, int64_t N, int dp, int k) {
 template <int NKB>
 int launch_small_scan_n(const SmallArgs& sa, int S, hipStream_t st) {
     constexpr int lds = sm_nst(NKB) * (NKB * SM_PIECE + 2 * SM_AUX) + 2 * TQ * 4 + SM_AUX;
+    if (knn_opt(MQ_KNN_OPT_SMALL_WAVES) == 8) {  // two waves per SIMD (knn_small8.inc)
+        MQ_DYNAMIC_LDS(lds, screen_small8_kernel<NKB>);
+        hipLaunchKernelGGL(screen_small8_kernel<NKB>, dim3((unsigned)S), dim3(512), lds, st, sa);
+        return MQ_OK;
+    }
     MQ_DYNAMIC_LDS(lds, screen_small_kernel<NKB>);
     hipLaunchKernelGGL(screen_small_kernel<NKB>, dim3((unsigned)S), dim3(256), lds, st, sa);
     return MQ_OK;

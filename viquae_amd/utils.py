@@ -30,9 +30,14 @@ def _describe(obj, h):
     if isinstance(obj, torch.nn.Module):
         h.update(type(obj).__qualname__.encode())
         cfg = getattr(obj, "config", None)
-        if cfg is not None:
+        if cfg is not None and not isinstance(cfg, torch.nn.Module):
             to_json = getattr(cfg, "to_json_string", None)
-            h.update((to_json() if callable(to_json) else repr(sorted(vars(cfg).items()))).encode())
+            if callable(to_json):          # a transformers PretrainedConfig
+                h.update(to_json().encode())
+            elif isinstance(cfg, dict):    # the HIP encoders keep the checkpoint's config.json as a dict
+                h.update(repr(sorted((str(k_), repr(v_)) for k_, v_ in cfg.items())).encode())
+            else:
+                h.update(repr(sorted((k_, repr(v_)) for k_, v_ in getattr(cfg, "__dict__", {}).items())).encode())
         for name, t in list(obj.named_parameters()) + list(obj.named_buffers()):
             _describe((name, t), h)
         return
