@@ -6,5 +6,5 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/ab
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -fno-fast-math -ffp-contract=off -Wno-unused-result $2 \
-  $R/viquae_amd/csrc/knn.hip $R/viquae_amd/csrc/encoder.hip $R/viquae_amd/csrc/conv.hip $R/viquae_amd/csrc/fuse.hip $R/viquae_amd/csrc/image.hip $R/viquae_amd/csrc/diag.hip -o $R/ab/lib_$1.so
+  $R/viquae_amd/csrc/knn.hip $R/viquae_amd/csrc/encoder.hip $R/viquae_amd/csrc/conv.hip $R/viquae_amd/csrc/fuse.hip $R/viquae_amd/csrc/image.hip $R/viquae_amd/csrc/diag.hip $R/viquae_amd/csrc/runfmt.cpp -lpthread -o $R/ab/lib_$1.so
 echo built ab/lib_$1.so
