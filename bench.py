@@ -578,17 +578,32 @@ def main():
                     local_step(a_, b_, q=qs, out=outs)
                 torch.cuda.synchronize()
                 tile_ms = sum(a_.elapsed_time(b_) for a_, b_ in evs_t) / reps
+            # ... and through round 4's streaming kernel (one wave per SIMD, csrc/knn_small.inc), same process
+            with _lib.knn_option(_lib.KNN_OPT_SMALL_WAVES, 4):
+                for _ in range(3):
+                    local_step(q=qs, out=outs)
+                evs_4 = make_events(reps)
+                torch.cuda.synchronize()
+                for a_, b_ in evs_4:
+                    local_step(a_, b_, q=qs, out=outs)
+                torch.cuda.synchronize()
+                one_wave_ms = sum(a_.elapsed_time(b_) for a_, b_ in evs_4) / reps
+            waves = int(lib.mq_knn_get_option(_lib.KNN_OPT_SMALL_WAVES))
+            small_name = "screen_small8_kernel" if waves == 8 else "screen_small_kernel"
             small_batch = {
                 "workload": f"{nqs} queries (the reference's Dataset.map batch) x {rows}x{DIM} KB, exact IP top-{k}, one C-ABI call",
-                "scan_kernel": {0: "none", 1: "screen_scan_kernel (256 x 256 tiles)", 2: "screen_small_kernel<12> (queries in registers, LDS ring of 32-row tiles)"}.get(kind, str(kind)),
+                "scan_kernel": {0: "none", 1: "screen_scan_kernel (256 x 256 tiles)",
+                                2: f"{small_name}<12> (queries in registers, LDS ring of 32-row tiles, "
+                                   f"{'two waves' if waves == 8 else 'one wave'} per SIMD)"}.get(kind, str(kind)),
                 "ms": round(call_ms, 4), "queries_per_s": round(nqs / call_ms * 1e3, 1),
                 "scan_kernel_ms": round(k_ms, 4),
                 "algorithmic_hbm_bytes": kb_bytes, "achieved_gbps": round(kb_bytes / (k_ms * 1e-3) / 1e9, 1),
                 "hbm_frac": round(kb_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
                 "mfma_frac": round(2.0 * nqs * rows * DIM / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                 "tile_kernel_scan_ms": round(tile_ms, 4),
-                "scan_kernel_ms_profile": profile_kernel_ms("screen_small_kernel", "_nq256_kernel_stats.csv")[0],
-                "scan_kernel_ms_profile_from": profile_kernel_ms("screen_small_kernel", "_nq256_kernel_stats.csv")[1],
+                "one_wave_per_simd_kernel_scan_ms": round(one_wave_ms, 4),
+                "scan_kernel_ms_profile": profile_kernel_ms(small_name, "_nq256_kernel_stats.csv")[0],
+                "scan_kernel_ms_profile_from": profile_kernel_ms(small_name, "_nq256_kernel_stats.csv")[1],
                 "traffic": load_traffic("screened_1500000x768_nq256_k100")[0],
                 "traffic_from_profile": load_traffic("screened_1500000x768_nq256_k100")[1],
             }

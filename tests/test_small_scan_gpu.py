@@ -19,9 +19,11 @@ def _default_switches():
     lib = _lib.load()
     lib.mq_knn_set_option(_lib.KNN_OPT_SMALL_SCAN, 1)
     lib.mq_knn_set_option(_lib.KNN_OPT_SMALL_MIN_TILES, 0)
+    lib.mq_knn_set_option(_lib.KNN_OPT_SMALL_WAVES, 8)
     yield
     lib.mq_knn_set_option(_lib.KNN_OPT_SMALL_SCAN, 1)
     lib.mq_knn_set_option(_lib.KNN_OPT_SMALL_MIN_TILES, 0)
+    lib.mq_knn_set_option(_lib.KNN_OPT_SMALL_WAVES, 8)
 
 
 def _index(X, metric=0, factory="Flat", screen=True, tie_order=None):
@@ -32,10 +34,18 @@ def _index(X, metric=0, factory="Flat", screen=True, tie_order=None):
 
 
 def _both_scans(idx, Q, k):
-    """(D, I) through the streaming kernel and through the tile kernel of the same index."""
+    """(D, I) through the streaming kernel and through the tile kernel of the same index.  The streaming kernel has two
+    instances -- two waves per SIMD (round 5, csrc/knn_small8.inc: the default) and one (round 4, csrc/knn_small.inc) -- which
+    must agree bit for bit; the first one's results and statistics are returned."""
+    from viquae_amd import _lib
     assert idx.scan_kind(len(Q), k) == "stream"
+    assert _lib.load().mq_knn_get_option(_lib.KNN_OPT_SMALL_WAVES) == 8
     D1, I1 = idx.search_batch(Q, k)
     stats = idx.screen_stats(len(Q), k)
+    with _lib.knn_option(_lib.KNN_OPT_SMALL_WAVES, 4):
+        D4, I4 = idx.search_batch(Q, k)
+        stats4 = idx.screen_stats(len(Q), k)
+    assert np.array_equal(I4, I1) and np.array_equal(D4, D1) and stats4[0] == stats[0]
     from viquae_amd import _lib
     with _lib.knn_option(_lib.KNN_OPT_SMALL_SCAN, 0):
         assert idx.scan_kind(len(Q), k) == "tile"

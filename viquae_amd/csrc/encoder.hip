@@ -310,6 +310,12 @@ __device__ __forceinline__ void store_split_pair(float x, bool valid, unsigned s
     if (valid) *reinterpret_cast<unsigned*>((odd ? lo : hi) + even_col_index) = word;
 }
 
+#ifndef MQ_GEMM_F32_VIA_LDS
+// fp32 outputs of whole tiles leave through the LDS transposition (16-byte stores) like the split ones, unless a residual is added:
+// round 5, tools/probe_gemm_m.py, same box -- QKV (bias) 1101-1107 -> 1159-1172 executed TFLOP/s, bias-only K = 3072: 1118 -> 1265;
+// with a residual (out-proj 1010-1018 -> 918, FFN2 1172-1233 -> 1198-1203) the direct epilogue stays (1 = the LDS path for those too)
+#define MQ_GEMM_F32_VIA_LDS 0
+#endif
 constexpr int XS_STAGE = 4 * X_W_BYTES;      // Ah, Al, Wh, Wl: [256][32] bf16 each
 constexpr int XS_LDS_BYTES = 2 * XS_STAGE;   // 128 KiB
 
@@ -505,9 +511,9 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
             }
         }
     };
-    if (SPLIT_OUT && m0 + GT <= M && n0 + GT <= N && (N & 7) == 0) {
-        // Round 3, SPLIT outputs only (measured: FFN1 + GELU 2.90 -> 2.83 ms; with fp32 outputs, whose direct stores are already
-        // 128-byte runs per half-wave, the detour through LDS costs 2-6 %): the C store of a tile that lies wholly inside C goes through LDS, one 32 x 32 accumulator at a time, so that
+    if ((SPLIT_OUT || EPI != EPI_BIAS_RESIDUAL || MQ_GEMM_F32_VIA_LDS) && m0 + GT <= M && n0 + GT <= N && (N & 7) == 0) {
+        // Round 3 for SPLIT outputs (FFN1 + GELU 2.90 -> 2.83 ms), round 5 for fp32 outputs without a residual (above; in round 3,
+        // before the tile layouts, the detour cost them 2-6 %): the C store of a tile that lies wholly inside C goes through LDS, one 32 x 32 accumulator at a time, so that
         // a lane ends up with EIGHT consecutive columns of one row: 16-byte stores (two for fp32, one each for the hi and the
         // lo halves of a split output) and 16-byte residual loads, instead of 4-byte ones -- a quarter of the memory
         // instructions, and the split pair needs no DPP exchange.  Bias and activation are applied in the accumulator layout
@@ -522,6 +528,26 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
         for (int a = 0; a < 4; ++a) {
             const f32x16& acc = a == 0 ? acc00 : a == 1 ? acc01 : a == 2 ? acc10 : acc11;
             const float bs = (a & 1) ? bias1 : bias0;
+            // the residual of this accumulator's two row groups, in the TRANSPOSED layout (8 consecutive columns of one row per
+            // lane), requested before the trip through LDS so that its round trip overlaps it (round 5: requested after the LDS
+            // reads, each accumulator paid it in full -- the reason fp32 outputs with a residual avoided this path)
+            float4 ru[2], rv[2];
+            if (EPI == EPI_BIAS_RESIDUAL) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int row = 16 * it + (lane >> 2), g = lane & 3;
+                    if (Rl) {
+                        const size_t rp = pair_index((size_t)(m0 + 64 * wr + 32 * (a >> 1) + row), n0 + 64 * wc + 32 * (a & 1) + 8 * g, N);
+                        ru[it] = __builtin_bit_cast(float4, *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(R) + rp));
+                        rv[it] = __builtin_bit_cast(float4, *reinterpret_cast<const uint4*>(Rl + rp));
+                    } else {
+                        const size_t at = (size_t)(m0 + 64 * wr + 32 * (a >> 1) + row) * N + (n0 + 64 * wc + 32 * (a & 1) + 8 * g);
+                        ru[it] = *reinterpret_cast<const float4*>(R + at);
+                        rv[it] = *reinterpret_cast<const float4*>(R + at + 4);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kg;
@@ -538,23 +564,21 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
                 float4 u = *reinterpret_cast<const float4*>(src), v = *reinterpret_cast<const float4*>(src + 4);
                 const size_t at = (size_t)(m0 + 64 * wr + 32 * (a >> 1) + row) * N + (n0 + 64 * wc + 32 * (a & 1) + 8 * g);
                 if (EPI == EPI_BIAS_RESIDUAL) {
-                    float4 ru, rv;
+                    float4 xu, xv;
                     if (Rl) {
-                        const size_t rp = pair_index((size_t)(m0 + 64 * wr + 32 * (a >> 1) + row), n0 + 64 * wc + 32 * (a & 1) + 8 * g, N);
-                        const uint4 h4 = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(R) + rp);
-                        const uint4 l4 = *reinterpret_cast<const uint4*>(Rl + rp);
+                        const uint4 h4 = __builtin_bit_cast(uint4, ru[it]), l4 = __builtin_bit_cast(uint4, rv[it]);
                         auto two = [](unsigned hw, unsigned lw, float& e0, float& e1) __attribute__((always_inline)) {
                             e0 = __uint_as_float(hw << 16) + __uint_as_float(lw << 16);
                             e1 = __uint_as_float(hw & 0xFFFF0000u) + __uint_as_float(lw & 0xFFFF0000u);
                         };
-                        two(h4.x, l4.x, ru.x, ru.y); two(h4.y, l4.y, ru.z, ru.w);
-                        two(h4.z, l4.z, rv.x, rv.y); two(h4.w, l4.w, rv.z, rv.w);
+                        two(h4.x, l4.x, xu.x, xu.y); two(h4.y, l4.y, xu.z, xu.w);
+                        two(h4.z, l4.z, xv.x, xv.y); two(h4.w, l4.w, xv.z, xv.w);
                     } else {
-                        ru = *reinterpret_cast<const float4*>(R + at);
-                        rv = *reinterpret_cast<const float4*>(R + at + 4);
+                        xu = ru[it];
+                        xv = rv[it];
                     }
-                    u.x += ru.x; u.y += ru.y; u.z += ru.z; u.w += ru.w;
-                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    u.x += xu.x; u.y += xu.y; u.z += xu.z; u.w += xu.w;
+                    v.x += xv.x; v.y += xv.y; v.z += xv.z; v.w += xv.w;
                 }
                 if (SPLIT_OUT) {
                     bf16x8_t hi8, lo8;
