@@ -36,6 +36,15 @@ extern "C" {
 
 #define MQ_METRIC_IP 0 /* faiss.METRIC_INNER_PRODUCT, "metric_type": 0 in experiments/ir/..../search/config.json */
 #define MQ_METRIC_L2 1 /* faiss.METRIC_L2 (FAISS default when metric_type is None) */
+/* Accepted by the mq_knn_screen_* entries, mq_knn_search_screened_f32, mq_knn_workspace_bytes_metric and mq_knn_screen_scan_kind only:
+ * the inner product served by the CENTRED-QUERY screen (round 5).  With c the centre of the bf16 copy, q.x = (q - c).(x - c) +
+ * c.(x - c) + q.c: the rows of a query rank by (q - c).(x - c) plus the per-row term c.(x - c), which the copy carries in two extra
+ * columns like the L2 metric's -||x||^2 / 2; the rounding error -- hence the margin, hence the candidates per query -- then follows
+ * the spread of the scores even when every vector shares a large common component (image features).  Results are the plain inner
+ * product's, bit for bit (the screen is a lossless filter either way).  The index is built with this code (screen_bytes /
+ * prepare / add_rows: a centre is required) and searched with it; xstats_dev then holds 4 + d floats: the four statistics, then
+ * the centre. */
+#define MQ_METRIC_IP_CENTRED 2
 
 /* `--k` is a user option of the reference (meerqat/ir/search.py:12,135; default 100) and faiss IndexFlat takes any k.  One
  * fused scan keeps up to MQ_KNN_FUSED_K neighbours; a larger k (up to MQ_KNN_MAX_K, FAISS-GPU's own limit) is served by
@@ -161,9 +170,10 @@ int mq_knn_search_f32_ev(const float *packed_dev, const float *sqnorm_dev, int64
  *   bf16_dev                  : mq_knn_screen_bytes(N, d, metric) bytes, bf16 copy (rows padded to 256, d (+2) to 64); an
  *                               opaque buffer owned by these three calls -- stored tile by tile ([row / 256][col / 64][256][64]:
  *                               one K step's operand is one contiguous 32-KiB block), a prefix of the rows is a prefix of it
- *   xstats_dev                : THREE floats kept by mq_knn_screen_prepare (zero them before its first call):
- *                               max ||x||^2, max ||xc - bf16(xc)||^2 and max ||xc||^2 over the shard (xc = x - centre),
- *                               the inputs of the error bound
+ *   xstats_dev                : FOUR floats kept by mq_knn_screen_prepare (zero them before its first call):
+ *                               max ||x||^2, max ||xc - bf16(xc)||^2, max ||xc||^2 and max |c . xc| over the shard (xc = x -
+ *                               centre c), the inputs of the error bound; under MQ_METRIC_IP_CENTRED 4 + d floats: the
+ *                               caller stores the centre behind the statistics, where the search reads it
  *   center_dev                : NULL, or d floats subtracted from every row before the bf16 rounding (both metrics;
  *                               ANY fixed vector is valid: q.(x - c) ranks the rows of a query like q.x, and for
  *                               embeddings with a large shared component the screen's margin then follows ||x - c||);

@@ -246,10 +246,12 @@ def test_centred_screen_on_embeddings_with_a_shared_component(factory, metric, m
     assert sc[0] == 0 and sc[1] < 0.8 * su[1], (sc[:3], su[:3])   # fewer rows re-scored, nothing fell back
 
 
-def test_centred_margin_dominates_the_measured_screening_error():
+def test_centred_margin_dominates_the_measured_screening_error(monkeypatch):
     """|S~c - Sc| <= margin / 2 with S~c = bf16(q) . bf16(x - c) and Sc = q . (x - c) in float64, for every (query, row);
-    and the centred margin is well below the uncentred one on such data."""
+    and the centred margin is well below the uncentred one on such data.  (The rows-only centring: MQ_KNN_CENTER_QUERIES=0;
+    with the queries centred as well -- the default at this width, where the two columns are free -- see the next test.)"""
     from viquae_amd.index import MI355XFlatIndex
+    monkeypatch.setenv("MQ_KNN_CENTER_QUERIES", "0")
     X, Q = _anisotropic(6000, 200, 200, 5)
     idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
     idx.add(X)
@@ -266,3 +268,64 @@ def test_centred_margin_dominates_the_measured_screening_error():
     assert margin < 0.8 * unc, (margin, unc)
     s = idx._xmax2.cpu().numpy()
     assert abs(s[0] - float((X.double() ** 2).sum(1).max())) < 1e-3 * s[0] and s[2] < 0.6 * s[0]
+
+
+@pytest.mark.parametrize("d,shift", [(200, 9.0), (1000, 20.0), (2048, 40.0), (128, 9.0)])
+def test_centred_query_margin_dominates_the_measured_screening_error(d, shift, monkeypatch):
+    """MQ_METRIC_IP_CENTRED (round 5): S~ = bf16(q - c) . bf16(x - c) + (h + l), (h, l) the bf16 pair of v = c . (x - c), against
+    S = q . x - q . c in float64 -- |S~ - S| <= margin / 2 for every (query, row), the margin is not vacuous, it sits well below
+    the rows-only margin on data with a large shared component, and the search is the exact scan's bit for bit."""
+    from viquae_amd.index import METRIC_IP_CENTRED, MI355XFlatIndex
+    n, nq, k = 6000, 200, 10
+    X, Q = _anisotropic(n, d, nq, 5 + d, shift=shift, noise=0.25)
+    if d == 128:
+        monkeypatch.setenv("MQ_KNN_CENTER_QUERIES", "1")   # d % 64 == 0 and d <= 768: not chosen by default (a 3rd K block)
+    idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
+    idx.add(X[:2560])
+    idx.add(X[2560:])
+    assert idx._screen_metric == METRIC_IP_CENTRED
+    D, I = idx.search_device(Q, k)
+    stats = idx.screen_stats(nq, k)
+    margin = stats[5] * 1e-6
+    ex = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=False)
+    ex.add(X)
+    De, Ie = ex.search_device(Q, k)
+    assert torch.equal(D, De) and torch.equal(I, Ie) and stats[0] == 0
+    c = idx._center
+    Xc32, Qc32 = X - c, Q - c                                                    # fp32, as the kernels form them
+    v = torch.zeros(n, device="cuda")
+    for t in range(d):                                                           # the k-ordered fp32 fma chain of the pack kernel
+        v = torch.addcmul(v, Xc32[:, t], c[t])                                   # (fused or not: inside the 2^-24 d terms of the margin)
+    h = v.to(torch.bfloat16)
+    l = (v - h.float()).to(torch.bfloat16)
+    screen = Qc32.to(torch.bfloat16).double() @ Xc32.to(torch.bfloat16).double().T + (h.double() + l.double())[None]
+    target = Q.double() @ X.double().T - (Q.double() @ c.double())[:, None]
+    dev = (screen - target).abs().max().item()
+    assert margin >= 2 * dev, (margin, dev)
+    assert margin <= 60 * dev, (margin, dev)                                      # not vacuous
+    monkeypatch.setenv("MQ_KNN_CENTER_QUERIES", "0")
+    rows_only = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
+    rows_only.add(X)
+    assert rows_only._screen_metric == 0
+    D0, I0 = rows_only.search_device(Q, k)
+    st0 = rows_only.screen_stats(nq, k)
+    assert torch.equal(D0, De) and torch.equal(I0, Ie)
+    assert margin < 0.5 * st0[5] * 1e-6, (margin, st0[5] * 1e-6)                  # the margin now follows ||q - c||, not ||q||
+    assert st0[0] > 0 or stats[1] <= st0[1]                                       # never more rows re-scored (unless the rows-only screen gave up)
+
+
+def test_centred_queries_policy():
+    """When the index centres its queries as well: inner product only, a centre that carries a quarter of the squared norms, and
+    either free columns (d % 64 in 1 ... 62) or a width beyond the streaming kernel's 768 columns; never d = 767 / 768."""
+    from viquae_amd.index import METRIC_IP_CENTRED, MI355XFlatIndex
+
+    def metric_of(d, shift, metric=0, factory="Flat"):
+        X, _ = _anisotropic(3000, d, 4, d, shift=shift, noise=0.25)
+        idx = MI355XFlatIndex(string_factory=factory, metric_type=metric, screen=True)
+        idx.add(X)
+        return idx._screen_metric
+
+    assert metric_of(200, 9.0) == METRIC_IP_CENTRED and metric_of(200, 0.0) == 0          # no shared component: plain
+    assert metric_of(1024, 20.0) == METRIC_IP_CENTRED and metric_of(2048, 30.0, factory="L2norm,Flat") == METRIC_IP_CENTRED
+    assert metric_of(768, 20.0) == 0 and metric_of(767, 20.0) == 0 and metric_of(512, 20.0) == 0
+    assert metric_of(200, 9.0, metric=1) == 1                                              # the L2 screen keeps its own row term

@@ -233,5 +233,8 @@ def clip_text_padded_throughput(B=2048, mean_len=8, std_len=3, longest=32, steps
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "arcface":   # rocprofv3 --kernel-trace --stats -- python3 tools/bench_encoders.py arcface
+        print(json.dumps({"arcface": arcface_throughput()}))
+        sys.exit(0)
     print(json.dumps({"dpr": dpr_throughput(), "dpr_padded": dpr_padded_throughput(), "clip": clip_throughput(),
                       "clip_text": clip_text_throughput(), "clip_text_padded": clip_text_padded_throughput()}))

@@ -51,7 +51,7 @@ def one_index(name, column, d, factory, rows, nq, k, reps, shared, device):
     make_queries = _fill(idx, rows, d, seed=d, shared=shared, device=device)
     Q = make_queries(nq).contiguous()
     stream = torch.cuda.current_stream(device)
-    ws_bytes = int(lib.mq_knn_workspace_bytes_metric(rows, d, nq, k, 0))
+    ws_bytes = int(lib.mq_knn_workspace_bytes_metric(rows, d, nq, k, idx._screen_metric))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
     D = torch.empty((nq, k), dtype=torch.float32, device=device)
     I = torch.empty((nq, k), dtype=torch.int64, device=device)
@@ -60,7 +60,7 @@ def one_index(name, column, d, factory, rows, nq, k, reps, shared, device):
     def call(e0=None, e1=None):
         _lib.check(lib.mq_knn_search_screened_f32(
             idx._packed.data_ptr() if idx._packed is not None else None, idx._sqnorm.data_ptr(), idx._rowmajor.data_ptr(),
-            idx._bf16.data_ptr(), idx._xmax2.data_ptr(), rows, d, Q.data_ptr(), nq, k, 0, flags, 0, D.data_ptr(), I.data_ptr(),
+            idx._bf16.data_ptr(), idx._xmax2.data_ptr(), rows, d, Q.data_ptr(), nq, k, idx._screen_metric, flags, 0, D.data_ptr(), I.data_ptr(),
             ws.data_ptr(), ws_bytes, stream.cuda_stream, e0.cuda_event if e0 else None, e1.cuda_event if e1 else None),
             "mq_knn_search_screened_f32")
 
@@ -88,9 +88,10 @@ def one_index(name, column, d, factory, rows, nq, k, reps, shared, device):
         qn = qn * (1.0 / qn.double().pow(2).sum(1, keepdim=True).sqrt()).float()
     ok = bool(((rows_of.double() * qn.double()[:, None, :]).sum(-1) - D[:8].double()).abs().max() < 1e-3 * max(1.0, float(D[:8].abs().max()))
               and (D[:, 1:] <= D[:, :-1]).all() and (I >= 0).all())
-    dp = (d + 63) // 64 * 64
+    dp = (d + (2 if idx._screen_metric else 0) + 63) // 64 * 64
     kb_bytes = rows * dp * 2
     out = {"index": name, "column": column, "d": d, "string_factory": factory, "metric_type": 0, "l2norm_form": "faiss" if "L2norm" in factory else None,
+           "queries_centred": idx._screen_metric == 2, "bf16_columns": dp,
            "scan_kind": idx.scan_kind(nq, k), "scan_ms": round(scan_ms, 4), "call_ms": round(call_ms, 4),
            "queries_per_s": round(nq / call_ms * 1e3, 1),
            "algorithmic_hbm_bytes": kb_bytes, "hbm_frac": round(kb_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),

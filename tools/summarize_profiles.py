@@ -21,7 +21,7 @@ def first(pattern):
     return hits[-1] if hits else None  # gpurun merges runs into the same directories: take the newest
 
 
-for sub, name in (("kt", f"{tag}_kernel_stats.csv"), ("enc", f"{tag}_encoders_kernel_stats.csv")):
+for sub, name in (("kt", f"{tag}_kernel_stats.csv"), ("enc", f"{tag}_encoders_kernel_stats.csv"), ("arc", f"{tag}_arcface_kernel_stats.csv")):
     f = first(f"{sub}/**/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(dst, name))
@@ -93,9 +93,10 @@ for key, kernel in (("screened_1500000x768_nq4096_k100", "screen_scan_kernel"), 
     if t:
         out[key] = t
 # the 256-query search (its own rocprofv3 passes): the streaming scan reads every row once
-c = next((v for k_, v in small.items() if k_.startswith("screen_small_kernel")), None) if small else None
+small_name = next((k_ for k_ in (small or {}) if k_.startswith("screen_small")), None)  # screen_small8_kernel<12> since round 5
+c = small[small_name] if small_name else None
 if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-    out["screened_1500000x768_nq256_k100"] = {"kernel": "screen_small_kernel<12>", "profile": f"profiles/{tag}_nq256_pmc.json",
+    out["screened_1500000x768_nq256_k100"] = {"kernel": small_name, "profile": f"profiles/{tag}_nq256_pmc.json",
                                               "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"]["max_per_launch"] + c["WRITE_SIZE"]["max_per_launch"]) * 1024),
                                               "fetch_kb_raw": c["FETCH_SIZE"]["max_per_launch"], "write_kb_raw": c["WRITE_SIZE"]["max_per_launch"]}
 if len(out) > 1:

@@ -991,7 +991,10 @@ struct Geometry {
 };
 
 // bf16 row length of the screening copy: d (inner product) or d + 2 (L2: the (h, l) pair of -||x||^2 / 2), padded to 64
-int screen_dp(int d, int metric) { return (int)round_up(d + (metric == MQ_METRIC_L2 ? 2 : 0), SBK); }
+// (two extra columns carry the per-row term of the L2 metric and of the centred-query inner product: knn_screen.inc)
+int screen_dp(int d, int metric) { return (int)round_up(d + ((metric == MQ_METRIC_L2 || metric == MQ_METRIC_IP_CENTRED) ? 2 : 0), SBK); }
+inline bool screen_metric_ok(int metric) { return metric == MQ_METRIC_IP || metric == MQ_METRIC_L2 || metric == MQ_METRIC_IP_CENTRED; }
+inline int true_metric(int metric) { return metric == MQ_METRIC_IP_CENTRED ? MQ_METRIC_IP : metric; }
 
 // metric: MQ_METRIC_IP / MQ_METRIC_L2, or -1 = unknown (reserve what either needs).  Only the L2 metric has the small-batch
 // direct form whose [nq][npad] distance matrix lives at the END of the workspace, so every other offset is metric-independent.
@@ -1271,8 +1274,8 @@ size_t mq_knn_workspace_bytes(int64_t N, int d, int nq, int k) {
 }
 
 size_t mq_knn_workspace_bytes_metric(int64_t N, int d, int nq, int k, int metric) {
-    if (N < 0 || d <= 0 || nq < 0 || k <= 0 || k > MQ_KNN_MAX_K || (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2)) return 0;
-    return geometry(N, d, nq, k, num_cus(), metric).total + partition_extra_bytes(N, nq, k);
+    if (N < 0 || d <= 0 || nq < 0 || k <= 0 || k > MQ_KNN_MAX_K || !screen_metric_ok(metric)) return 0;
+    return geometry(N, d, nq, k, num_cus(), true_metric(metric)).total + partition_extra_bytes(N, nq, k);
 }
 
 int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[8]) {
@@ -1291,11 +1294,11 @@ int mq_knn_launch_info(int64_t N, int d, int nq, int k, int64_t out[8]) {
 
 int mq_knn_screen_scan_kind(int64_t N, int d, int nq, int k, int metric) {
     if (N <= 0 || d <= 0 || nq <= 0 || k <= 0 || k > MQ_KNN_MAX_K) return MQ_EINVAL;
-    if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
+    if (!screen_metric_ok(metric)) return MQ_EINVAL;
     if (metric == MQ_METRIC_L2 && nq < MQ_KNN_L2_DIRECT_BELOW) return MQ_SCAN_KIND_NONE;
     if (const PartPlan pl = partition_plan(N, k); pl.P) { N = pl.per; k = PART_K; }  // the scan of each row range
     if (k > SCREEN_MAX_K) return MQ_SCAN_KIND_NONE;
-    const Geometry g = geometry(N, d, nq, k, num_cus(), metric);
+    const Geometry g = geometry(N, d, nq, k, num_cus(), true_metric(metric));
     return small_scan_serves(g, N, screen_dp(d, metric), k) ? MQ_SCAN_KIND_STREAM : MQ_SCAN_KIND_TILE;
 }
 
@@ -1475,7 +1478,8 @@ static int screen_copy_and_stats(const float* sqnorm_dev, int d, int metric, int
     const float* rm = rowmajor_dev + (size_t)row_offset * d;
     const int64_t quads = n * (int64_t)(dp / 4);
     hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, rm, n, d, dp,
-                       (unsigned short*)bf16_dev, metric == MQ_METRIC_L2 ? 1 : 0, sqnorm_dev + row_offset, center_dev, row_offset);
+                       (unsigned short*)bf16_dev, metric == MQ_METRIC_L2 ? 1 : (metric == MQ_METRIC_IP_CENTRED ? 3 : 0), sqnorm_dev + row_offset,
+                       center_dev, row_offset);
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(row_err_stats_kernel, dim3((unsigned)((n + 3) / 4 < 2048 ? (n + 3) / 4 : 2048)), dim3(256), 0, st, rm,
                        (const unsigned short*)bf16_dev, n, d, dp, (unsigned*)xstats_dev, center_dev, row_offset);
@@ -1490,7 +1494,7 @@ int mq_knn_screen_prepare(const float* packed_dev, const float* sqnorm_dev, int6
     if (!packed_dev || !sqnorm_dev || !rowmajor_dev || !bf16_dev || !xstats_dev || n < 0 || d <= 0 || row_offset < 0 ||
         row_offset + n > capacity_rows)
         return MQ_EINVAL;
-    if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
+    if (!screen_metric_ok(metric) || (metric == MQ_METRIC_IP_CENTRED && !center_dev)) return MQ_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int dpad = mq_padded_dim(d);
     float* rm = rowmajor_dev + (size_t)row_offset * d;
@@ -1507,7 +1511,7 @@ int mq_knn_screen_add_rows_f32(const float* rows_dev, int64_t n, int d, int64_t 
     if (!rows_dev || !sqnorm_dev || !rowmajor_dev || !bf16_dev || !xstats_dev || n < 0 || d <= 0 || row_offset < 0 ||
         row_offset + n > capacity_rows)
         return MQ_EINVAL;
-    if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
+    if (!screen_metric_ok(metric) || (metric == MQ_METRIC_IP_CENTRED && !center_dev)) return MQ_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(store_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, rows_dev, n, d, mq_padded_dim(d), row_offset,
                        l2norm, rowmajor_dev, sqnorm_dev);
@@ -1520,14 +1524,19 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
                                int nq, int k, int metric, int flags, int64_t id_offset, float* D_dev, int64_t* I_dev,
                                void* ws_dev, size_t ws_bytes, void* stream, void* ev_scan_begin, void* ev_scan_end) {
     if (nq == 0) return MQ_OK;
-    if (metric != MQ_METRIC_IP && metric != MQ_METRIC_L2) return MQ_EINVAL;
+    if (!screen_metric_ok(metric)) return MQ_EINVAL;
     if (flags & ~MQ_KNN_SCREENED_FLAGS) return MQ_EINVAL;
     // the two halves of one search (MQ_KNN_FLAG_PHASE_*): neither or both bits = the whole search
     const int phase = flags & (MQ_KNN_FLAG_PHASE_FRONT | MQ_KNN_FLAG_PHASE_TAIL);
     const bool do_front = phase != MQ_KNN_FLAG_PHASE_TAIL, do_tail = phase != MQ_KNN_FLAG_PHASE_FRONT;
     const int l2norm_queries = query_l2norm_form(flags);
     const unsigned flip = tie_flip(flags);
+    // MQ_METRIC_IP_CENTRED: the index was built for the centred-query screen (two extra columns = the row term c . (x - c), the
+    // centre itself behind the statistics: xstats_dev[4 .. 4 + d)); everything exact -- re-scoring, fallback scans, merges -- is
+    // the plain inner product
     const int l2 = metric == MQ_METRIC_L2;
+    const int ipc = metric == MQ_METRIC_IP_CENTRED;
+    const int tm = true_metric(metric);
     const int dp = screen_dp(d, metric);
     // packed_dev may be NULL (an index that keeps no panel copy): the exact-scan fallback and FAISS's small-batch L2 form then
     // read the row-major copy
@@ -1536,7 +1545,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     if (N <= 0 || d <= 0 || nq < 0 || k <= 0) return MQ_EINVAL;
     if (k > MQ_KNN_MAX_K) return MQ_EUNSUPPORTED;
     if (N >= 0xFFFFFFFFll) return MQ_EUNSUPPORTED;
-    const Geometry g = geometry(N, d, nq, k, num_cus(), metric);
+    const Geometry g = geometry(N, d, nq, k, num_cus(), tm);
     if (ws_bytes < g.total) return MQ_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     // searches served without the screen are one piece: the FRONT call does all of it, the TAIL call has nothing left to do
@@ -1602,7 +1611,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         a.Xp = packed_dev ? packed_dev : rowmajor_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = pools; a.d = d;
         a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = nullptr; a.only = pflags;
         a.flip = flip; a.ceil = nullptr;
-        return exact_scan_rounds(metric, packed_dev == nullptr, a, g, nq, k, id_offset, D_dev, I_dev, ws, pflags, st, nullptr, nullptr);
+        return exact_scan_rounds(tm, packed_dev == nullptr, a, g, nq, k, id_offset, D_dev, I_dev, ws, pflags, st, nullptr, nullptr);
     }
     if (k > SCREEN_MAX_K) {
         // More than SCREEN_MAX_K neighbours: the bounded screening buffers are sized for the reference's k = 100 (the pools hold
@@ -1616,7 +1625,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         a.Xp = packed_dev ? packed_dev : rowmajor_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = pools; a.d = d;
         a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = nullptr; a.only = nullptr;
         a.flip = flip; a.ceil = nullptr;
-        return exact_scan_rounds(metric, packed_dev == nullptr, a, g, nq, k, id_offset, D_dev, I_dev, ws, nullptr, st, ev_scan_begin,
+        return exact_scan_rounds(tm, packed_dev == nullptr, a, g, nq, k, id_offset, D_dev, I_dev, ws, nullptr, st, ev_scan_begin,
                                  ev_scan_end);
     }
     if (do_front) {
@@ -1634,10 +1643,10 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     {
         const int64_t quads = (int64_t)nq * (dp / 4);
         hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, q_rm, (int64_t)nq, d, dp, Qb,
-                           l2 ? 2 : 0, (const float*)nullptr, (const float*)nullptr, (int64_t)0);
+                           (l2 || ipc) ? 2 : 0, (const float*)nullptr, ipc ? xstats_dev + 4 : (const float*)nullptr, (int64_t)0);
         MQ_HIP(hipGetLastError());
         hipLaunchKernelGGL(screen_margin_kernel, dim3((unsigned)((g.nqpad + 3) / 4)), dim3(256), 0, st, q_rm, Qb, xstats_dev, nq,
-                           (int)g.nqpad, d, dp, margin, l2);
+                           (int)g.nqpad, d, dp, margin, l2 ? 1 : (ipc ? 2 : 0), ipc ? xstats_dev + 4 : (const float*)nullptr);
         MQ_HIP(hipGetLastError());
     }
     // 1. bf16 screening scan
@@ -1691,7 +1700,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         a.Xp = packed_dev ? packed_dev : rowmajor_dev; a.Qp = Qp; a.xn = sqnorm_dev; a.qn = qn; a.lists = pools; a.d = d;
         a.N = N; a.dpad = g.dpad; a.nqt = g.nqt; a.S = g.S; a.k = k; a.nchunks = g.nchunks; a.qpx = g.qpx; a.dbg = nullptr; a.only = ovf;
         a.flip = flip; a.ceil = nullptr;
-        const int rc = exact_scan_rounds(metric, packed_dev == nullptr, a, g, nq, k, id_offset, D_dev, I_dev, ws, ovf, st, nullptr, nullptr);
+        const int rc = exact_scan_rounds(tm, packed_dev == nullptr, a, g, nq, k, id_offset, D_dev, I_dev, ws, ovf, st, nullptr, nullptr);
         if (rc != MQ_OK) return rc;
     }
     return MQ_OK;

@@ -37,6 +37,7 @@ from . import _lib
 
 METRIC_INNER_PRODUCT = 0  # faiss.METRIC_INNER_PRODUCT
 METRIC_L2 = 1  # faiss.METRIC_L2
+METRIC_IP_CENTRED = 2  # MQ_METRIC_IP_CENTRED: the inner product behind the centred-query screen (screen entry points only)
 MAX_K = 2048  # MQ_KNN_MAX_K; the screened search serves k <= 224 itself, k <= 1792 over row ranges, beyond: ceil(k / 128) exact scans (include/meerqat_hip.h)
 FLAG_L2NORM_QUERIES, FLAG_TIE_ID_DESC, MERGE_TIE_ID_DESC = 1, 2, 0x100  # MQ_KNN_FLAG_*, MQ_MERGE_TIE_ID_DESC
 FLAG_L2NORM_FAISS = 4                            # MQ_KNN_FLAG_L2NORM_FAISS
@@ -164,8 +165,11 @@ class MI355XFlatIndex(BaseIndex):
         self.keep_panel = bool(keep_panel) or not self.screen
         self._rowmajor = None  # torch.float32 [capacity, d] (screened path only)
         self._bf16 = None      # torch.uint8 bf16 copy
-        self._xmax2 = None     # torch.float32 [3]: max ||x||^2, max ||xc - bf16(xc)||^2, max ||xc||^2 (kept by mq_knn_screen_prepare)
-        self._center = None    # torch.float32 [d]: the vector the bf16 screening copy is centred on (inner product only)
+        self._xmax2 = None     # torch.float32 [4 + d]: max ||x||^2, max ||xc - bf16(xc)||^2, max ||xc||^2, max |c . xc| (kept by
+        #                        mq_knn_screen_prepare), then the centre (read by the search under MQ_METRIC_IP_CENTRED)
+        self._center = None    # torch.float32 [d]: the vector the bf16 screening copy is centred on (a view of _xmax2[4:])
+        self._screen_metric = self.metric_type   # what the mq_knn_screen_* entries are told: METRIC_IP_CENTRED (2) when the
+        #                        queries are centred as well (decided at the first add, _prepare_screen)
 
     def __reduce__(self):
         # Like a FAISS GPU index: device-resident, not picklable.  It also keeps `datasets` from hashing the whole shard
@@ -199,7 +203,7 @@ class MI355XFlatIndex(BaseIndex):
             new_sqnorm[: self._sqnorm.numel()].copy_(self._sqnorm)
         if self.screen:
             new_rm = torch.empty((cap, self.d), dtype=torch.float32, device=self._torch_device)
-            new_bf = torch.zeros(int(lib.mq_knn_screen_bytes(cap, self.d, self.metric_type)), dtype=torch.uint8, device=self._torch_device)
+            new_bf = torch.zeros(int(lib.mq_knn_screen_bytes(cap, self.d, self._screen_metric)), dtype=torch.uint8, device=self._torch_device)
             if self._rowmajor is not None and self.ntotal > 0:
                 new_rm[: self.ntotal].copy_(self._rowmajor[: self.ntotal])
                 new_bf[: self._bf16.numel()].copy_(self._bf16)
@@ -224,6 +228,8 @@ class MI355XFlatIndex(BaseIndex):
             n, d = vecs.shape
         if n == 0:
             return
+        if self.screen and self._xmax2 is None:
+            self._prepare_screen(vecs[:_UPLOAD_ROWS], d)  # centre + screen metric: BEFORE the bf16 copy is sized
         self._ensure_capacity(max(self.ntotal + n, total_hint or 0), d, exact=bool(total_hint))
         stream = torch.cuda.current_stream(self._torch_device).cuda_stream
         if not self.keep_panel:
@@ -248,7 +254,7 @@ class MI355XFlatIndex(BaseIndex):
                                                 self._capacity, self._sqnorm.data_ptr(), stream), "mq_pack_rows_f32")
                 if self.screen:
                     _lib.check(lib.mq_knn_screen_prepare(self._packed.data_ptr(), self._sqnorm.data_ptr(), self._capacity, self.d,
-                                                         self.metric_type, floor, blk.shape[0], self._rowmajor.data_ptr(),
+                                                         self._screen_metric, floor, blk.shape[0], self._rowmajor.data_ptr(),
                                                          self._bf16.data_ptr(), self._xmax2.data_ptr(),
                                                          self._center.data_ptr() if self._center is not None else None, stream),
                                "mq_knn_screen_prepare")
@@ -268,11 +274,8 @@ class MI355XFlatIndex(BaseIndex):
                                                 self._packed.data_ptr(), self._capacity, self._sqnorm.data_ptr(),
                                                 stream), "mq_pack_rows_f32")
                 if self.screen:
-                    if self._xmax2 is None:
-                        self._xmax2 = torch.zeros(3, dtype=torch.float32, device=self._torch_device)
-                        self._center = self._choose_center(dev)
                     _lib.check(lib.mq_knn_screen_prepare(self._packed.data_ptr(), self._sqnorm.data_ptr(), self._capacity, self.d,
-                                                         self.metric_type, self.ntotal, dev.shape[0], self._rowmajor.data_ptr(),
+                                                         self._screen_metric, self.ntotal, dev.shape[0], self._rowmajor.data_ptr(),
                                                          self._bf16.data_ptr(), self._xmax2.data_ptr(),
                                                          self._center.data_ptr() if self._center is not None else None, stream),
                                "mq_knn_screen_prepare")
@@ -298,15 +301,47 @@ class MI355XFlatIndex(BaseIndex):
         with torch.cuda.device(self._torch_device):
             for i in range(0, n, _UPLOAD_ROWS):
                 dev = self._upload(vecs[i:i + _UPLOAD_ROWS])
-                if self._xmax2 is None:
-                    self._xmax2 = torch.zeros(3, dtype=torch.float32, device=self._torch_device)
-                    self._center = self._choose_center(dev)
                 _lib.check(lib.mq_knn_screen_add_rows_f32(
-                    dev.data_ptr(), dev.shape[0], self.d, self.ntotal, self._l2norm_arg(), self.metric_type, self._capacity,
+                    dev.data_ptr(), dev.shape[0], self.d, self.ntotal, self._l2norm_arg(), self._screen_metric, self._capacity,
                     self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(), self._xmax2.data_ptr(),
                     self._center.data_ptr() if self._center is not None else None, stream), "mq_knn_screen_add_rows_f32")
                 self.ntotal += dev.shape[0]  # `dev` is released stream-ordered (see add())
             torch.cuda.current_stream(self._torch_device).synchronize()
+
+    def _prepare_screen(self, first_rows, d):
+        """First add of a screened index: the centre of the bf16 copy (``_choose_center``) and whether the QUERIES are centred as
+        well (``MQ_METRIC_IP_CENTRED``, include/meerqat_hip.h): with the inner product, a centre that carries a quarter or more of
+        the rows' squared norm (image features: non-negative, far from centred -- the reference's 2048-d ``imagenet-RN50`` and
+        1024-d ``clip-RN50`` columns) makes the margin follow ||q|| while the scores spread like ||q - c|| ||x - c||; the
+        centred-query screen removes that at the price of two more bf16 columns.  It is chosen when those columns are free
+        (d % 64 in 1 ... 62) or the index is wider than the streaming kernel's 768 columns anyway; never for d = 767 / 768, where
+        a 13th K block would cost the one-query-tile search its streaming kernel.  MQ_KNN_CENTER_QUERIES=0 / 1 overrides."""
+        import torch
+        if self._torch_device is None:
+            self._torch_device = _resolve_device(self.device)
+        dev = self._upload(first_rows)
+        center = self._choose_center(dev)
+        self._screen_metric = self.metric_type
+        if center is not None and self.metric_type == METRIC_INNER_PRODUCT:
+            x = dev.to(torch.float32)
+            if self.do_l2norm:
+                x = torch.nn.functional.normalize(x, dim=1)
+            x2 = float(torch.nan_to_num(x, nan=0.0, posinf=0.0, neginf=0.0).pow(2).sum(1).mean())
+            share = float(center.pow(2).sum()) / x2 if x2 > 0 else 0.0
+            dp_plain, dp_cols = (int(d) + 63) // 64, (int(d) + 2 + 63) // 64
+            free = dp_cols == dp_plain
+            want = share >= 0.25 and (free or int(d) > 768)
+            env = os.environ.get("MQ_KNN_CENTER_QUERIES")
+            if env is not None:
+                want = env != "0"
+            if want and not (dp_plain <= 12 < dp_cols and env is None):
+                self._screen_metric = METRIC_IP_CENTRED
+        self._xmax2 = torch.zeros(4 + int(d), dtype=torch.float32, device=self._torch_device)
+        if center is not None:
+            self._xmax2[4:].copy_(center)
+            self._center = self._xmax2[4:]
+        else:
+            self._center = None
 
     def _l2norm_arg(self):
         """The `l2norm` argument of the row-ingest entry points: 0 or the MQ_L2NORM_* code of this index's arithmetic."""
@@ -413,14 +448,14 @@ class MI355XFlatIndex(BaseIndex):
             for s, e in pieces:
                 q = queries[s:e]
                 self._last_call_nq = e - s  # screen_stats reads the workspace geometry of the LAST C-ABI call
-                nb = int(lib.mq_knn_workspace_bytes_metric(self.ntotal, self.d, q.shape[0], k, self.metric_type))
+                nb = int(lib.mq_knn_workspace_bytes_metric(self.ntotal, self.d, q.shape[0], k, self._screen_metric if self.screen else self.metric_type))
                 ws = self._workspace(nb)
                 Dq, Iq = D[s:e], I[s:e]
                 flags = self._search_flags()
                 if self.screen:
                     _lib.check(lib.mq_knn_search_screened_f32(
                         self._packed.data_ptr() if self._packed is not None else None, self._sqnorm.data_ptr(), self._rowmajor.data_ptr(), self._bf16.data_ptr(),
-                        self._xmax2.data_ptr(), self.ntotal, self.d, q.data_ptr(), q.shape[0], k, self.metric_type,
+                        self._xmax2.data_ptr(), self.ntotal, self.d, q.data_ptr(), q.shape[0], k, self._screen_metric,
                         flags,
                         self.id_offset, Dq.data_ptr(), Iq.data_ptr(), ws.data_ptr(), ws.numel(), stream, None, None),
                         "mq_knn_search_screened_f32")
@@ -468,7 +503,7 @@ class MI355XFlatIndex(BaseIndex):
 
     def pipeline_workspaces(self, nq, k):
         """-> ((workspace of even chunks, workspace of odd chunks), the stream second halves run on) for chunks of <= nq queries."""
-        nb = int(_lib.load().mq_knn_workspace_bytes_metric(self.ntotal, self.d, int(nq), k, self.metric_type))
+        nb = int(_lib.load().mq_knn_workspace_bytes_metric(self.ntotal, self.d, int(nq), k, self._screen_metric))
         return (self._workspace(nb), self._second_workspace(nb)), self._tail_stream
 
     def search_phase(self, q, k, out, ws, phase, stream):
@@ -477,7 +512,7 @@ class MI355XFlatIndex(BaseIndex):
         self._last_call_nq, self._last_ws = q.shape[0], ws
         _lib.check(_lib.load().mq_knn_search_screened_f32(
             self._packed.data_ptr() if self._packed is not None else None, self._sqnorm.data_ptr(), self._rowmajor.data_ptr(),
-            self._bf16.data_ptr(), self._xmax2.data_ptr(), self.ntotal, self.d, q.data_ptr(), q.shape[0], k, self.metric_type,
+            self._bf16.data_ptr(), self._xmax2.data_ptr(), self.ntotal, self.d, q.data_ptr(), q.shape[0], k, self._screen_metric,
             self._search_flags() | phase, self.id_offset, out[0].data_ptr(), out[1].data_ptr(), ws.data_ptr(), ws.numel(),
             stream.cuda_stream, None, None), "mq_knn_search_screened_f32")
 
@@ -539,7 +574,7 @@ class MI355XFlatIndex(BaseIndex):
         tile, queries in registers: csrc/knn_small.inc) or "none" (exact rounds / FAISS's small-batch L2 form / exact index)."""
         if not self.screen or not self.ntotal:
             return "none"
-        kind = int(_lib.load().mq_knn_screen_scan_kind(self.ntotal, self.d, int(nq), int(k), self.metric_type))
+        kind = int(_lib.load().mq_knn_screen_scan_kind(self.ntotal, self.d, int(nq), int(k), self._screen_metric))
         if kind < 0:
             raise ValueError(f"mq_knn_screen_scan_kind: invalid arguments (status {kind})")
         return ("none", "tile", "stream")[kind]
