@@ -314,8 +314,9 @@ class MI355XFlatIndex(BaseIndex):
         the rows' squared norm (image features: non-negative, far from centred -- the reference's 2048-d ``imagenet-RN50`` and
         1024-d ``clip-RN50`` columns) makes the margin follow ||q|| while the scores spread like ||q - c|| ||x - c||; the
         centred-query screen removes that at the price of two more bf16 columns.  It is chosen when those columns are free
-        (d % 64 in 1 ... 62) or the index is wider than the streaming kernel's 768 columns anyway; never for d = 767 / 768, where
-        a 13th K block would cost the one-query-tile search its streaming kernel.  MQ_KNN_CENTER_QUERIES=0 / 1 overrides."""
+        (d % 64 in 1 ... 62) or the index is wider than the streaming kernel's 768 columns anyway -- and, where they cost a K block
+        (d = 64 ... 704, multiples of 64), when the centre carries three quarters of the squared norm; never for d = 767 / 768,
+        where a 13th K block would cost the one-query-tile search its streaming kernel.  MQ_KNN_CENTER_QUERIES=0 / 1 overrides."""
         import torch
         if self._torch_device is None:
             self._torch_device = _resolve_device(self.device)
@@ -330,7 +331,9 @@ class MI355XFlatIndex(BaseIndex):
             share = float(center.pow(2).sum()) / x2 if x2 > 0 else 0.0
             dp_plain, dp_cols = (int(d) + 63) // 64, (int(d) + 2 + 63) // 64
             free = dp_cols == dp_plain
-            want = share >= 0.25 and (free or int(d) > 768)
+            # free columns or a width the tile kernel serves anyway: a quarter of the squared norms; otherwise (a K block more:
+            # +8 ... 25 % of the scan at d = 64 ... 704) only when the common component dominates (3/4: shared : noise >= 1.7)
+            want = share >= (0.25 if (free or int(d) > 768) else 0.75)
             env = os.environ.get("MQ_KNN_CENTER_QUERIES")
             if env is not None:
                 want = env != "0"
