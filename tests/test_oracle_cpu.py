@@ -28,6 +28,12 @@ def _cases(g):
 
 @pytest.mark.parametrize("name", ["random", "small_nq", "lattice", "ties", "lattice_small_nq", "ties_small_nq"])
 def test_oracle_reproduces_golden(name):
+    """SELF-MINTED goldens: tests/golden/knn_*.npz were produced by the REFERENCE's KnowledgeBase.search_batch run in the
+    build container over tools/ref_import.py's stand-in for `faiss` -- and that stand-in computes with this very oracle (scores, tie
+    rule, the FAISS-form "L2norm,").  What the files pin is therefore the reference's PLUMBING (list -> ndarray, host-side L2norm, the
+    call into the index, None handling) and that the oracle has not drifted since they were minted; the arithmetic is pinned against
+    independent float64 / torch.mm brute force on the order-independent files below, and against a real FAISS only where `import faiss`
+    works (tests/test_faiss_parity_cpu.py, tools/compare_with_faiss.py: skipped in this image)."""
     g = _load(name)
     X, Q = g["X"].astype(np.float32), g["Q"].astype(np.float32)
     n = 0

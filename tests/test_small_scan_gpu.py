@@ -172,3 +172,24 @@ def test_consecutive_searches_reuse_the_workspace():
         D, I = idx.search_batch(Q, 100)
         Do, Io = ok.knn(X, Q, 100)
         assert np.array_equal(I, Io) and np.array_equal(D, Do)
+
+
+@pytest.mark.parametrize("d,shift", [(200, 9.0), (512, 20.0), (700, 12.0)])
+def test_centred_queries_through_the_streaming_kernel(d, shift):
+    """MQ_METRIC_IP_CENTRED (the index centres its queries too: a large shared component) on shards the streaming kernel serves:
+    the two row-term columns ride through the MFMAs like any other column -- 4, 9 (one K block more than d = 512 alone) and 11 K
+    blocks -- and the result is the tile kernel's, the exact scan's and the oracle's."""
+    from oracle import knn as ok
+    from viquae_amd.index import METRIC_IP_CENTRED
+    g = torch.Generator(device="cuda").manual_seed(d)
+    mu = torch.randn((1, d), generator=g, device="cuda")
+    mu = shift * mu / mu.norm()
+    X = (mu + 0.25 * torch.randn((70000, d), generator=g, device="cuda")).cpu().numpy()
+    Q = (mu + 0.25 * torch.randn((256, d), generator=g, device="cuda")).cpu().numpy()
+    idx = _index(X, 0)
+    assert idx._screen_metric == METRIC_IP_CENTRED
+    (D1, I1), (D0, I0), stats = _both_scans(idx, Q, 100)
+    assert np.array_equal(I1, I0) and np.array_equal(D1, D0)
+    Do, Io = ok.knn(X, Q, 100)
+    assert np.array_equal(I1, Io) and np.array_equal(D1, Do)
+    assert stats[0] == 0

@@ -71,7 +71,9 @@ class _FlatStandIn:
 
 
 class _PreTransformStandIn:
-    """faiss.IndexPreTransform(NormalizationTransform(d, 2.0), IndexFlat) stand-in ("L2norm,Flat")."""
+    """faiss.IndexPreTransform(NormalizationTransform(d, 2.0), IndexFlat) stand-in ("L2norm,Flat").  It normalises with
+    oracle.knn.l2norm_rows(form="faiss") -- the function the goldens are later compared with: files minted through this class are
+    SELF-MINTED for the transform's arithmetic (they pin the reference's plumbing, not FAISS's last bit; tests/test_oracle_cpu.py)."""
 
     def __init__(self, d, metric):
         self.index = _FlatStandIn(d, metric)

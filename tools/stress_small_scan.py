@@ -19,7 +19,7 @@ def case(seed):
     d = pick([3, 32, 64, 100, 200, 256, 320, 512, 700, 766, 768])
     nq = pick([1, 7, 19, 20, 21, 63, 64, 65, 100, 200, 255, 256])
     k = pick([1, 10, 100, 128])
-    regime = pick(["normal", "normal", "clustered", "dups", "scaled", "lowrank", "sorted", "l2norm_numpy", "l2norm_faiss"])
+    regime = pick(["normal", "normal", "clustered", "dups", "scaled", "lowrank", "sorted", "l2norm_numpy", "l2norm_faiss", "shared", "shared"])
     metric = pick([0, 0, 1])
     tie = pick(["id_asc", "id_asc", "id_desc"])
     X = torch.randn((n, d), generator=g, device="cuda")
@@ -44,6 +44,11 @@ def case(seed):
         X = X[torch.argsort(X @ Q[0])]
     elif regime.startswith("l2norm"):
         factory, form = "L2norm,Flat", regime.split("_")[1]
+    elif regime == "shared":  # a common component 0.5 ... 6 x the isotropic part: the centred-query screen where the index picks it
+        ratio = float(pick([0.5, 1.0, 2.0, 4.0, 6.0]))
+        mu = torch.randn((1, d), generator=g, device="cuda")
+        mu = ratio * mu / mu.norm() * d ** 0.5
+        X, Q = X + mu, Q + mu
     return X, Q, k, regime, factory, form, metric, tie
 
 
