@@ -206,6 +206,90 @@ def test_runs_kept_as_arrays_equal_the_reference_loop(mapping, many2one):
         assert np.allclose(list(got[q].values()), list(want[q].values()), rtol=0, atol=1e-9), q
 
 
+@pytest.mark.parametrize("many2one", [None, "max"])
+def test_block_fan_out_through_a_disjoint_mapping_equals_the_reference_loop(many2one, tmp_path):
+    """Round 5: the article -> passage fan-out of the fusion configs' image indexes (index_mapping_path, many2one) for a WHOLE
+    block of hits at once when no run entry can be written twice (a disjoint mapping, distinct hits per query): same dicts, same
+    order, same float32 penalties, same cut behind the hit that fills the run -- incl. articles without passages, a cut that
+    falls on such an article, runs that never fill, and k larger than what one article brings.  A repeated hit or a passage shared
+    by two articles takes the per-query path; so does a question id seen twice.  (And the CSR form of the mapping is built once
+    per KB: round 4 rebuilt it for every query -- 0.2 s per question at 200 k articles.)"""
+    import datasets
+    from datasets.search import BaseIndex, BatchedSearchResults
+    from viquae_amd.ir import searcher as S
+    from viquae_amd.ir.runs import ArrayRun
+    from viquae_amd.ir.search import Index, KnowledgeBase, register_index
+    rng = np.random.default_rng(7)
+    n_art = 400
+    lens = rng.integers(0, 5, n_art)                      # 0 ... 4 passages per article
+    lens[:3] = 0
+    off = np.concatenate([[0], np.cumsum(lens)])
+    passages = rng.permutation(off[-1] + 50)[:off[-1]]    # disjoint, in no particular order
+    mapping = {int(a): [int(x) for x in passages[off[a]:off[a + 1]]] for a in range(n_art)}
+
+    class Canned(BaseIndex):
+        calls = []
+
+        def search_batch(self, queries, k=10, **kw):
+            n = len(queries)
+            I = np.argsort(rng.random((n, n_art)), axis=1)[:, :k]
+            rest = [a for a in I[0].tolist() if a > 2]     # a query that starts with the three articles without passages
+            I[0] = np.array(([0, 1, 2] + rest + [3 + j for j in range(k)])[:k])   # (distinct; padding only when k > len(rest) + 3)
+            if len(set(I[0].tolist())) < k:
+                I[0] = np.arange(k)
+            D = -np.sort(-rng.standard_normal((n, k)).astype(np.float32), axis=1)
+            self.calls.append((D, I))
+            return BatchedSearchResults(D, I)
+
+    def searcher(k):
+        kb = KnowledgeBase(dataset=datasets.Dataset.from_dict({"vec": [[0.0]] * n_art}))
+        idx = Canned()
+        idx.calls = []
+        register_index(kb.dataset, "img", idx)
+        kb.indexes["img"] = Index(key="q")
+        kb.index_mapping, kb.many2one = mapping, many2one
+        (tmp_path / "qrels.json").write_text("{}")
+        with pytest.warns(UserWarning):
+            return S.Searcher(kb_kwargs={"kb": {}}, k=k, kbs={"kb": kb}, qrels=str(tmp_path / "qrels.json")), idx, kb
+
+    built = []
+    plain_init = S._Mapping.__init__
+    S._Mapping.__init__ = lambda self, m: (built.append(1), plain_init(self, m))[1]
+    try:
+        for k in (1, 7, 40, 300):                         # 300: no run ever fills (40 hits x <= 4 passages)
+            s, idx, kb = searcher(k)
+            batches = [[f"q{b}_{i}" for i in range(n)] for b, n in enumerate((5, 3, 9))]
+            for ids in batches:
+                s({"id": ids, "q": [np.zeros(1, np.float32)] * len(ids)})
+            want = _reference_loop(k, mapping, many2one, [(ids, D, I) for ids, (D, I) in zip(batches, idx.calls)])
+            got = s.runs["img"]
+            assert isinstance(got, ArrayRun) and got.lazy_questions() == 17          # every block went through as a block
+            assert list(got) == list(want)
+            for q in want:
+                assert list(got[q]) == list(want[q]), (k, q)
+                assert list(got[q].values()) == list(want[q].values()), (k, q)        # float32 penalties, bit for bit
+        assert len(built) == 4                                                       # one CSR per searcher's KB, not one per query
+        # a repeated article among a query's hits: the dict semantics matter again -> the per-query path, same answer
+        s, idx, kb = searcher(7)
+        plain = idx.search_batch
+
+        def with_repeat(queries, k=10, **kw):
+            r = plain(queries, k=k)
+            r.total_indices[1, 4] = r.total_indices[1, 2]
+            return r
+        idx.search_batch = with_repeat
+        s({"id": ["a", "b", "c"], "q": [np.zeros(1, np.float32)] * 3})
+        want = _reference_loop(7, mapping, many2one, [(["a", "b", "c"], *idx.calls[-1])])
+        got = s.runs["img"]
+        assert got.lazy_questions() == 0 and got == want and [list(got[q]) for q in want] == [list(want[q]) for q in want]
+        # a passage shared by two articles: never the block path
+        shared = dict(mapping)
+        shared[399] = list(mapping[399]) + [int(passages[0])]
+        assert not S._Mapping(shared).disjoint and S._Mapping(mapping).disjoint
+    finally:
+        S._Mapping.__init__ = plain_init
+
+
 @pytest.mark.parametrize("window", [0, 16, 20, 64, 4096])
 def test_search_ahead_windows_serve_every_batch_the_arrays_of_its_own_search(tmp_path, monkeypatch, window):
     """ArrowQueryColumns.search: one search per WINDOW of consecutive rows instead of one per `Dataset.map` batch

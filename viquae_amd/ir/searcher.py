@@ -71,6 +71,13 @@ class _Mapping:
         lens = np.array([len(mapping[k]) for k in keys], dtype=np.int64)
         self.offsets = np.concatenate([[0], np.cumsum(lens)])
         self.values = np.concatenate([np.asarray(mapping[k], dtype=np.int64) for k in keys]) if keys else np.zeros(0, np.int64)
+        # for whole blocks of hits: the keys as a sorted array (when they are integers) and whether no passage belongs to two
+        # articles -- then distinct hits can never write one run entry twice, and a block needs no per-query dict semantics
+        try:
+            self.keys = np.asarray(keys, dtype=np.int64) if all(isinstance(k, (int, np.integer)) for k in keys) else None
+        except (TypeError, ValueError, OverflowError):
+            self.keys = None
+        self.disjoint = bool(self.values.size == np.unique(self.values).size) and bool((self.values >= 0).all())
 
     def expand(self, indices, scores, many2one):
         """(passage ids, scores) of one query's hits, in hit order."""
@@ -86,6 +93,45 @@ class _Mapping:
             # under NumPy 1.x): the penalty is cast to float32 first
             sc = sc - (1e-8 * pos).astype(np.float32)
         return ids, sc, np.cumsum(counts)
+
+    def expand_block(self, indices, scores, k, many2one):
+        """A whole block of hits at once: ``indices`` / ``scores`` [nq, kk] -> (passage ids [nq, W] padded with -1, scores
+        [nq, W] float32) after the reference's loop (meerqat/ir/search.py:419-440): every hit's passages in order, the 1e-8
+        penalty per rank inside the article (``many2one`` None) or the hit's score (``"max"``), cut behind the first HIT at
+        which the run holds k entries.  Only for blocks where no run entry can be written twice -- a disjoint mapping and
+        distinct hits per query, which the caller checks -- so that the dict semantics reduce to a running count.  Returns None
+        when a hit is not a key of the mapping (the caller's per-query path raises the reference's KeyError)."""
+        nq, kk = indices.shape
+        flat = indices.ravel()
+        rows = np.searchsorted(self.keys, flat)
+        rows[rows >= self.keys.size] = 0
+        if self.keys.size == 0 or not bool((self.keys[rows] == flat).all()):
+            return None
+        counts = (self.offsets[rows + 1] - self.offsets[rows]).reshape(nq, kk)
+        cum = np.cumsum(counts, axis=1)
+        # the loop stops behind the first hit with cum >= k (checked after EVERY hit, also one that maps to no passage)
+        reached = cum >= k
+        last = np.where(reached.any(axis=1), reached.argmax(axis=1), kk - 1)
+        keep_hit = np.arange(kk)[None, :] <= last[:, None]
+        counts = np.where(keep_hit, counts, 0)
+        per_q = counts.sum(axis=1)
+        W = int(per_q.max()) if nq else 0
+        ids = np.full((nq, max(W, 1)), -1, dtype=np.int64)
+        sc = np.zeros((nq, max(W, 1)), dtype=np.float32)
+        c = counts.ravel()
+        total = int(c.sum())
+        if total:
+            first = np.cumsum(c) - c                                  # position of each hit's first passage in the flat expansion
+            pos = np.arange(total) - np.repeat(first, c)              # rank of a passage inside its article
+            src = np.repeat(self.offsets[rows], c) + pos
+            qrow = np.repeat(np.repeat(np.arange(nq), kk), c)
+            col = np.arange(total) - np.repeat(np.cumsum(per_q) - per_q, per_q)
+            ids[qrow, col] = self.values[src]
+            val = np.repeat(scores.ravel().astype(np.float32), c)
+            if many2one is None:
+                val = val - (1e-8 * pos).astype(np.float32)
+            sc[qrow, col] = val
+        return ids, sc
 
 
 class Searcher:
@@ -182,10 +228,27 @@ class Searcher:
                 w[3].append(scores[:, :cut])
                 continue
             file_waiting(index_name)
+            if (kb.index_mapping is not None and kb.many2one in (None, "max") and isinstance(run, ArrayRun) and nq and kk
+                    and len(set(q_ids)) == nq and not any(q in run for q in q_ids)):
+                # article -> passage fan-out of a whole block (the image indexes of the fusion configs): when the mapping is disjoint
+                # and a query's hits are distinct, no run entry is written twice and the reference's loop is a running count
+                csr = self._csr_of(kb)
+                srt = np.sort(indices, axis=1)
+                if csr.keys is not None and csr.disjoint and bool((srt[:, 1:] != srt[:, :-1]).all()):
+                    block = csr.expand_block(indices, scores, self.k, kb.many2one)
+                    if block is not None:
+                        run.add_block(q_ids, block[0], block[1])
+                        continue
             for q_id, sc, idx in zip(q_ids, scores.tolist(), indices.tolist()):
                 self._fill_run(kb, run.setdefault(q_id, {}), sc, idx)
         for index_name in list(waiting):
             file_waiting(index_name)
+
+    def _csr_of(self, kb):
+        csr = self._csr.get(id(kb))
+        if csr is None:  # (dict.setdefault would build the CSR arrays again for EVERY query: its argument is evaluated first)
+            csr = self._csr[id(kb)] = _Mapping(kb.index_mapping)
+        return csr
 
     def _fill_run(self, kb, run_q, scores, indices):
         """One query's hits -> run dict, cut at k entries (reference: search.py:413-440)."""
@@ -199,7 +262,7 @@ class Searcher:
                 if len(run_q) >= self.k:
                     break
             return
-        csr = self._csr.setdefault(id(kb), _Mapping(kb.index_mapping))
+        csr = self._csr_of(kb)
         ids, sc, ends = csr.expand(indices, scores, kb.many2one)
         if kb.many2one not in (None, "max"):
             raise ValueError(f"Invalid value for many2one: '{kb.many2one}'. Choose from {{None, 'max'}}")
