@@ -71,6 +71,14 @@ def test_small_batch_l2_form_and_queries_only():
         torch.cuda.synchronize()
         assert np.array_equal(t.cpu().numpy(), ok.l2norm_rows(X, form=form), equal_nan=True)
     assert lib.mq_l2norm_rows_form_f32(t.data_ptr(), 1, 1, 3, None) < 0  # unknown form
+    # both kernels behind the entry (8 rows per workgroup up to 4096 rows -- a search's queries --, 64 beyond), ragged widths
+    for n, d in ((4096, 2048), (4097, 2048), (5000, 100), (256, 1000), (3, 1)):
+        Y = _rows(max(n, 12), d, n + d)[:n] if d >= 2 else np.random.default_rng(1).standard_normal((n, d)).astype(np.float32)
+        for form in ("numpy", "faiss"):
+            t = torch.from_numpy(Y.copy()).cuda()
+            _lib.check(lib.mq_l2norm_rows_form_f32(t.data_ptr(), n, d, L2NORM_FORMS[form], torch.cuda.current_stream().cuda_stream), "l2norm")
+            torch.cuda.synchronize()
+            assert np.array_equal(t.cpu().numpy(), ok.l2norm_rows(Y, form=form), equal_nan=True), (n, d, form)
 
 
 def test_knowledge_base_picks_the_form_from_the_device_key():

@@ -103,18 +103,20 @@ def one_index(name, column, d, factory, rows, nq, k, reps, shared, device):
     return out
 
 
-def main(rows=1_500_000, nq=256, k=100, reps=20, shared=1.0):
+def main(rows=1_500_000, nq=256, k=100, reps=20, shared=1.0, only=None):
     device = torch.device("cuda", torch.cuda.current_device())
     out = {"workload": f"the four dense indexes of experiments/ir/viquae/dpr+arcface+clip+imagenet/config_test.json, {rows} synthetic rows each "
                        f"(shared component : noise = {shared} : 1), {nq}-question batches (map_kwargs.batch_size), exact IP top-{k}, one C-ABI call per batch",
            "indexes": []}
     for name, column, d, factory in INDEXES:
+        if only and name != only:
+            continue
         try:
             out["indexes"].append(one_index(name, column, d, factory, rows, nq, k, reps, shared, device))
         except Exception as e:  # one index failing must not lose the others
             out["indexes"].append({"index": name, "d": d, "error": repr(e)})
     ms = [r["call_ms"] for r in out["indexes"] if "call_ms" in r]
-    if len(ms) == len(INDEXES):
+    if len(ms) == len(INDEXES) and not only:
         out["all_four_ms_per_batch"] = round(sum(ms), 4)
         out["questions_per_s_all_four"] = round(nq / sum(ms) * 1e3, 1)
     return out
@@ -126,5 +128,6 @@ if __name__ == "__main__":
     ap.add_argument("--rows", type=int, default=1_500_000)
     ap.add_argument("--shared", type=float, default=1.0)
     ap.add_argument("--nq", type=int, default=256)
+    ap.add_argument("--only", default=None, help="one index name (profiling)")
     a = ap.parse_args()
-    print(json.dumps(main(rows=a.rows, nq=a.nq, shared=a.shared)))
+    print(json.dumps(main(rows=a.rows, nq=a.nq, shared=a.shared, only=a.only)))

@@ -301,6 +301,44 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ ro
     }
 }
 
+// The same normalisation for FEW rows (a search's queries: 256 per call in the reference's batches): l2norm_rows_kernel gives 64
+// rows to a workgroup, so 256 queries of 2048 columns were four workgroups walking 32 dependent load -> barrier -> chain steps
+// each -- 229 us of a 2.25-ms search over the 2048-d "L2norm,Flat" index (rocprofv3, round 5).  Here a workgroup takes 8 rows and
+// 256 columns per step (one 1-KiB run per row); the sum of squares stays the k-ordered fp32 fma chain of one thread per row,
+// the bits are the same.
+__global__ __launch_bounds__(256) void l2norm_rows_small_kernel(float* __restrict__ rows, int64_t n, int d, int form) {
+    __shared__ float tile[8][257];
+    __shared__ float nrm[8];
+    const int t = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 8;
+    float acc = 0.f;
+    for (int kc = 0; kc < d; kc += 256) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tile[r][t] = (row0 + r < n && kc + t < d) ? rows[(row0 + r) * (int64_t)d + kc + t] : 0.f;
+        __syncthreads();
+        if (t < 8) {
+            const int kn = d - kc < 256 ? d - kc : 256;
+            for (int k = 0; k < kn; ++k) acc = fmaf(tile[t][k], tile[t][k], acc);
+        }
+        __syncthreads();
+    }
+    if (t < 8) nrm[t] = l2norm_scale(acc, form);
+    __syncthreads();
+    for (int r = 0; r < 8; ++r) {
+        if (row0 + r >= n) break;
+        float* p = rows + (row0 + r) * (int64_t)d;
+        const float sc = nrm[r];
+        for (int k = t; k < d; k += 256) p[k] = l2norm_apply(p[k], sc, form);
+    }
+}
+constexpr int64_t L2NORM_SMALL_ROWS = 4096;  // up to here the 8-row kernel (>= 512 workgroups beyond)
+inline void launch_l2norm_rows(float* rows, int64_t n, int d, int form, hipStream_t st) {
+    if (n <= L2NORM_SMALL_ROWS)
+        hipLaunchKernelGGL(l2norm_rows_small_kernel, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, rows, n, d, form);
+    else
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, rows, n, d, form);
+}
+
 // ------------------------------------------------------------------------------------------------
 // the scan kernel
 // ------------------------------------------------------------------------------------------------
@@ -1168,8 +1206,7 @@ int mq_unpack_rows_f32(const float* packed_dev, int64_t capacity_rows, int d, in
 int mq_l2norm_rows_form_f32(float* rows_dev, int64_t n, int d, int form, void* stream) {
     if (n == 0) return MQ_OK;
     if (!rows_dev || n < 0 || d <= 0 || (form != MQ_L2NORM_NUMPY && form != MQ_L2NORM_FAISS)) return MQ_EINVAL;
-    const unsigned grid = (unsigned)((n + 63) / 64);
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rows_dev, n, d, form);
+    launch_l2norm_rows(rows_dev, n, d, form, (hipStream_t)stream);
     MQ_HIP(hipGetLastError());
     return MQ_OK;
 }
@@ -1331,7 +1368,7 @@ static int knn_search_l2_direct(const float* packed_dev, const float* rowmajor_d
     const float* q_rm = queries_dev;
     if (query_l2norm_form(flags)) {
         MQ_HIP(hipMemcpyAsync(qtmp, queries_dev, (size_t)nq * d * 4, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, qtmp, (int64_t)nq, d, query_l2norm_form(flags));
+        launch_l2norm_rows(qtmp, (int64_t)nq, d, query_l2norm_form(flags), st);
         MQ_HIP(hipGetLastError());
         q_rm = qtmp;
     }
@@ -1574,7 +1611,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     if (l2norm_queries) {
         if (do_front) {
             MQ_HIP(hipMemcpyAsync(qtmp, queries_dev, (size_t)nq * d * 4, hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, qtmp, (int64_t)nq, d, l2norm_queries);
+            launch_l2norm_rows(qtmp, (int64_t)nq, d, l2norm_queries, st);
             MQ_HIP(hipGetLastError());
         }
         q_rm = qtmp;
