@@ -433,7 +433,7 @@ def main():
         if (which or mode) == "screened":
             _lib.check(lib.mq_knn_search_screened_f32(
                 local._packed.data_ptr() if local._packed is not None else None, local._sqnorm.data_ptr(), local._rowmajor.data_ptr(), local._bf16.data_ptr(),
-                local._xmax2.data_ptr(), rows, DIM, q.data_ptr(), q.shape[0], k, 0, 0, local.id_offset, Dq.data_ptr(), Iq.data_ptr(),
+                local._xmax2.data_ptr(), rows, DIM, q.data_ptr(), q.shape[0], k, local._screen_metric, 0, local.id_offset, Dq.data_ptr(), Iq.data_ptr(),
                 ws.data_ptr(), ws_bytes, stream.cuda_stream, e0, e1), "mq_knn_search_screened_f32")
         else:
             _lib.check(lib.mq_knn_search_f32_ev(local._packed.data_ptr(), local._sqnorm.data_ptr(), rows, DIM, q.data_ptr(),

@@ -32,7 +32,7 @@ for d in [int(x) for x in sys.argv[1:]] or [768, 512]:
 
         def run(D, I, e0=None, e1=None):
             _lib.check(lib.mq_knn_search_screened_f32(None, idx._sqnorm.data_ptr(), idx._rowmajor.data_ptr(), idx._bf16.data_ptr(),
-                                                      idx._xmax2.data_ptr(), rows, d, Q.data_ptr(), nq, k, 0, 0, 0, D.data_ptr(), I.data_ptr(),
+                                                      idx._xmax2.data_ptr(), rows, d, Q.data_ptr(), nq, k, idx._screen_metric, 0, 0, D.data_ptr(), I.data_ptr(),
                                                       ws.data_ptr(), wsb, stream.cuda_stream, e0.cuda_event if e0 else None,
                                                       e1.cuda_event if e1 else None), "search")
 
