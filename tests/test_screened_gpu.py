@@ -331,3 +331,8 @@ def test_centred_queries_policy():
     assert metric_of(768, 20.0) == 0 and metric_of(767, 20.0) == 0                            # the streaming kernel's last K block
     assert metric_of(512, 20.0) == METRIC_IP_CENTRED and metric_of(512, 5.0) == 0             # a K block more: only when it dominates
     assert metric_of(200, 9.0, metric=1) == 1                                              # the L2 screen keeps its own row term
+    X, _ = _anisotropic(3000, 200, 4, 1)
+    few = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
+    few.add(X[:10])                                                                        # ten rows are not evidence of a common component
+    few.add(X[10:])
+    assert few._screen_metric == 0

@@ -323,7 +323,8 @@ class MI355XFlatIndex(BaseIndex):
         dev = self._upload(first_rows)
         center = self._choose_center(dev)
         self._screen_metric = self.metric_type
-        if center is not None and self.metric_type == METRIC_INNER_PRODUCT:
+        # (a first add of a handful of rows says nothing about a common component: their mean IS most of them)
+        if center is not None and self.metric_type == METRIC_INNER_PRODUCT and dev.shape[0] >= 256:
             x = dev.to(torch.float32)
             if self.do_l2norm:
                 x = torch.nn.functional.normalize(x, dim=1)
