@@ -336,3 +336,43 @@ def test_centred_queries_policy():
     few.add(X[:10])                                                                        # ten rows are not evidence of a common component
     few.add(X[10:])
     assert few._screen_metric == 0
+
+
+def test_centred_queries_on_every_index_path(monkeypatch, tmp_path):
+    """MQ_METRIC_IP_CENTRED through the paths an index has: a kept panel with ragged appends (the open-panel re-pack), row shards on
+    one device (every shard decides for itself), k beyond the screen (row ranges), several query chunks with the post-scan half
+    on a second stream, save -> load.  Always the exact scan's answer."""
+    from viquae_amd.index import METRIC_IP_CENTRED, MI355XFlatIndex
+    from viquae_amd.sharded import LocalShardsFlatIndex
+    X, Q = _anisotropic(41000, 200, 4096 + 300, 17, shift=12.0, noise=0.25)
+    ex = MI355XFlatIndex(string_factory="L2norm,Flat", metric_type=0, screen=False, l2norm_form="faiss")
+    ex.add(X)
+    De, Ie = ex.search_device(Q, 100)
+    # kept panel, ragged appends
+    a = MI355XFlatIndex(string_factory="L2norm,Flat", metric_type=0, screen=True, keep_panel=True, l2norm_form="faiss")
+    for lo, hi in ((0, 1000), (1000, 1037), (1037, 30001), (30001, 41000)):
+        a.add(X[lo:hi])
+    assert a._screen_metric == METRIC_IP_CENTRED
+    D, I = a.search_device(Q, 100)
+    assert torch.equal(D, De) and torch.equal(I, Ie)
+    # chunks pipelined over two streams
+    monkeypatch.setenv("MQ_KNN_TAIL_OVERLAP", "1")
+    D, I = a.search_device(Q, 100)
+    assert torch.equal(D, De) and torch.equal(I, Ie)
+    monkeypatch.delenv("MQ_KNN_TAIL_OVERLAP")
+    # k beyond the screen: row ranges, merged and proved
+    D3, I3 = a.search_device(Q[:300], 300)
+    De3, Ie3 = ex.search_device(Q[:300], 300)
+    assert torch.equal(D3, De3) and torch.equal(I3, Ie3)
+    # row shards on one device
+    sh = LocalShardsFlatIndex([0] * 4, string_factory="L2norm,Flat", metric_type=0, allow_repeated_devices=True, l2norm_form="faiss")
+    sh.add_vectors(X.cpu().numpy())
+    assert all(s._screen_metric == METRIC_IP_CENTRED for s in sh.shards)
+    Ds, Is = sh.search_batch(Q[:500].cpu().numpy(), 100)
+    assert np.array_equal(Is, Ie[:500].cpu().numpy()) and np.array_equal(Ds, De[:500].cpu().numpy())
+    # save -> load rebuilds the screen (the file holds the fp32 rows)
+    a.save(tmp_path / "kb.index")
+    b = MI355XFlatIndex.load(tmp_path / "kb.index")
+    assert b._screen_metric == METRIC_IP_CENTRED
+    Db, Ib = b.search_device(Q[:256], 100)
+    assert torch.equal(Db, De[:256]) and torch.equal(Ib, Ie[:256])
