@@ -66,3 +66,27 @@ def test_search_path_switches_are_set_through_the_abi(hip_lib):
     if before:
         assert hip_lib.mq_knn_screen_scan_kind(1_500_000, 768, 4096, 300, 0) == 1
     assert hip_lib.mq_knn_set_option(99, 1) == -1 and hip_lib.mq_knn_set_option(0, -5) == -1 and hip_lib.mq_knn_get_option(-1) == -1
+
+
+def test_streaming_kernels_do_not_spill():
+    """The streaming scans keep queries in registers and an LDS-DMA ring in flight: a spilled register is a scratch reload inside
+    the loop, whose `s_waitcnt vmcnt(0)` drains the ring every item.  The 12-K-block instances sit at the
+    register limit (two waves per SIMD: 128 + 128; one wave per SIMD: 256 + 256), so the invariant is checked at build time: hipcc's
+    kernel-resource remarks must report no scratch for every instance of both kernels and for the 256 x 256 tile kernel."""
+    import subprocess
+    src = os.path.join(ROOT, "viquae_amd", "csrc", "knn.hip")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
+           "-Wno-unused-result", "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600).stderr
+    cur, seen = None, {}
+    for line in out.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.search(r"remark:\s+ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and cur:
+            seen[cur] = int(m.group(1))
+    watched = {k: v for k, v in seen.items() if "screen_small8_kernel" in k or "screen_small_kernel" in k or "screen_scan_kernel" in k}
+    assert len(watched) >= 25, sorted(watched)          # 12 + 12 streaming instances + the tile kernel
+    assert all(v == 0 for v in watched.values()), {k: v for k, v in watched.items() if v}
