@@ -57,6 +57,67 @@ def test_searcher_matches_reference_golden(case):
     check(build(golden, case, oracle_index), golden["cases"][case])
 
 
+def _reference_answer_preprocess(answer):
+    """meerqat/data/loading.py:152-164, as written there (character loop, re.sub, split / join)."""
+    import re
+    import string
+    exclude = set(string.punctuation)
+    text = "".join(ch for ch in answer.lower() if ch not in exclude)
+    text = re.sub(r"\b(a|an|the)\b", " ", text)
+    return " ".join(text.split())
+
+
+def test_answer_preprocess_and_passage_cache_equal_the_reference_statement():
+    """The relevance judgement's string work (f1, meerqat/ir/search.py:442-457 -> metrics.py:79-124): the translate-based
+    preprocessing gives the reference's strings; judging through the passage cache (one Arrow `take` per request, every passage
+    preprocessed once) gives the reference loop's lists."""
+    import re
+    import string
+    import datasets
+    from viquae_amd.ir.searcher import PassageTexts, answer_preprocess, find_relevant
+    rng = np.random.default_rng(0)
+    alphabet = list(string.ascii_letters + string.digits + string.punctuation + "    \t\n" + "éÉßøŒ«»’“”–—…¿¡ñçüİı́") + [" the ", " a ", " an ", "The", "AN", " a", "the"]
+    texts = ["".join(rng.choice(alphabet, rng.integers(0, 120))) for _ in range(3000)] + ["", "the", "a an the", "An  apple, a day!", "THE-END"]
+    for t in texts:
+        assert answer_preprocess(t) == _reference_answer_preprocess(t), repr(t)
+    words = ["paris", "tower", "eiffel", "lyon", "seine", "river", "the", "of", "1889", "gustave"]
+    passages = [" ".join(rng.choice(words, rng.integers(3, 30))).capitalize() + rng.choice([".", "!", "", " (x)"]) for _ in range(500)]
+    kb = datasets.Dataset.from_dict({"passage": passages})
+
+    def reference_loop(retrieved, original, aliases):
+        orig, rel = [], []
+        for i in retrieved:
+            passage = _reference_answer_preprocess(kb[int(i)]["passage"])
+            if re.search(rf"\b{_reference_answer_preprocess(original)}\b", passage) is not None:
+                orig.append(int(i))
+                rel.append(int(i))
+                continue
+            for a in aliases:
+                if re.search(rf"\b{_reference_answer_preprocess(a)}\b", passage) is not None:
+                    rel.append(int(i))
+                    break
+        return orig, rel
+
+    cache = PassageTexts(kb, "passage")
+    assert cache._column is not None
+    for trial in range(40):
+        retrieved = [str(i) for i in rng.choice(500, 60, replace=False)]
+        original = str(rng.choice(["Paris", "The Eiffel Tower", "Gustave", "1889!", "nowhere"]))
+        aliases = [str(a) for a in rng.choice(["Lyon", "the Seine", "river of", "", "tower."], rng.integers(0, 4), replace=False)]
+        want = reference_loop(retrieved, original, aliases)
+        assert find_relevant(retrieved, original, aliases, kb) == want
+        assert find_relevant(retrieved, original, aliases, kb, passages=cache) == want
+    assert 0 < len(cache.texts) <= 500
+    assert find_relevant([], "x", [], kb, passages=cache) == ([], [])
+    small = PassageTexts(kb, "passage", capacity=50)             # the cache empties itself instead of growing without bound
+    small.get_many(list(range(40)))
+    small.get_many(list(range(40, 80)))
+    assert len(small.texts) == 40 and small.get_many([41, 3]) == [answer_preprocess(passages[41]), answer_preprocess(passages[3])]
+    shuffled = kb.shuffle(seed=0)                                # an indices mapping: rows through the dataset, not the raw column
+    assert PassageTexts(shuffled, "passage")._column is None
+    assert PassageTexts(shuffled, "passage").get_many([0, 1]) == [answer_preprocess(shuffled[0]["passage"]), answer_preprocess(shuffled[1]["passage"])]
+
+
 def test_find_relevant_whole_word_matching():
     from viquae_amd.ir.searcher import find_relevant
     kb = [{"passage": "The Eiffel Tower is in Paris, France."}, {"passage": "Parisian cafes"}, {"passage": "A tower."}]

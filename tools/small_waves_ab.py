@@ -57,7 +57,8 @@ for d in [int(x) for x in sys.argv[1:]] or [768, 512]:
             idx._last_call_nq = nq
             st = idx.screen_stats(nq, k)
             res[name] = {"scan_ms": round(scan, 4), "call_ms": round(call, 4), "hbm_frac": round(rows * ((d + 63) // 64 * 64) * 2 / (scan * 1e-3) / 8e12, 4),
-                         "kind": int(lib.mq_knn_screen_scan_kind(rows, d, nq, k, 0)), "recomputed": st[0], "cand_per_q": round(st[1] / nq, 1)}
+                         "kind": int(lib.mq_knn_screen_scan_kind(rows, d, nq, k, 0)), "recomputed": st[0], "cand_per_q": round(st[1] / nq, 1),
+                         "pool_keys_per_q": round(st[4] / nq, 1)}
             res[name + "_DI"] = (D, I)
         for name in ("stream4", "stream8"):
             res[name]["equal_to_tile"] = bool(torch.equal(res[name + "_DI"][0], res["tile_DI"][0]) and torch.equal(res[name + "_DI"][1], res["tile_DI"][1]))

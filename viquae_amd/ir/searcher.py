@@ -34,31 +34,71 @@ from .runs import ArrayRun, dump_run
 from .search import KnowledgeBase
 
 
+_PUNCTUATION = str.maketrans("", "", string.punctuation)
+_ARTICLES = re.compile(r"\b(a|an|the)\b")
+
+
 def answer_preprocess(answer):
-    """Lower-case, drop punctuation, articles and extra whitespace (meerqat/data/loading.py:152-164)."""
-    answer = "".join(ch for ch in answer.lower() if ch not in set(string.punctuation))
-    answer = re.sub(r"\b(a|an|the)\b", " ", answer)
-    return " ".join(answer.split())
+    """Lower-case, drop punctuation, articles and extra whitespace (meerqat/data/loading.py:152-164, in its order: lower ->
+    punctuation -> articles -> whitespace).  Same string as the reference's character loop, through ``str.translate`` and a
+    compiled pattern: ~15 x faster on a 100-word passage, and the relevance judgement calls it once per retrieved passage."""
+    return " ".join(_ARTICLES.sub(" ", answer.lower().translate(_PUNCTUATION)).split())
 
 
-def find_relevant(retrieved, original_answer, alternative_answers, kb, reference_key="passage", question_type="String"):
-    """Which retrieved passages contain the answer (or one of its aliases) as whole words."""
+class PassageTexts:
+    """The reference KB's passages, preprocessed once each.  ``find_relevant`` (meerqat/ir/metrics.py:79-124) reads
+    ``kb[i][reference_key]`` -- one Arrow row materialised as a Python dict per retrieved passage -- and preprocesses it, 100
+    times per question and index; here the misses of a whole request are fetched with ONE ``take`` on the Arrow column and the
+    preprocessed strings are kept (up to ``capacity`` of them: popular passages come back for many questions)."""
+
+    def __init__(self, kb, reference_key="passage", capacity=1 << 20):
+        self.kb, self.key, self.capacity = kb, reference_key, int(capacity)
+        self.texts = {}
+        self._column = None
+        try:
+            if getattr(kb, "_indices", None) is None and reference_key in kb.column_names:
+                self._column = kb.data.column(reference_key)
+        except Exception:  # not an Arrow-backed datasets.Dataset (tests pass plain lists of dicts)
+            self._column = None
+
+    def get_many(self, ids):
+        texts = self.texts
+        missing = [i for i in ids if i not in texts]
+        if missing:
+            if len(texts) + len(missing) > self.capacity:
+                texts.clear()
+            if self._column is not None:
+                raw = self._column.take(missing).to_pylist()
+            else:
+                raw = [self.kb[i][self.key] for i in missing]
+            for i, t in zip(missing, raw):
+                texts[i] = answer_preprocess(t)
+        return [texts[i] for i in ids]
+
+
+def find_relevant(retrieved, original_answer, alternative_answers, kb, reference_key="passage", question_type="String", passages=None):
+    """Which retrieved passages contain the answer (or one of its aliases) as whole words (meerqat/ir/metrics.py:79-124).
+    ``passages``: a :class:`PassageTexts` over ``kb`` (the searcher keeps one); without it every passage is read and preprocessed
+    here.  A passage is relevant when ANY alias matches, which is all the reference's first-match loop decides."""
     if question_type not in ("String", None):
         raise NotImplementedError("numerical / time question types (InfoSeek) are not judged by this mirror")
     original_relevant, relevant = [], []
+    ids = [int(i) for i in retrieved]
+    if not ids:
+        return original_relevant, relevant
+    # After answer_preprocess an answer holds no ASCII punctuation, hence no regex metacharacter: `\b{answer}\b` is the literal
+    # answer between word boundaries, and `answer in passage` (a C substring search, ~100 x cheaper than the regex on a 100-word
+    # passage) is a necessary condition -- the pattern only runs on the passages that contain the answer at all.
     answer0 = answer_preprocess(original_answer)
-    aliases = [answer_preprocess(a) for a in alternative_answers]
-    for i in retrieved:
-        i = int(i)
-        passage = answer_preprocess(kb[i][reference_key])
-        if re.search(rf"\b{answer0}\b", passage) is not None:
+    first = re.compile(rf"\b{answer0}\b")
+    aliases = [(a, re.compile(rf"\b{a}\b")) for a in dict.fromkeys(answer_preprocess(a) for a in alternative_answers)]
+    texts = passages.get_many(ids) if passages is not None else [answer_preprocess(kb[i][reference_key]) for i in ids]
+    for i, passage in zip(ids, texts):
+        if answer0 in passage and first.search(passage) is not None:
             original_relevant.append(i)
             relevant.append(i)
-            continue
-        for answer in aliases:
-            if re.search(rf"\b{answer}\b", passage) is not None:
-                relevant.append(i)
-                break
+        elif any(a in passage and pat.search(passage) is not None for a, pat in aliases):
+            relevant.append(i)
     return original_relevant, relevant
 
 
@@ -244,6 +284,12 @@ class Searcher:
         for index_name in list(waiting):
             file_waiting(index_name)
 
+    def _passage_texts(self):
+        texts = getattr(self, "_texts", None)
+        if texts is None or texts.kb is not self.reference_kb:
+            texts = self._texts = PassageTexts(self.reference_kb, self.reference_key)
+        return texts
+
     def _csr_of(self, kb):
         csr = self._csr.get(id(kb))
         if csr is None:  # (dict.setdefault would build the CSR arrays again for EVERY query: its argument is evaluated first)
@@ -316,7 +362,8 @@ class Searcher:
                         self.qnonrels.setdefault(q_id, {})
                         retrieved = run_q.keys() - (self.qrels[q_id].keys() | self.qnonrels[q_id].keys())
                         _, relevant = find_relevant(retrieved, gt["original_answer"], gt["answer"], self.reference_kb,
-                                                    reference_key=self.reference_key, question_type=question_type)
+                                                    reference_key=self.reference_key, question_type=question_type,
+                                                    passages=self._passage_texts())
                         self.qrels[q_id].update({str(i): 1 for i in relevant})
                         self.qnonrels[q_id].update({i: 0 for i in retrieved - self.qrels[q_id].keys()})
         return batch
