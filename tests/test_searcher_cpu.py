@@ -118,6 +118,67 @@ def test_answer_preprocess_and_passage_cache_equal_the_reference_statement():
     assert PassageTexts(shuffled, "passage").get_many([0, 1]) == [answer_preprocess(shuffled[0]["passage"]), answer_preprocess(shuffled[1]["passage"])]
 
 
+@pytest.mark.parametrize("mapped", [False, True])
+def test_judged_job_keeps_its_runs_as_arrays(mapped):
+    """Round 5: with a reference KB (every shipped search config) the relevance judgement needs the SET of documents a question
+    retrieved, not its dict -- the runs stay rows of the result arrays, and runs / qrels / qnonrels equal the reference's loop."""
+    import re
+    import datasets
+    from datasets.search import BaseIndex, BatchedSearchResults
+    from viquae_amd.ir.runs import ArrayRun
+    from viquae_amd.ir.search import Index, KnowledgeBase, register_index
+    from viquae_amd.ir.searcher import Searcher
+    rng = np.random.default_rng(5)
+    words = ["paris", "tower", "eiffel", "lyon", "seine", "river", "the", "of", "1889", "gustave"]
+    n_pass = 600
+    passages = [" ".join(rng.choice(words, rng.integers(3, 25))).capitalize() + "." for _ in range(n_pass)]
+    ref = datasets.Dataset.from_dict({"passage": passages})
+    n_art = 150
+    mapping = None
+    if mapped:
+        perm = rng.permutation(n_pass)
+        mapping = {a: [int(x) for x in perm[4 * a:4 * a + int(rng.integers(0, 5))]] for a in range(n_art)}
+
+    class Canned(BaseIndex):
+        calls = []
+
+        def search_batch(self, queries, k=10, **kw):
+            n = len(queries)
+            I = np.argsort(rng.random((n, n_art if mapped else n_pass)), axis=1)[:, :k]
+            D = -np.sort(-rng.standard_normal((n, k)).astype(np.float32), axis=1)
+            self.calls.append((D, I))
+            return BatchedSearchResults(D, I)
+
+    kb = KnowledgeBase(dataset=datasets.Dataset.from_dict({"vec": [[0.0]]}))
+    idx = Canned()
+    idx.calls = []
+    register_index(kb.dataset, "dense", idx)
+    kb.indexes["dense"] = Index(key="q")
+    if mapped:
+        kb.index_mapping, kb.many2one = mapping, None
+    s = Searcher(kb_kwargs={"kb": {}}, k=12, kbs={"kb": kb}, reference_kb=ref)
+    answers = [{"original_answer": "Paris", "answer": ["Paris", "the Seine"]}, {"original_answer": "Gustave Eiffel", "answer": ["Eiffel"]},
+               {"original_answer": "nowhere", "answer": []}]
+    batches = [[f"q{b}_{i}" for i in range(n)] for b, n in enumerate((4, 7))]
+    outs = []
+    for ids in batches:
+        out = [answers[int(rng.integers(0, 3))] for _ in ids]
+        outs.append(out)
+        s({"id": ids, "q": [np.zeros(1, np.float32)] * len(ids), "output": out})
+    got = s.runs["dense"]
+    assert isinstance(got, ArrayRun) and got.lazy_questions() == 11
+    want = _reference_loop(12, mapping, None, [(ids, D, I) for ids, (D, I) in zip(batches, idx.calls)])
+    assert list(got) == list(want) and all(list(got[q].items()) == list(want[q].items()) for q in want)
+    for ids, out in zip(batches, outs):
+        for q, gt in zip(ids, out):
+            rel = set()
+            for doc in want[q]:
+                p = _reference_answer_preprocess(passages[int(doc)])
+                if any(re.search(rf"\b{_reference_answer_preprocess(a)}\b", p) for a in [gt["original_answer"]] + gt["answer"]):
+                    rel.add(doc)
+            assert set(s.qrels[q]) == rel and set(s.qnonrels[q]) == set(want[q]) - rel, q
+
+
 def test_find_relevant_whole_word_matching():
     from viquae_amd.ir.searcher import find_relevant
     kb = [{"passage": "The Eiffel Tower is in Paris, France."}, {"passage": "Parisian cafes"}, {"passage": "A tower."}]

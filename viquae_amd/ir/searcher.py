@@ -235,6 +235,33 @@ class Searcher:
         self._pending = []
         self._runs = value
 
+    def _as_block(self, kb, run, q_ids, scores, indices):
+        """(ids [nq, W] padded with -1, scores [nq, W]) of a result block that can enter ``run`` as rows of arrays -- new, distinct
+        question ids whose hits cannot write one run entry twice -- else None (the per-query loop with the reference's dict
+        semantics then fills the run).  Without an ``index_mapping``: distinct non-negative hits, cut at k; with one: a disjoint
+        mapping and distinct hits (``_Mapping.expand_block``)."""
+        nq, kk = indices.shape
+        if not isinstance(run, ArrayRun) or not nq or not kk or len(set(q_ids)) != nq or any(q in run for q in q_ids):
+            return None
+        if kb.index_mapping is None:
+            cut = min(self.k, kk)
+            if cut <= 0:
+                return None
+            srt = np.sort(indices[:, :cut], axis=1)
+            if not bool((srt[:, 0] >= 0).all() and (srt[:, 1:] != srt[:, :-1]).all()):
+                return None
+            # distinct hits of new questions: the reference's loop keeps exactly the first k of them, in order
+            return indices[:, :cut], scores[:, :cut]
+        if kb.many2one not in (None, "max"):
+            return None
+        # article -> passage fan-out of a whole block (the image indexes of the fusion configs): when the mapping is disjoint and a
+        # query's hits are distinct, no run entry is written twice and the reference's loop is a running count
+        csr = self._csr_of(kb)
+        srt = np.sort(indices, axis=1)
+        if csr.keys is None or not csr.disjoint or not bool((srt[:, 1:] != srt[:, :-1]).all()):
+            return None
+        return csr.expand_block(indices, scores, self.k, kb.many2one)
+
     def _flush(self):
         pending, self._pending = self._pending, []
         waiting = {}   # index_name -> (q_ids, set(q_ids), [ids blocks], [score blocks]): consecutive plain blocks filed as ONE
@@ -249,36 +276,21 @@ class Searcher:
             run = self._runs[index_name]
             indices = np.asarray(indices)
             scores = np.asarray(scores, dtype=np.float32)
-            nq, kk = indices.shape
-            cut = min(self.k, kk)
-            plain = kb.index_mapping is None and cut > 0
-            if plain:
-                srt = np.sort(indices[:, :cut], axis=1)
-                plain = bool((srt[:, 0] >= 0).all() and (srt[:, 1:] != srt[:, :-1]).all())
+            block = self._as_block(kb, run, q_ids, scores, indices)
             w = waiting.get(index_name)
-            if plain and isinstance(run, ArrayRun) and len(set(q_ids)) == nq and not any(q in run for q in q_ids) \
-                    and (w is None or (w[1].isdisjoint(q_ids) and w[2][0].shape[1] == cut)):
-                # distinct hits of new questions: the reference's loop keeps exactly the first k of them, in order -- the block
-                # stays a block of rows (viquae_amd/ir/runs.py); dicts are built when somebody indexes the run
+            if block is not None and kb.index_mapping is None and (w is None or (w[1].isdisjoint(q_ids) and w[2][0].shape[1] == block[0].shape[1])):
+                # the block stays a block of rows (viquae_amd/ir/runs.py): dicts are built when somebody indexes the run
                 if w is None:
                     w = waiting[index_name] = ([], set(), [], [])
                 w[0].extend(q_ids)
                 w[1].update(q_ids)
-                w[2].append(indices[:, :cut])
-                w[3].append(scores[:, :cut])
+                w[2].append(block[0])
+                w[3].append(block[1])
                 continue
             file_waiting(index_name)
-            if (kb.index_mapping is not None and kb.many2one in (None, "max") and isinstance(run, ArrayRun) and nq and kk
-                    and len(set(q_ids)) == nq and not any(q in run for q in q_ids)):
-                # article -> passage fan-out of a whole block (the image indexes of the fusion configs): when the mapping is disjoint
-                # and a query's hits are distinct, no run entry is written twice and the reference's loop is a running count
-                csr = self._csr_of(kb)
-                srt = np.sort(indices, axis=1)
-                if csr.keys is not None and csr.disjoint and bool((srt[:, 1:] != srt[:, :-1]).all()):
-                    block = csr.expand_block(indices, scores, self.k, kb.many2one)
-                    if block is not None:
-                        run.add_block(q_ids, block[0], block[1])
-                        continue
+            if block is not None and not any(q in run for q in q_ids):
+                run.add_block(q_ids, block[0], block[1])
+                continue
             for q_id, sc, idx in zip(q_ids, scores.tolist(), indices.tolist()):
                 self._fill_run(kb, run.setdefault(q_id, {}), sc, idx)
         for index_name in list(waiting):
@@ -351,16 +363,29 @@ class Searcher:
                     self._pending.append((kb, index_name, list(batch["id"]), scores_batch, indices_batch))
                     continue
                 self._flush()
-                for q_id, scores, indices, gt, question_type in zip(batch["id"], scores_batch, indices_batch, outputs,
-                                                                    question_types):
-                    run_q = self._runs[index_name].setdefault(q_id, {})
-                    scores = np.asarray(scores).tolist()
-                    indices = np.asarray(indices).tolist()
-                    self._fill_run(kb, run_q, scores, indices)
+                run = self._runs[index_name]
+                block = None
+                if isinstance(scores_batch, np.ndarray) and isinstance(indices_batch, np.ndarray) and indices_batch.ndim == 2:
+                    # the judged job keeps its runs as arrays too (round 5): what the judgement needs of a question's run is the SET
+                    # of retrieved documents, which is the row of the block
+                    block = self._as_block(kb, run, list(batch["id"]), np.asarray(scores_batch, dtype=np.float32), indices_batch)
+                    if block is not None:
+                        run.add_block(list(batch["id"]), block[0], block[1])
+                for row, (q_id, scores, indices, gt, question_type) in enumerate(zip(batch["id"], scores_batch, indices_batch, outputs,
+                                                                                     question_types)):
+                    if block is None:
+                        run_q = run.setdefault(q_id, {})
+                        scores = np.asarray(scores).tolist()
+                        indices = np.asarray(indices).tolist()
+                        self._fill_run(kb, run_q, scores, indices)
+                        run_keys = run_q.keys()
+                    else:
+                        ids_row = block[0][row]
+                        run_keys = {str(i) for i in ids_row[ids_row >= 0].tolist()}
                     if self.reference_kb is not None:
                         self.qrels.setdefault(q_id, {})
                         self.qnonrels.setdefault(q_id, {})
-                        retrieved = run_q.keys() - (self.qrels[q_id].keys() | self.qnonrels[q_id].keys())
+                        retrieved = run_keys - (self.qrels[q_id].keys() | self.qnonrels[q_id].keys())
                         _, relevant = find_relevant(retrieved, gt["original_answer"], gt["answer"], self.reference_kb,
                                                     reference_key=self.reference_key, question_type=question_type,
                                                     passages=self._passage_texts())
