@@ -122,6 +122,42 @@ def test_tie_heavy_data_overflows_the_pool_halves_and_falls_back():
     assert idx.screen_stats(21, 100)[0] == 1
 
 
+@pytest.mark.parametrize("copies", [40, 300])
+def test_runs_of_equal_rows_fill_pool_halves_beyond_their_first_line(copies):
+    """Every row repeated `copies` times in a run: the slabs that hold a query's best rows take dozens (40 copies) to more than a
+    hundred (300 copies: a run is longer than a slab, and the k-th score is tied 300 ways) keys per lane half.  The two-waves
+    kernel fills a half front to back and cand_select_kernel reads its first 64-byte line directly, the lines behind it from a
+    list in LDS (POOL_LAYOUT_HALVES); the answer must stay the exact scan's and the oracle's, without the fallback."""
+    from oracle import knn as ok
+    rng = np.random.default_rng(copies)
+    n, d, nq = 70000, 48, 200
+    X = np.repeat(rng.standard_normal((n // copies + 1, d), dtype=np.float32), copies, axis=0)[:n]
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    for tie in ("id_asc", "id_desc"):
+        idx = _index(X, 0, tie_order=tie)
+        (D1, I1), (D0, I0), stats = _both_scans(idx, Q, 100)
+        assert np.array_equal(I1, I0) and np.array_equal(D1, D0)
+        Do, Io = ok.knn(X, Q, 100, tie_order=tie)
+        assert np.array_equal(I1, Io) and np.array_equal(D1, Do)
+        assert stats[0] == 0 and stats[3] > 16, stats  # no fallback; some pool held more than two first lines' worth
+
+
+def test_identical_rows_overrun_the_line_list_and_fall_back():
+    """All rows equal: every lane half takes every row it sees (~137 keys = 17 lines, 8.7 k lines per query against a list of
+    1024), the walk finishes the slow way, finds more ties than the selection can hold and hands the tile to the exact scan --
+    lower (or higher) ids first."""
+    from oracle import knn as ok
+    X = np.ones((70000, 16), dtype=np.float32)
+    Q = np.random.default_rng(1).standard_normal((30, 16)).astype(np.float32)
+    for tie in ("id_asc", "id_desc"):
+        idx = _index(X, 0, tie_order=tie)
+        assert idx.scan_kind(30, 100) == "stream"
+        D, I = idx.search_batch(Q, 100)
+        Do, Io = ok.knn(X, Q, 100, tie_order=tie)
+        assert np.array_equal(I, Io) and np.array_equal(D, Do)
+        assert idx.screen_stats(30, 100)[0] == 1
+
+
 def test_heavy_tailed_and_clustered_rows():
     """Rows of wildly different norms and a shared direction (what the centred screen is for): thresholds stay valid."""
     from oracle import knn as ok

@@ -163,7 +163,8 @@ __device__ __forceinline__ void load_tile64(const float* __restrict__ src, int64
 // one workgroup (256 threads) per 64-row panel
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src, int64_t n, int d, int dpad,
                                                         int64_t row_offset, int l2norm, float* __restrict__ packed,
-                                                        float* __restrict__ sqnorm, const int* __restrict__ only_tiles = nullptr) {
+                                                        float* __restrict__ sqnorm, const int* __restrict__ only_tiles = nullptr,
+                                                        int64_t n_pad = 0) {
     __shared__ float tile[64][65];
     __shared__ float nrm[64];
     const int t = threadIdx.x;
@@ -214,7 +215,8 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
         }
         __syncthreads();
     }
-    if (t < 64 && row0 + t < n) sqnorm[row_offset + row0 + t] = acc2;
+    // n_pad > n: the panels and norms of padding rows [n, n_pad) are written too (zeros), for a destination nobody cleared
+    if (t < 64 && row0 + t < (n_pad > n ? n_pad : n)) sqnorm[row_offset + row0 + t] = acc2;
 }
 
 __global__ void unpack_rows_kernel(const float* __restrict__ packed, int d, int dpad, int64_t row_offset, int64_t n,
@@ -1676,14 +1678,14 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     }
     if (g.nqpad > nq)  // bf16 rows of the padding queries: the last tile (tile layout: its real rows are written below)
         MQ_HIP(hipMemsetAsync(Qb + (size_t)(g.nqpad - TQ) * dp, 0, (size_t)TQ * dp * 2, st));
-    MQ_HIP(hipMemsetAsync(ovf, 0, g.off_smax + (size_t)g.nqpad * g.ms * 4 - g.off_ovf, st));  // ovf + gthr + smax
     {
         const int64_t quads = (int64_t)nq * (dp / 4);
         hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, q_rm, (int64_t)nq, d, dp, Qb,
                            (l2 || ipc) ? 2 : 0, (const float*)nullptr, ipc ? xstats_dev + 4 : (const float*)nullptr, (int64_t)0);
         MQ_HIP(hipGetLastError());
         hipLaunchKernelGGL(screen_margin_kernel, dim3((unsigned)((g.nqpad + 3) / 4)), dim3(256), 0, st, q_rm, Qb, xstats_dev, nq,
-                           (int)g.nqpad, d, dp, margin, l2 ? 1 : (ipc ? 2 : 0), ipc ? xstats_dev + 4 : (const float*)nullptr);
+                           (int)g.nqpad, d, dp, margin, l2 ? 1 : (ipc ? 2 : 0), ipc ? xstats_dev + 4 : (const float*)nullptr,
+                           (unsigned*)ovf, (g.off_smax + (size_t)g.nqpad * g.ms * 4 - g.off_ovf) / 4);  // clears ovf + gthr + smax
         MQ_HIP(hipGetLastError());
     }
     // 1. bf16 screening scan
@@ -1711,8 +1713,15 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     }  // do_front
     if (!do_tail) return MQ_OK;
     // 2.-4. candidates -> exact scores -> exact top-k
+#ifdef MQ_TIMING
+    {
+        unsigned long long* p = dbg_ptr();
+        MQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_cs_dbg), &p, sizeof(p)));
+    }
+#endif
     hipLaunchKernelGGL(cand_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin,
-                       (const unsigned*)(ws + g.off_gthr), (const unsigned*)(ws + g.off_smax), g.ms, ovf, nq, g.S, k, cand, ccount);
+                       (const unsigned*)(ws + g.off_gthr), (const unsigned*)(ws + g.off_smax), g.ms, ovf, nq, g.S, k, cand, ccount,
+                       g.nqt == 1 ? (const int*)(ovf + 1) : (const int*)nullptr);
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq, RMAX / 64), dim3(256), 0, st, rowmajor_dev, q_rm, d, cand, ccount, ckeys,
                        l2 ? (const float*)qn : (const float*)nullptr, sqnorm_dev, flip);
@@ -1727,10 +1736,9 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
     // 5. query tiles whose bounded buffers overflowed are recomputed by the exact scan (no-op otherwise:
     //    every workgroup of an unflagged tile returns at once)
     {
-        if (!l2) {
-            MQ_HIP(hipMemsetAsync(Qp, 0, (size_t)g.nqpad * g.dpad * 4 + (size_t)g.nqpad * 4, st));
-            hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((nq + PANEL - 1) / PANEL)), dim3(256), 0, st, q_rm, (int64_t)nq, d,
-                               g.dpad, (int64_t)0, 0, Qp, qn, (const int*)ovf);
+        if (!l2) {  // (panels of flagged tiles only, their padding rows included: no clearing launch in front)
+            hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)(g.nqpad / PANEL)), dim3(256), 0, st, q_rm, (int64_t)nq, d,
+                               g.dpad, (int64_t)0, 0, Qp, qn, (const int*)ovf, (int64_t)g.nqpad);
             MQ_HIP(hipGetLastError());
         }
         ScanArgs a;
