@@ -98,3 +98,33 @@ def test_phase_flags_through_the_c_abi():
                                         idx._xmax2.data_ptr(), idx.ntotal, idx.d, Q.data_ptr(), 700, 10, 0, 32, 0, D.data_ptr(),
                                         I.data_ptr(), spaces[0].data_ptr(), spaces[0].numel(), main.cuda_stream, None, None)
     assert rc != 0
+
+
+@pytest.mark.parametrize("front,tail", [(8, 4), (4, 8)])
+def test_streaming_variant_switched_between_the_two_phases(front, tail):
+    """The two streaming scans leave their pools in different layouts (knn_screen.inc: POOL_LAYOUT_*); the scan records which in
+    the workspace.  A TAIL call whose host-side choice disagrees with what the FRONT call's scan left (MQ_KNN_OPT_SMALL_WAVES
+    changed in between) must notice and hand the tile to the exact scan -- same answer, never a walk of the wrong layout."""
+    import torch
+    from viquae_amd import _lib
+    from viquae_amd.index import FLAG_PHASE_FRONT, FLAG_PHASE_TAIL, MI355XFlatIndex
+    g = torch.Generator(device="cuda").manual_seed(front)
+    X = torch.randn((70000, 96), generator=g, device="cuda")
+    Q = torch.randn((200, 96), generator=g, device="cuda")
+    idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
+    idx.add(X)
+    assert idx.scan_kind(200, 100) == "stream"
+    D, I = idx.search_device(Q, 100)
+    assert idx.screen_stats(200, 100)[0] == 0
+    spaces, _ = idx.pipeline_workspaces(200, 100)
+    main = torch.cuda.current_stream()
+    out = (torch.zeros_like(D), torch.zeros_like(I))
+    with _lib.knn_option(_lib.KNN_OPT_SMALL_WAVES, front):
+        idx.search_phase(Q, 100, out, spaces[1], FLAG_PHASE_FRONT, main)
+    with _lib.knn_option(_lib.KNN_OPT_SMALL_WAVES, tail):
+        idx.search_phase(Q, 100, out, spaces[1], FLAG_PHASE_TAIL, main)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], D) and torch.equal(out[1], I)
+    idx._last_ws = spaces[1]
+    idx._last_call_nq = 200
+    assert idx.screen_stats(200, 100)[0] == 1  # recomputed by the exact scan

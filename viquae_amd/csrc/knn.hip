@@ -1719,9 +1719,17 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         MQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_cs_dbg), &p, sizeof(p)));
     }
 #endif
-    hipLaunchKernelGGL(cand_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin,
-                       (const unsigned*)(ws + g.off_gthr), (const unsigned*)(ws + g.off_smax), g.ms, ovf, nq, g.S, k, cand, ccount,
-                       g.nqt == 1 ? (const int*)(ovf + 1) : (const int*)nullptr);
+    {
+        const int* layout_word = g.nqt == 1 ? (const int*)(ovf + 1) : (const int*)nullptr;
+        const unsigned* gthr = (const unsigned*)(ws + g.off_gthr);
+        const unsigned* smax = (const unsigned*)(ws + g.off_smax);
+        if (small_scan_serves(g, N, dp, k) && knn_opt(MQ_KNN_OPT_SMALL_WAVES) == 8)  // (checked against the word the scan left)
+            hipLaunchKernelGGL(cand_select_kernel<POOL_LAYOUT_HALVES>, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin, gthr,
+                               smax, g.ms, ovf, nq, g.S, k, cand, ccount, layout_word);
+        else
+            hipLaunchKernelGGL(cand_select_kernel<POOL_LAYOUT_SLICES>, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin, gthr,
+                               smax, g.ms, ovf, nq, g.S, k, cand, ccount, layout_word);
+    }
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq, RMAX / 64), dim3(256), 0, st, rowmajor_dev, q_rm, d, cand, ccount, ckeys,
                        l2 ? (const float*)qn : (const float*)nullptr, sqnorm_dev, flip);
