@@ -306,21 +306,43 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ ro
 // The same normalisation for FEW rows (a search's queries: 256 per call in the reference's batches): l2norm_rows_kernel gives 64
 // rows to a workgroup, so 256 queries of 2048 columns were four workgroups walking 32 dependent load -> barrier -> chain steps
 // each -- 229 us of a 2.25-ms search over the 2048-d "L2norm,Flat" index (rocprofv3, round 5).  Here a workgroup takes 8 rows and
-// 256 columns per step (one 1-KiB run per row); the sum of squares stays the k-ordered fp32 fma chain of one thread per row,
-// the bits are the same.
+// 1024 columns per step, 32 unconditional loads in flight per thread (256 columns per step, each load under its bounds test:
+// 50 us at d = 2048 -- one round trip per load); the sum of squares stays the k-ordered fp32 fma chain of one thread per
+// row, the bits are the same.
 __global__ __launch_bounds__(256) void l2norm_rows_small_kernel(float* __restrict__ rows, int64_t n, int d, int form) {
-    __shared__ float tile[8][257];
+    constexpr int CH = 1024;
+    __shared__ float tile[8][CH + 1];
     __shared__ float nrm[8];
     const int t = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * 8;
     float acc = 0.f;
-    for (int kc = 0; kc < d; kc += 256) {
+    for (int kc = 0; kc < d; kc += CH) {
+        // every load at an address inside the matrix (clamped), all 32 in flight, then the stores: a load under a condition is
+        // a branch and a wait of its own (32 round trips per step)
+        float v[8][CH / 256];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) tile[r][t] = (row0 + r < n && kc + t < d) ? rows[(row0 + r) * (int64_t)d + kc + t] : 0.f;
+        for (int r = 0; r < 8; ++r) {
+            const int64_t rr = row0 + r < n ? row0 + r : n - 1;
+#pragma unroll
+            for (int j = 0; j < CH / 256; ++j) {
+                const int c = kc + t + 256 * j;
+                v[r][j] = rows[rr * (int64_t)d + (c < d ? c : d - 1)];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+#pragma unroll
+            for (int j = 0; j < CH / 256; ++j) tile[r][t + 256 * j] = v[r][j];  // (columns >= d, rows >= n: never read)
+        }
         __syncthreads();
         if (t < 8) {
-            const int kn = d - kc < 256 ? d - kc : 256;
-            for (int k = 0; k < kn; ++k) acc = fmaf(tile[t][k], tile[t][k], acc);
+            const int kn = d - kc < CH ? d - kc : CH;
+            int k = 0;
+            for (; k + 16 <= kn; k += 16) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc = fmaf(tile[t][k + u], tile[t][k + u], acc);
+            }
+            for (; k < kn; ++k) acc = fmaf(tile[t][k], tile[t][k], acc);
         }
         __syncthreads();
     }
@@ -1724,10 +1746,13 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         const unsigned* gthr = (const unsigned*)(ws + g.off_gthr);
         const unsigned* smax = (const unsigned*)(ws + g.off_smax);
         if (small_scan_serves(g, N, dp, k) && knn_opt(MQ_KNN_OPT_SMALL_WAVES) == 8)  // (checked against the word the scan left)
-            hipLaunchKernelGGL(cand_select_kernel<POOL_LAYOUT_HALVES>, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin, gthr,
+            hipLaunchKernelGGL(cand_select_kernel<CSEL_WALK_HALVES>, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin, gthr,
+                               smax, g.ms, ovf, nq, g.S, k, cand, ccount, layout_word);
+        else if (g.S >= 64)
+            hipLaunchKernelGGL(cand_select_kernel<CSEL_WALK_SLICE_LINES>, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin, gthr,
                                smax, g.ms, ovf, nq, g.S, k, cand, ccount, layout_word);
         else
-            hipLaunchKernelGGL(cand_select_kernel<POOL_LAYOUT_SLICES>, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin, gthr,
+            hipLaunchKernelGGL(cand_select_kernel<CSEL_WALK_SLICES>, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin, gthr,
                                smax, g.ms, ovf, nq, g.S, k, cand, ccount, layout_word);
     }
     MQ_HIP(hipGetLastError());
