@@ -1538,9 +1538,12 @@ static int screen_copy_and_stats(const float* sqnorm_dev, int d, int metric, int
     const int dp = screen_dp(d, metric);
     const float* rm = rowmajor_dev + (size_t)row_offset * d;
     const int64_t quads = n * (int64_t)(dp / 4);
-    hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, rm, n, d, dp,
-                       (unsigned short*)bf16_dev, metric == MQ_METRIC_L2 ? 1 : (metric == MQ_METRIC_IP_CENTRED ? 3 : 0), sqnorm_dev + row_offset,
-                       center_dev, row_offset);
+    if (metric == MQ_METRIC_IP_CENTRED)  // rows of x - c and their row term c . (x - c): 64 rows per workgroup
+        hipLaunchKernelGGL(to_bf16_rows_centred_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, rm, n, d, dp,
+                           (unsigned short*)bf16_dev, center_dev, row_offset);
+    else
+        hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, rm, n, d, dp,
+                           (unsigned short*)bf16_dev, metric == MQ_METRIC_L2 ? 1 : 0, sqnorm_dev + row_offset, center_dev, row_offset);
     MQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(row_err_stats_kernel, dim3((unsigned)((n + 3) / 4 < 2048 ? (n + 3) / 4 : 2048)), dim3(256), 0, st, rm,
                        (const unsigned short*)bf16_dev, n, d, dp, (unsigned*)xstats_dev, center_dev, row_offset);
