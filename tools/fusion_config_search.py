@@ -10,8 +10,9 @@
 all with `device: null` (-> FAISS's own NormalizationTransform arithmetic, l2norm_form "faiss") and searched in 256-question
 batches (map_kwargs.batch_size, :59-62), each over a synthetic 1.5M-row KB (BASELINE's KB size; the real tables hold 11.9M
 passages / ~1M articles / ~0.5M articles) through the same C-ABI call the index makes (mq_knn_search_screened_f32), HIP events
-around the scan kernel.  Per index: which scan serves it (`scan_kind`), the scan's time and the fraction of the 8 TB/s HBM
-roofline that reading the bf16 screening copy ONCE amounts to, the whole call, and the screen's own statistics.
+around the scan kernel.  Per index: which scan serves it (`scan_kind`), the scan's time, the fraction of the 8 TB/s HBM
+roofline that reading the bf16 screening copy ONCE amounts to and the fraction of the 2.5 PFLOP/s bf16 peak its 2 nq N dp
+flops amount to (256 questions x 2048 columns: the larger of the two), the whole call, and the screen's own statistics.
 
 Data: every vector = a shared component + isotropic noise (``shared`` : 1 in norm ratio; image / DPR embeddings are not centred),
 the same generator for KB rows and questions."""
@@ -24,6 +25,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 PEAK_HBM_GBPS = 8000.0
+PEAK_BF16_TFLOPS = 2500.0
 INDEXES = [  # (index name, column, d, string_factory) in config order
     ("DPR_few_shot_dp", "DPR_few_shot", 768, "Flat"),
     ("resnet", "imagenet-RN50", 2048, "L2norm,Flat"),
@@ -95,6 +97,9 @@ def one_index(name, column, d, factory, rows, nq, k, reps, shared, device):
            "scan_kind": idx.scan_kind(nq, k), "scan_ms": round(scan_ms, 4), "call_ms": round(call_ms, 4),
            "queries_per_s": round(nq / call_ms * 1e3, 1),
            "algorithmic_hbm_bytes": kb_bytes, "hbm_frac": round(kb_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+           # 256 questions against every row: at 1024 / 2048 columns the scan is nearer the matrix pipe's roofline than HBM's
+           "bf16_tflops": round(2.0 * nq * rows * dp / (scan_ms * 1e-3) / 1e12, 1),
+           "mfma_frac": round(2.0 * nq * rows * dp / (scan_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
            "screen": {"query_tiles_recomputed_exactly": st[0], "candidates_rescored_per_query": round(st[1] / nq, 1),
                       "max_candidates_of_a_query": st[2]},
            "sanity_scores_sorted_and_rescored": ok}
