@@ -270,7 +270,7 @@ def test_centred_margin_dominates_the_measured_screening_error(monkeypatch):
     assert abs(s[0] - float((X.double() ** 2).sum(1).max())) < 1e-3 * s[0] and s[2] < 0.6 * s[0]
 
 
-@pytest.mark.parametrize("d,shift", [(200, 9.0), (1000, 20.0), (2048, 40.0), (128, 9.0)])
+@pytest.mark.parametrize("d,shift", [(200, 9.0), (1000, 20.0), (2048, 40.0), (128, 9.0), (127, 9.0), (63, 6.0)])
 def test_centred_query_margin_dominates_the_measured_screening_error(d, shift, monkeypatch):
     """MQ_METRIC_IP_CENTRED (round 5): S~ = bf16(q - c) . bf16(x - c) + (h + l), (h, l) the bf16 pair of v = c . (x - c), against
     S = q . x - q . c in float64 -- |S~ - S| <= margin / 2 for every (query, row), the margin is not vacuous, it sits well below
@@ -278,8 +278,10 @@ def test_centred_query_margin_dominates_the_measured_screening_error(d, shift, m
     from viquae_amd.index import METRIC_IP_CENTRED, MI355XFlatIndex
     n, nq, k = 6000, 200, 10
     X, Q = _anisotropic(n, d, nq, 5 + d, shift=shift, noise=0.25)
-    if d == 128:
-        monkeypatch.setenv("MQ_KNN_CENTER_QUERIES", "1")   # d % 64 == 0 and d <= 768: not chosen by default (a 3rd K block)
+    if d in (128, 127, 63):
+        # d % 64 == 0 and d <= 768: not chosen by default (a 3rd K block); d % 64 == 63: the two row-term columns fall into
+        # DIFFERENT K blocks of the tile layout (to_bf16_rows_centred_kernel writes them apart)
+        monkeypatch.setenv("MQ_KNN_CENTER_QUERIES", "1")
     idx = MI355XFlatIndex(string_factory="Flat", metric_type=0, screen=True)
     idx.add(X[:2560])
     idx.add(X[2560:])
