@@ -66,7 +66,7 @@ def one_index(name, column, d, factory, rows, nq, k, reps, shared, device):
             ws.data_ptr(), ws_bytes, stream.cuda_stream, e0.cuda_event if e0 else None, e1.cuda_event if e1 else None),
             "mq_knn_search_screened_f32")
 
-    for _ in range(3):
+    for _ in range(25):  # (the first calls after the index build run 10 - 30 % slow -- clocks settling; 3 warm-up calls left that in the mean)
         call()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in evs:
@@ -101,7 +101,7 @@ def one_index(name, column, d, factory, rows, nq, k, reps, shared, device):
            "bf16_tflops": round(2.0 * nq * rows * dp / (scan_ms * 1e-3) / 1e12, 1),
            "mfma_frac": round(2.0 * nq * rows * dp / (scan_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
            "screen": {"query_tiles_recomputed_exactly": st[0], "candidates_rescored_per_query": round(st[1] / nq, 1),
-                      "max_candidates_of_a_query": st[2]},
+                      "max_candidates_of_a_query": st[2], "pool_keys_per_query": round(st[4] / nq, 1)},
            "sanity_scores_sorted_and_rescored": ok}
     del idx, ws, D, I, Q
     torch.cuda.empty_cache()
