@@ -13,14 +13,14 @@ for s in range(0, N, 1 << 16):
     idx.add(torch.randn((min(1 << 16, N - s), d), generator=g, device=dev), total_hint=N)
 Q = torch.randn((nq, d), generator=g, device=dev)
 NW = int(os.environ.get('MQ_KNN_SMALL_WAVES', '8'))
-dbg = torch.zeros(256 * NW * 8, dtype=torch.int64, device=dev)
+dbg = torch.zeros(32768 + 256 * 8, dtype=torch.int64, device=dev)  # (+ cand_select's stamps behind the scan's slots in timing builds)
 os.environ["MQ_DBG_PTR"] = str(dbg.data_ptr())
 for _ in range(3):
     idx.search_device(Q, k)
 torch.cuda.synchronize()
 dbg.zero_()
 idx.search_device(Q, k); torch.cuda.synchronize()
-t = dbg.view(256, NW, 8).double()
+t = dbg[:256 * NW * 8].view(256, NW, 8).double()
 cyc = t[..., :6].sum(-1)
 rt = t[..., 6]
 print("nq %d variant %s: per-wave cycles mean %.3e max %.3e; kernel wall %.1f us (100 MHz ticks) -> clock %.2f GHz" %
