@@ -422,6 +422,46 @@ int mq_fuse_wsum_f64(const int64_t *ids_dev, const double *scores_dev, int n_run
                      int32_t *out_count_dev, void *ws_dev, size_t ws_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Rank metrics of a run against relevance judgements -- what `ranx.compare(qrels, runs, metrics=[...])` reports at
+ * the end of a search job (meerqat/ir/search.py:397,500-512; ranx is un-vendored, `ranx>=0.3.2`: the published
+ * definitions are restated, parity unpinned):
+ *   ids_dev [nq, K] int64    one run, best first; a row ends at its first negative id
+ *   rel_ptr_dev [nq + 1] / rel_ids_dev    CSR of the RELEVANT documents (judgement >= 1) of every query, ascending
+ *                                         inside a query
+ *   codes_host / ks_host [n_metrics]      MQ_RANK_METRIC_* and the cut k (0 = the whole run); n_metrics <= MQ_RANK_MAX_METRICS
+ *     MRR        1 / (1 + rank of the first relevant document inside the cut), else 0
+ *     PRECISION  (relevant inside the cut) / k     (k = 0: / the length of the query's run; an empty run scores 0)
+ *     HIT_RATE   1 when a relevant document is inside the cut
+ *     RECALL     (relevant inside the cut) / (relevant documents of the query), 0 when it has none
+ *   per_query_dev [n_metrics, nq] f64, mean_dev [n_metrics] f64 = numpy's mean of each row (np.mean's pairwise
+ *   summation restated: the number ranx.evaluate returns)
+ * ------------------------------------------------------------------------------------------- */
+#define MQ_RANK_METRIC_MRR 0
+#define MQ_RANK_METRIC_PRECISION 1
+#define MQ_RANK_METRIC_HIT_RATE 2
+#define MQ_RANK_METRIC_RECALL 3
+#define MQ_RANK_MAX_METRICS 16
+int mq_run_metrics_f64(const int64_t *ids_dev, int nq, int K, const int64_t *rel_ptr_dev, const int64_t *rel_ids_dev,
+                       int n_metrics, const int *codes_host, const int *ks_host, double *per_query_dev,
+                       double *mean_dev, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The weight search of `Fusion.fit` (meerqat/ir/fuse.py:193-217 -> `ranx.optimize_fusion(method="wsum")`): every
+ * trial weight vector fuses the runs like mq_fuse_wsum_f64 and is scored by ONE rank metric, all trials in one
+ * launch (a workgroup sorts and normalises a query's entries once, then walks the trials).
+ *   ids_dev / scores_dev / n_runs / nq / K / norm / defmin: as mq_fuse_wsum_f64
+ *   trials_dev [n_trials, n_runs] f64 (DEVICE memory)
+ *   rel_ptr_dev / rel_ids_dev: as mq_run_metrics_f64;  metric / metric_k: one MQ_RANK_METRIC_* and its cut
+ *   per_query_dev [n_trials, nq] f64: the metric of query q under trial t (rank = fused score descending, equal
+ *   scores by ascending id -- the order mq_fuse_wsum_f64 writes); mean_dev [n_trials] f64: np.mean of each row.
+ *   ws_dev: mq_fuse_workspace_bytes(n_runs, nq, K).
+ * ------------------------------------------------------------------------------------------- */
+int mq_fuse_fit_wsum_f64(const int64_t *ids_dev, const double *scores_dev, int n_runs, int nq, int K,
+                         const double *trials_dev, int n_trials, int norm, int defmin, const int64_t *rel_ptr_dev,
+                         const int64_t *rel_ids_dev, int metric, int metric_k, double *per_query_dev, double *mean_dev,
+                         void *ws_dev, size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Run files -- HOST function, no device work: replaces the per-hit Python objects behind
  * `run.save(metric_save_path / f"{index_name}.json")` (meerqat/ir/search.py:485-498) over the dicts of :413-440.  Formats the
  * rows of a result block kept as arrays into the text `json.dump({q_id: {str(doc): float(score)}})` writes, byte for byte

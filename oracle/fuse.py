@@ -97,3 +97,75 @@ def fusion_test(runs, weights, norm="gzmuv", defmin=False):
         runs = default_minimum(runs)
     runs = [NORMS[norm](run) for run in runs]
     return wsum(runs, weights)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Rank metrics and the weight search (round 6).  ranx (requirements.txt:15) is NOT installed here and not vendored:
+# what follows restates its PUBLISHED definitions -- parity unpinned vs ranx.
+#
+# * ``rank_metric``   -- ranx ``metrics/{reciprocal_rank,precision,hit_rate,recall}.py``: the run is taken best first
+#   (here: in the order given, which is how every run of this build is stored), the cut is ``k`` (``k = 0``: the
+#   length of the query's run), a document is relevant when its judgement is >= 1; ``precision`` divides by the
+#   cut itself, ``recall`` by the number of relevant documents of the query (0 when it has none); the job-level
+#   figure is ``np.mean`` over the queries of the qrels (``ranx.evaluate``; called at meerqat/ir/search.py:500-504
+#   and meerqat/ir/fuse.py:233-234 with ["mrr@100", "precision@1", "precision@20", "hit_rate@20"]).
+# * ``wsum_trials``   -- ranx ``fusion/wsum.py`` + ``fusion/common.py``: the candidate weights are
+#   ``[round(x, 2) for x in np.arange(0, 1 + step, step)]`` with step 0.1 and a trial is every tuple of
+#   ``itertools.product`` whose Python ``sum`` equals 1.0 EXACTLY -- so the tuples whose floating-point sum misses
+#   1.0 (4 of the 66 for three runs, 30 of 286 for four) are not tried; restated as published, quirk included.
+# * ``fusion_fit``    -- ``Fusion.fit`` (meerqat/ir/fuse.py:193-217): default-minimum on the raw runs (done by
+#   ``Fusion.__init__``, :176-177), the custom norm as a preprocessing (:198-201), then ``optimize_fusion``: every
+#   trial is fused with ``wsum`` and scored with ``metric``; the FIRST trial that reaches the best score wins.
+# ---------------------------------------------------------------------------------------------------------------
+import itertools
+
+
+def parse_metric(name):
+    base, _, k = name.partition("@")
+    return base, int(k) if k else 0
+
+
+def rank_metric(run, qrels, name):
+    """np.mean over the queries of ``run`` of one metric; returns (mean, per-query list)."""
+    base, k = parse_metric(name)
+    values = []
+    for q_id, results in run.items():
+        docs = list(results)
+        relevant = {d for d, r in qrels.get(q_id, {}).items() if r >= 1}
+        cut = len(docs) if k == 0 else k
+        top = docs[:cut]
+        flags = [d in relevant for d in top]
+        if cut == 0:
+            v = 0.0
+        elif base == "mrr":
+            v = 1.0 / (flags.index(True) + 1) if any(flags) else 0.0
+        elif base == "precision":
+            v = sum(flags) / cut
+        elif base == "hit_rate":
+            v = 1.0 if any(flags) else 0.0
+        elif base == "recall":
+            v = sum(flags) / len(relevant) if relevant else 0.0
+        else:
+            raise ValueError(f"metric '{name}' is not restated")
+        values.append(v)
+    return (float(np.mean(np.array(values, dtype=np.float64))) if values else 0.0), values
+
+
+def wsum_trials(n_runs, step=0.1):
+    weights = [round(float(x), 2) for x in np.arange(0, 1 + step, step)]
+    return [seq for seq in itertools.product(*[weights] * n_runs) if sum(seq) == 1.0]
+
+
+def fusion_fit(runs, qrels, norm="gzmuv", defmin=False, metric="mrr@100", step=0.1):
+    """-> (best_params, [(weights, score)] in trial order)."""
+    if defmin:
+        runs = default_minimum(runs)
+    runs = [NORMS[norm](run) for run in runs]
+    report = []
+    best, best_score = None, None
+    for weights in wsum_trials(len(runs), step):
+        score, _ = rank_metric(wsum(runs, weights), qrels, metric)
+        report.append((weights, score))
+        if best_score is None or score > best_score:
+            best, best_score = weights, score
+    return {"weights": list(best)}, report

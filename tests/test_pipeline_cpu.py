@@ -249,3 +249,17 @@ def test_job_fingerprint_takes_every_kind_of_model_config():
     m = M({"hidden_size": 8})
     m.w[0, 0] = 1.0
     assert job_fingerprint(ds, "job", model=m) not in fps     # non-persistent buffers are part of the model's identity
+
+
+def test_job_fingerprint_follows_the_code_that_computes_the_embeddings(monkeypatch):
+    """the deterministic fingerprint must change when the library (or the pipeline source) changes, otherwise a
+    rebuilt libmeerqat_hip.so serves the stale cached column."""
+    from viquae_amd import utils
+
+    class DS:
+        _fingerprint = "abc"
+    a = utils.job_fingerprint(DS(), "job", key="passage")
+    assert a == utils.job_fingerprint(DS(), "job", key="passage")
+    assert "meerqat_hip" in utils.code_fingerprint()
+    monkeypatch.setattr(utils, "_CODE_FINGERPRINT", "meerqat_hip 9.9 (gfx950):0123456789abcdef")
+    assert utils.job_fingerprint(DS(), "job", key="passage") != a

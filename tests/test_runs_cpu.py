@@ -153,7 +153,7 @@ def test_dataset_search_writes_the_run_file_json_dump_would(tmp_path, hip_lib):
     kb.indexes["dense"] = Index(key="vec_q")
     out = tmp_path / "metrics"
     with pytest.warns(UserWarning):
-        s = S.dataset_search(qs, k=9, metric_save_path=out, map_kwargs={"batch_size": 16, "load_from_cache_file": False},
+        s = S.dataset_search(qs, k=9, metric_save_path=out, report=False, map_kwargs={"batch_size": 16, "load_from_cache_file": False},
                              kb_kwargs={"kb": {}}, kbs={"kb": kb}, qrels=str(tmp_path / "qrels.json"), do_fusion=False)
     run = s.runs["dense"]
     assert isinstance(run, ArrayRun) and run.lazy_questions() == 70       # the job built no per-hit object
@@ -162,3 +162,25 @@ def test_dataset_search_writes_the_run_file_json_dump_would(tmp_path, hip_lib):
     assert (out / "dense.json").read_bytes() == json.dumps(want).encode()
     assert run == want and list(run["question 3"]) == [str(i) for i in I[3]]
     assert os.path.exists(out / "qrels.json")
+
+
+def test_run_file_with_question_ids_that_are_not_strings():
+    """json.dump coerces int / float / bool / None dict keys to strings; the array writer must write the same bytes."""
+    import io
+    import json
+    import numpy as np
+    from viquae_amd.ir.runs import ArrayRun
+    ids = np.array([[3, 1, -1], [7, 8, 9], [2, -1, -1], [4, 5, 6], [1, 2, 3]], dtype=np.int64)
+    scores = np.array([[1.5, 0.25, 0], [3, 2, 1], [9.75, 0, 0], [1, 0.5, 0.1], [2, 1, 0]], dtype=np.float32)
+    q_ids = [5, "six", 7.5, True, None]
+    run = ArrayRun()
+    run.add_block(q_ids, ids, scores)
+    run[12] = {"4": 1.0}                       # a dict entry with an int id as well
+    want = json.dumps(run.to_dict()).encode()
+    assert run.json_bytes() == want
+    assert json.loads(run.json_bytes()) == {"5": {"3": 1.5, "1": 0.25}, "six": {"7": 3.0, "8": 2.0, "9": 1.0}, "7.5": {"2": 9.75},
+                                            "true": {"4": 1.0, "5": 0.5, "6": float(np.float32(0.1))}, "null": {"1": 2.0, "2": 1.0, "3": 0.0},
+                                            "12": {"4": 1.0}}
+    buf = io.BytesIO()
+    run.dump_json(buf)
+    assert buf.getvalue() == want

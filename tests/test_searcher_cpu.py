@@ -247,7 +247,7 @@ def test_arrow_query_transport_changes_the_transport_not_the_runs(tmp_path):
     assert np.array_equal(fast.batch("vec_q", list(range(5, 21))), Q[5:21])
     assert np.array_equal(fast.batch("vec_q", [3, 9, 4]), Q[[3, 9, 4]])
     with pytest.warns(UserWarning):
-        s_fast = S.dataset_search(qs, map_kwargs={"batch_size": 16, "load_from_cache_file": False}, **kb_kwargs())
+        s_fast = S.dataset_search(qs, report=False, map_kwargs={"batch_size": 16, "load_from_cache_file": False}, **kb_kwargs())
     assert s_fast.runs == s_py.runs and len(s_fast.runs["dense"]["5"]) == 10 and s_fast.runs["face"]["0"] == {}
     assert not S.ArrowQueryColumns(qs.with_format("numpy"), s_py)                   # the user's format stands
     assert not S.ArrowQueryColumns(qs.select([3, 1, 2]), s_py)                      # indices mapping: ordinary path
@@ -442,12 +442,12 @@ def test_search_ahead_windows_serve_every_batch_the_arrays_of_its_own_search(tmp
 
     monkeypatch.setenv("MQ_SEARCH_WINDOW", "0")
     with pytest.warns(UserWarning):
-        want = S.dataset_search(qs, map_kwargs={"batch_size": 16, "load_from_cache_file": False}, **kb_kwargs()).runs
+        want = S.dataset_search(qs, report=False, map_kwargs={"batch_size": 16, "load_from_cache_file": False}, **kb_kwargs()).runs
     assert calls == [16] * 6 + [4]
     del calls[:]
     monkeypatch.setenv("MQ_SEARCH_WINDOW", str(window))
     with pytest.warns(UserWarning):
-        got = S.dataset_search(qs, map_kwargs={"batch_size": 16, "load_from_cache_file": False}, **kb_kwargs()).runs
+        got = S.dataset_search(qs, report=False, map_kwargs={"batch_size": 16, "load_from_cache_file": False}, **kb_kwargs()).runs
     assert got == want and list(got["dense"]) == [str(i) for i in range(100)]
     # windows are whole batches (20 rows under 16-row batches -> 16 = the batch itself: no window)
     expect = {0: [16] * 6 + [4], 16: [16] * 6 + [4], 20: [16] * 6 + [4], 64: [64, 36], 4096: [100]}[window]
@@ -489,10 +489,20 @@ def test_search_ahead_keeps_the_l2_form_of_every_batch(tmp_path, monkeypatch, ba
     assert not np.array_equal(ok.knn(art, tail, 9, metric=1)[0], ok.knn(art, Q, 9, metric=1)[0][110 - 14:])  # the forms differ
     monkeypatch.setenv("MQ_SEARCH_WINDOW", "0")
     with pytest.warns(UserWarning):
-        want = S.dataset_search(qs, map_kwargs={"batch_size": batch_size, "load_from_cache_file": False}, **kb_kwargs()).runs
+        want = S.dataset_search(qs, report=False, map_kwargs={"batch_size": batch_size, "load_from_cache_file": False}, **kb_kwargs()).runs
     del calls[:]
     monkeypatch.setenv("MQ_SEARCH_WINDOW", "4096")
     with pytest.warns(UserWarning):
-        got = S.dataset_search(qs, map_kwargs={"batch_size": batch_size, "load_from_cache_file": False}, **kb_kwargs()).runs
+        got = S.dataset_search(qs, report=False, map_kwargs={"batch_size": batch_size, "load_from_cache_file": False}, **kb_kwargs()).runs
     assert got == want
     assert calls == expect
+
+
+def test_passage_cache_eviction_refetches_the_whole_request():
+    """with a small capacity the eviction dropped ids of the CURRENT request that were cached -> KeyError."""
+    from viquae_amd.ir.searcher import PassageTexts, answer_preprocess
+    kb = [{"passage": f"The passage, number {i}!"} for i in range(12)]
+    cache = PassageTexts(kb, capacity=4)
+    assert cache.get_many([0, 1, 2]) == [answer_preprocess(kb[i]["passage"]) for i in (0, 1, 2)]
+    assert cache.get_many([0, 1, 3, 4, 5]) == [answer_preprocess(kb[i]["passage"]) for i in (0, 1, 3, 4, 5)]
+    assert cache.get_many([5, 5, 0, 11]) == [answer_preprocess(kb[i]["passage"]) for i in (5, 5, 0, 11)]

@@ -3,15 +3,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 sys.path.insert(0, "tools")
 import stress_small_scan as st
+from viquae_amd import _lib
 from viquae_amd.index import MI355XFlatIndex
 for seed in [int(x) for x in sys.argv[1:]]:
     X, Q, k, regime, factory, form, metric, tie = st.case(seed)
     a = MI355XFlatIndex(string_factory=factory, metric_type=metric, screen=True, tie_order=tie, l2norm_form=form); a.add(X)
     b = MI355XFlatIndex(string_factory=factory, metric_type=metric, screen=False, tie_order=tie, l2norm_form=form); b.add(X)
     D, I = a.search_device(Q, k); torch.cuda.synchronize(); s1 = a.screen_stats(Q.shape[0], k)
-    os.environ["MQ_KNN_SMALL"] = "0"
-    Dt, It = a.search_device(Q, k); torch.cuda.synchronize(); s0 = a.screen_stats(Q.shape[0], k)
-    del os.environ["MQ_KNN_SMALL"]
+    with _lib.knn_option(_lib.KNN_OPT_SMALL_SCAN, 0):   # the tile kernel (the switches are read through the C ABI, not the environment)
+        Dt, It = a.search_device(Q, k); torch.cuda.synchronize(); s0 = a.screen_stats(Q.shape[0], k)
     D0, I0 = b.search_device(Q, k); torch.cuda.synchronize()
     badq = (~((I == I0).all(1) & (D.view(torch.int32) == D0.view(torch.int32)).all(1))).nonzero().flatten().tolist()
     print(seed, X.shape, Q.shape, k, regime, metric, tie, "stream stats", s1[:5], "tile stats", s0[:5], "tile ok", bool(torch.equal(It, I0)), "bad queries", badq[:20], len(badq))

@@ -3,6 +3,7 @@ clustered data: query tiles recomputed exactly, candidates per query, ms per sea
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
+from viquae_amd import _lib
 from viquae_amd.index import MI355XFlatIndex
 dev = torch.device("cuda"); rows, d, nq, k = 1_500_000, 768, 256, 100
 g = torch.Generator(device=dev).manual_seed(7)
@@ -20,7 +21,7 @@ for name in ("dpr_like", "clusters_1000"):
             idx.add(c[torch.randint(0, 1000, (n,), generator=g, device=dev)] + 0.3 * torch.randn((n, d), generator=g, device=dev), total_hint=rows)
         Q = c[torch.randint(0, 1000, (nq,), generator=g, device=dev)] + 0.3 * torch.randn((nq, d), generator=g, device=dev)
     for small in ("1", "0"):
-        os.environ["MQ_KNN_SMALL"] = small
+      with _lib.knn_option(_lib.KNN_OPT_SMALL_SCAN, int(small)):   # through the C ABI: the environment is read once at load
         D, I = idx.search_device(Q, k); torch.cuda.synchronize()
         st = idx.screen_stats(nq, k)
         t0 = time.perf_counter()

@@ -1,5 +1,5 @@
 """Cycle accounting of knn_scan_kernel / screen_scan_kernel (SCREEN=1) (needs a -DMQ_TIMING build: MEERQAT_HIP_LIB=ab/lib_timing.so;
-NQ, D from the environment; with NQ <= 256 and D <= 768 set MQ_KNN_SMALL_SCAN=0 to keep the tile kernel)."""
+NQ, D from the environment; with NQ <= 256 and D <= 768 export MQ_KNN_SMALL=0 BEFORE the library loads -- the switches are read once -- to keep the tile kernel)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -90,6 +90,9 @@ SIGNATURES = {
     "mq_fuse_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "mq_fuse_wsum_f64": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_sz,
                                  c_ptr]),
+    "mq_run_metrics_f64": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mq_fuse_fit_wsum_f64": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_int,
+                                     c_int, c_ptr, c_ptr, c_ptr, c_sz, c_ptr]),
     "mq_format_run_json": (c_i64, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
 }
 

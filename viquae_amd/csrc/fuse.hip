@@ -263,6 +263,228 @@ __global__ __launch_bounds__(FT) void fuse_combine_kernel(FuseArgs A) {
     if (t == 0) A.out_count[q] = count;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Rank metrics of a run against qrels, and the weight search of `Fusion.fit` (meerqat/ir/fuse.py:193-217 ->
+// ranx.optimize_fusion; the metric report of meerqat/ir/search.py:397,500-512 -> ranx.compare).  qrels are a CSR
+// table: rel_ptr [nq + 1], rel_ids ascending inside one query (only the documents whose judgement is >= 1).
+//   mrr@k       1 / (1 + rank of the first relevant document among the first k), else 0
+//   precision@k (relevant among the first k) / k             -- k = 0: the length of the query's run
+//   hit_rate@k  1 when a relevant document is among the first k
+//   recall@k    (relevant among the first k) / (relevant documents of the query); 0 when it has none
+// ------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ bool is_relevant(const int64_t* rel, int64_t n, int64_t id) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        int64_t v = rel[mid];
+        if (v < id) lo = mid + 1; else hi = mid;
+    }
+    return lo < n && rel[lo] == id;
+}
+
+// first: rank (0-based) of the best relevant document inside the cut, or -1; hits: relevant inside the cut
+__device__ __forceinline__ double metric_value(int code, int k, int len, int first, int hits, int64_t n_rel) {
+    int cut = k == 0 ? len : k;
+    if (cut == 0) return 0.0;
+    switch (code) {
+        case MQ_RANK_METRIC_MRR: return first >= 0 ? 1.0 / (double)(first + 1) : 0.0;
+        case MQ_RANK_METRIC_PRECISION: return (double)hits / (double)cut;
+        case MQ_RANK_METRIC_HIT_RATE: return hits > 0 ? 1.0 : 0.0;
+        default: return n_rel > 0 ? (double)hits / (double)n_rel : 0.0;
+    }
+}
+
+struct MetricArgs {
+    const int64_t* ids;      // [nq, K] best first, a row ends at its first negative id
+    const int64_t* rel_ptr;  // [nq + 1]
+    const int64_t* rel_ids;
+    double* out;             // [n_metrics, nq]
+    int nq, K, n_metrics;
+    int code[MQ_RANK_MAX_METRICS], k[MQ_RANK_MAX_METRICS];
+};
+
+// one wave per query: relevance flags of the row as 64-bit ballots, every metric from the same flags
+__global__ __launch_bounds__(256) void run_metrics_kernel(MetricArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= A.nq) return;
+    const int64_t* row = A.ids + (size_t)q * A.K;
+    const int64_t r0 = A.rel_ptr[q], n_rel = A.rel_ptr[q + 1] - r0;
+    const int64_t* rel = A.rel_ids + r0;
+    int len = A.K;
+    for (int base = 0; base < A.K; base += 64) {
+        int s = base + lane;
+        bool dead = s < A.K && row[s] < 0;
+        unsigned long long m = __ballot(dead);
+        if (m) { len = base + __ffsll((long long)m) - 1; break; }
+    }
+    for (int mi = 0; mi < A.n_metrics; ++mi) {
+        const int k = A.k[mi];
+        const int cut = k == 0 ? len : (k < len ? k : len);
+        int first = -1, hits = 0;
+        for (int base = 0; base < cut; base += 64) {
+            int s = base + lane;
+            bool r = s < cut && is_relevant(rel, n_rel, row[s]);
+            unsigned long long m = __ballot(r);
+            if (m) {
+                if (first < 0) first = base + __ffsll((long long)m) - 1;
+                hits += __popcll(m);
+            }
+        }
+        if (lane == 0) A.out[(size_t)mi * A.nq + q] = metric_value(A.code[mi], k, len, first, hits, n_rel);
+    }
+}
+
+// np.mean of each row of v [rows, n] (numpy's pairwise summation, restated: blocks of <= 128 summed with eight
+// interleaved accumulators, halves split on a multiple of 8), one thread per row -- the mean ranx.evaluate takes
+__device__ double np_block_sum(const double* a, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+__global__ void np_mean_rows_kernel(const double* v, double* out, int rows, int n) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const double* a = v + (size_t)row * n;
+    // iterative form of the recursion sum(a, n) = n <= 128 ? block : sum(a, h) + sum(a + h, n - h), h = n/2 - (n/2) % 8
+    struct Frame { int off, n, state; double left; };
+    Frame st[40];
+    int sp = 0;
+    st[0].off = 0; st[0].n = n; st[0].state = 0; st[0].left = 0.0;
+    double ret = 0.0;
+    while (sp >= 0) {
+        Frame& f = st[sp];
+        if (f.n <= 128) { ret = np_block_sum(a + f.off, f.n); --sp; continue; }
+        int h = f.n / 2; h -= h % 8;
+        if (f.state == 0) { f.state = 1; ++sp; st[sp].off = f.off; st[sp].n = h; st[sp].state = 0; }
+        else if (f.state == 1) { f.left = ret; f.state = 2; ++sp; st[sp].off = f.off + h; st[sp].n = f.n - h; st[sp].state = 0; }
+        else { ret = f.left + ret; --sp; }
+    }
+    out[row] = n > 0 ? ret / (double)n : 0.0;
+}
+
+struct FitArgs {
+    FuseArgs F;
+    const double* trials;    // [T, R] device
+    const int64_t* rel_ptr;
+    const int64_t* rel_ids;
+    double* out;             // [T, nq]
+    int T, code, k;
+};
+
+// one workgroup per query, all trials: the (id, run) sort and the normalisation happen once; a trial costs one weighted
+// sum per document and, for the relevant documents only, a count of the documents ranked in front of them
+// (fused score descending, then id ascending: the order fuse_combine_kernel writes)
+__global__ __launch_bounds__(FT) void fuse_fit_kernel(FitArgs G) {
+    const FuseArgs& A = G.F;
+    extern __shared__ uint64_t lds[];
+    uint64_t* a = lds;                       // sort keys (id, run)
+    uint64_t* b = lds + A.nsort;             // normalised scores
+    double* fs = (double*)(lds + 2 * A.nsort);        // fused score per head
+    int* hpos = (int*)(lds + 3 * A.nsort);            // sorted position of head h
+    int* rlist = hpos + A.nsort;                      // heads that are relevant
+    __shared__ double r_mean[MQ_FUSE_MAX_RUNS], r_den[MQ_FUSE_MAX_RUNS], r_fill[MQ_FUSE_MAX_RUNS], w[MQ_FUSE_MAX_RUNS];
+    __shared__ int r_has[MQ_FUSE_MAX_RUNS];
+    __shared__ int heads, nrel_heads, red_first[FT / 64], red_hits[FT / 64];
+    const int q = blockIdx.x, t = threadIdx.x;
+    if (t == 0) { heads = 0; nrel_heads = 0; }
+    if (t < A.R) {
+        const double* st = A.stats + ((size_t)t * A.nq + q) * STAT;
+        double mean = 0.0, den = 1.0;
+        if (A.norm == MQ_FUSE_NORM_GZMUV) { mean = A.moments[2 * t]; den = A.moments[2 * t + 1]; }
+        else if (A.norm == MQ_FUSE_NORM_ZMUV) { mean = st[4]; den = st[5]; }
+        r_mean[t] = mean; r_den[t] = den;
+        r_has[t] = st[0] > 0.0;
+        r_fill[t] = st[0] > 0.0 ? (A.norm == MQ_FUSE_NORM_NONE ? st[1] : (st[1] - mean) / den) : 0.0;
+    }
+    __syncthreads();
+    const int norm = A.norm;
+    load_entries(A, q, a, b, [&](int r, double s) {
+        double x = norm == MQ_FUSE_NORM_NONE ? s : (s - r_mean[r]) / r_den[r];
+        return (uint64_t)__double_as_longlong(x);
+    });
+    bitonic_pairs(a, b, A.nsort);
+    const int64_t r0 = G.rel_ptr[q], n_rel = G.rel_ptr[q + 1] - r0;
+    const int64_t* rel = G.rel_ids + r0;
+    // heads in sorted (= ascending id) order: head h sits at hpos[h]; since ids ascend with h, "id ascending" = "h ascending"
+    for (int base = 0; base < A.nsort; base += FT) {
+        const int i = base + t;
+        const bool head = a[i] != EMPTY && (i == 0 || (a[i - 1] >> RUN_BITS) != (a[i] >> RUN_BITS));
+        // stable compaction: positions before `base` are already numbered
+        unsigned long long m = __ballot(head);
+        __shared__ int wave_cnt[FT / 64];
+        if ((t & 63) == 0) wave_cnt[t >> 6] = __popcll(m);
+        __syncthreads();
+        int before = heads;
+        for (int wv = 0; wv < (t >> 6); ++wv) before += wave_cnt[wv];
+        if (head) hpos[before + __popcll(m & ((1ull << (t & 63)) - 1ull))] = i;
+        __syncthreads();
+        if (t == 0) { int tot = 0; for (int wv = 0; wv < FT / 64; ++wv) tot += wave_cnt[wv]; heads += tot; }
+        __syncthreads();
+    }
+    const int nh = heads;
+    for (int h = t; h < nh; h += FT)
+        if (is_relevant(rel, n_rel, (int64_t)(a[hpos[h]] >> RUN_BITS))) rlist[atomicAdd(&nrel_heads, 1)] = h;
+    __syncthreads();
+    const int nr = nrel_heads;
+    const int cut = G.k == 0 ? nh : (G.k < nh ? G.k : nh);
+    for (int trial = 0; trial < G.T; ++trial) {
+        if (t < A.R) w[t] = G.trials[(size_t)trial * A.R + t];
+        __syncthreads();
+        for (int h = t; h < nh; h += FT) {
+            const int i = hpos[h];
+            const uint64_t id = a[i] >> RUN_BITS;
+            int j = i;
+            double acc = 0.0;
+            for (int r = 0; r < A.R; ++r) {
+                if (j < A.nsort && a[j] == ((id << RUN_BITS) | (uint64_t)r)) {
+                    acc = acc + w[r] * __longlong_as_double((long long)b[j]);
+                    ++j;
+                } else if (A.defmin && r_has[r]) {
+                    acc = acc + w[r] * r_fill[r];
+                }
+            }
+            if (acc == 0.0) acc = 0.0;
+            fs[h] = acc;
+        }
+        __syncthreads();
+        int first = 0x7fffffff, hits = 0;
+        for (int x = t; x < nr; x += FT) {
+            const int h = rlist[x];
+            const double s = fs[h];
+            int rank = 0;
+            for (int e = 0; e < nh; ++e) {
+                const double se = fs[e];
+                rank += (se > s || (se == s && e < h)) ? 1 : 0;
+            }
+            if (rank < cut) { ++hits; first = rank < first ? rank : first; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            int of = __shfl_xor(first, o), oh = __shfl_xor(hits, o);
+            first = of < first ? of : first; hits += oh;
+        }
+        if ((t & 63) == 0) { red_first[t >> 6] = first; red_hits[t >> 6] = hits; }
+        __syncthreads();
+        if (t == 0) {
+            for (int wv = 1; wv < FT / 64; ++wv) { first = red_first[wv] < first ? red_first[wv] : first; hits += red_hits[wv]; }
+            G.out[(size_t)trial * A.nq + q] = metric_value(G.code, G.k, nh, first == 0x7fffffff ? -1 : first, hits, n_rel);
+        }
+        __syncthreads();
+    }
+}
+
 int next_pow2(int v) {
     int p = 64;
     while (p < v) p <<= 1;
@@ -304,6 +526,65 @@ extern "C" int mq_fuse_wsum_f64(const int64_t* ids_dev, const double* scores_dev
         FUSE_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(fuse_combine_kernel, dim3(nq), dim3(FT), lds, st, A);
+    FUSE_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+extern "C" int mq_run_metrics_f64(const int64_t* ids_dev, int nq, int K, const int64_t* rel_ptr_dev,
+                                  const int64_t* rel_ids_dev, int n_metrics, const int* codes_host, const int* ks_host,
+                                  double* per_query_dev, double* mean_dev, void* stream) {
+    if (!ids_dev || !rel_ptr_dev || !codes_host || !ks_host || !per_query_dev || !mean_dev) return MQ_EINVAL;
+    if (nq <= 0 || K <= 0 || n_metrics <= 0 || n_metrics > MQ_RANK_MAX_METRICS) return MQ_EINVAL;
+    MetricArgs A;
+    A.ids = ids_dev; A.rel_ptr = rel_ptr_dev; A.rel_ids = rel_ids_dev; A.out = per_query_dev;
+    A.nq = nq; A.K = K; A.n_metrics = n_metrics;
+    for (int m = 0; m < n_metrics; ++m) {
+        if (codes_host[m] < MQ_RANK_METRIC_MRR || codes_host[m] > MQ_RANK_METRIC_RECALL || ks_host[m] < 0) return MQ_EINVAL;
+        A.code[m] = codes_host[m]; A.k[m] = ks_host[m];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(run_metrics_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, A);
+    FUSE_HIP(hipGetLastError());
+    hipLaunchKernelGGL(np_mean_rows_kernel, dim3((n_metrics + 63) / 64), dim3(64), 0, st, per_query_dev, mean_dev, n_metrics, nq);
+    FUSE_HIP(hipGetLastError());
+    return MQ_OK;
+}
+
+extern "C" int mq_fuse_fit_wsum_f64(const int64_t* ids_dev, const double* scores_dev, int n_runs, int nq, int K,
+                                    const double* trials_dev, int n_trials, int norm, int defmin,
+                                    const int64_t* rel_ptr_dev, const int64_t* rel_ids_dev, int metric, int metric_k,
+                                    double* per_query_dev, double* mean_dev, void* ws_dev, size_t ws_bytes, void* stream) {
+    if (!ids_dev || !scores_dev || !trials_dev || !rel_ptr_dev || !per_query_dev || !mean_dev || !ws_dev) return MQ_EINVAL;
+    if (n_runs <= 0 || n_runs > MQ_FUSE_MAX_RUNS || nq <= 0 || K <= 0 || n_trials <= 0 || metric_k < 0) return MQ_EINVAL;
+    if (metric < MQ_RANK_METRIC_MRR || metric > MQ_RANK_METRIC_RECALL) return MQ_EINVAL;
+    if ((int64_t)n_runs * K > FCAP) return MQ_EUNSUPPORTED;
+    if (norm != MQ_FUSE_NORM_NONE && norm != MQ_FUSE_NORM_GZMUV && norm != MQ_FUSE_NORM_ZMUV) return MQ_EINVAL;
+    if (ws_bytes < mq_fuse_workspace_bytes(n_runs, nq, K)) return MQ_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    FitArgs G;
+    FuseArgs& A = G.F;
+    A.ids = ids_dev; A.scores = scores_dev;
+    A.stats = (double*)ws_dev;
+    A.moments = A.stats + (size_t)n_runs * nq * STAT;
+    A.out_ids = nullptr; A.out_scores = nullptr; A.out_count = nullptr;
+    A.R = n_runs; A.nq = nq; A.K = K; A.nsort = next_pow2(n_runs * K); A.norm = norm; A.defmin = defmin ? 1 : 0;
+    if (A.nsort < FT) A.nsort = FT;
+    for (int r = 0; r < MQ_FUSE_MAX_RUNS; ++r) A.w[r] = 0.0;
+    G.trials = trials_dev; G.rel_ptr = rel_ptr_dev; G.rel_ids = rel_ids_dev; G.out = per_query_dev;
+    G.T = n_trials; G.code = metric; G.k = metric_k;
+    const size_t lds = (size_t)A.nsort * 2 * sizeof(uint64_t);
+    const size_t lds_fit = (size_t)A.nsort * (3 * sizeof(uint64_t) + 2 * sizeof(int));
+    MQ_DYNAMIC_LDS_WITH(FUSE_HIP, mq_detail::LDS_PER_CU, fuse_stats_kernel);
+    MQ_DYNAMIC_LDS_WITH(FUSE_HIP, mq_detail::LDS_PER_CU, fuse_fit_kernel);
+    hipLaunchKernelGGL(fuse_stats_kernel, dim3(nq), dim3(FT), lds, st, A);
+    FUSE_HIP(hipGetLastError());
+    if (norm == MQ_FUSE_NORM_GZMUV) {
+        hipLaunchKernelGGL(fuse_moments_kernel, dim3(n_runs), dim3(1024), 0, st, A);
+        FUSE_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(fuse_fit_kernel, dim3(nq), dim3(FT), lds_fit, st, G);
+    FUSE_HIP(hipGetLastError());
+    hipLaunchKernelGGL(np_mean_rows_kernel, dim3((n_trials + 63) / 64), dim3(64), 0, st, per_query_dev, mean_dev, n_trials, nq);
     FUSE_HIP(hipGetLastError());
     return MQ_OK;
 }

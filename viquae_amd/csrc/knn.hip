@@ -1171,7 +1171,7 @@ int launch_small_scan(const SmallArgs& sa, int nkb, int S, hipStream_t st) {
 
 extern "C" {
 
-const char* mq_version(void) { return "meerqat_hip 0.1 (gfx950)"; }
+const char* mq_version(void) { return "meerqat_hip 0.6 (gfx950)"; }
 
 const char* mq_strerror(int code) {
     switch (code) {

@@ -8,8 +8,11 @@ fusion -- runs on the MI355X (``viquae_amd/csrc/fuse.hip`` through ``mq_fuse_wsu
 padded ``[n_runs, nq, K]`` tables of (integer document id, f64 score), one workgroup fuses one query.  There is
 no CPU fallback: without the HIP library and a GPU the call raises.
 
-What differs from the reference: ``fit`` (ranx's ``optimize_fusion`` grid search driven by a ranx metric) is
-evaluation tooling outside this build and needs ``ranx``; ``method`` other than ``"wsum"`` and ranx norms other
+``Fusion.fit`` (:193-217, ranx's ``optimize_fusion`` for ``wsum``: a grid of weights in steps of 0.1, each trial
+fused and scored by a rank metric) runs on the device too, all trials in one launch (``mq_fuse_fit_wsum_f64``); its trial
+set and tie rule restate ranx's published code -- parity unpinned vs ranx, which is not installed.
+
+What differs from the reference: ``method`` other than ``"wsum"`` and ranx norms other
 than ``None`` / ``"zmuv"`` are not implemented; documents with EQUAL fused scores are ordered by ascending
 document id (the reference leaves that order to ranx's sort).  Results are plain ``{q_id: {doc_id: score}}``
 dicts, best first (wrapped in ``ranx.Run`` when ranx is importable).
@@ -148,9 +151,70 @@ def fuse_runs(runs, weights, norm="gzmuv", defmin=False, device="cuda:0"):
     return tables_to_run(q_ids, doc_names, *fuse_tables(ids, scores, weights, norm=norm, defmin=defmin), as_arrays=as_arrays)
 
 
+def wsum_trials(n_runs, step=0.1):
+    """ranx's trial set for ``wsum`` (``fusion/wsum.py`` + ``fusion/common.py``, restated as published -- parity unpinned vs
+    ranx, which is not installed): candidate weights ``round(x, 2)`` for x in ``np.arange(0, 1 + step, step)``, a trial is every
+    tuple of ``itertools.product`` whose Python ``sum`` is EXACTLY 1.0 (so tuples whose floating-point sum misses 1.0 -- 4 of 66
+    for three runs, 30 of 286 for four -- are not tried, as there)."""
+    import itertools
+    weights = [round(float(x), 2) for x in np.arange(0, 1 + step, step)]
+    return [seq for seq in itertools.product(*[weights] * n_runs) if sum(seq) == 1.0]
+
+
+def fit_tables(ids, scores, trials, rel_ptr, rel_ids, metric_code, metric_k, norm="gzmuv", defmin=False):
+    """Every trial fused and scored on the device.  ``ids`` / ``scores`` [n_runs, nq, K] as for ``fuse_tables``, ``trials`` f64
+    [T, n_runs], qrels as CSR (``viquae_amd.ir.metrics.qrels_to_csr``) -> (mean f64 [T], per-query f64 [T, nq]), on the device."""
+    if norm not in NORM_CODES:
+        raise NotImplementedError(f"norm '{norm}': only None, 'gzmuv' and 'zmuv' run on the device")
+    lib = _lib.load()
+    _lib.require_gpu()
+    if ids.dim() != 3 or ids.shape != scores.shape:
+        raise ValueError("ids and scores must both be [n_runs, nq, K]")
+    n_runs, nq, K = ids.shape
+    if trials.dim() != 2 or trials.shape[1] != n_runs:
+        raise ValueError(f"trials must be [T, {n_runs}]")
+    dev = ids.device
+    ids = ids.to(torch.int64).contiguous()
+    scores = scores.to(torch.float64).contiguous()
+    trials = trials.to(device=dev, dtype=torch.float64).contiguous()
+    T = trials.shape[0]
+    per_q = torch.empty((T, nq), dtype=torch.float64, device=dev)
+    mean = torch.empty((T,), dtype=torch.float64, device=dev)
+    if nq == 0 or T == 0:
+        return mean.zero_(), per_q
+    ws_bytes = lib.mq_fuse_workspace_bytes(n_runs, nq, K)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.mq_fuse_fit_wsum_f64(ids.data_ptr(), scores.data_ptr(), n_runs, nq, K, trials.data_ptr(), T,
+                                            NORM_CODES[norm], int(bool(defmin)), rel_ptr.data_ptr(), rel_ids.data_ptr(),
+                                            int(metric_code), int(metric_k), per_q.data_ptr(), mean.data_ptr(), ws.data_ptr(),
+                                            ws_bytes, stream), "mq_fuse_fit_wsum_f64")
+    return mean, per_q
+
+
+def fit_wsum(runs, qrels, norm="gzmuv", defmin=False, metric="mrr@100", step=0.1, device="cuda:0"):
+    """-> (``{"weights": [...]}``, [(weights, score)] in trial order): the first trial with the best score wins."""
+    from .metrics import parse_metric, qrels_to_csr
+    code, k = parse_metric(metric)
+    runs = [_as_dict(run) for run in runs]
+    q_ids, doc_names, ids, scores = runs_to_tables(runs, device)
+    lookup = None if doc_names is None else {d: i for i, d in enumerate(doc_names)}
+    ptr, rel = qrels_to_csr(qrels, q_ids, lookup)
+    trials = wsum_trials(len(runs), step)
+    if not trials:
+        raise ValueError(f"no trial for {len(runs)} runs at step {step}")
+    dev = torch.device(device)
+    mean, _ = fit_tables(ids, scores, torch.tensor(trials, dtype=torch.float64), torch.from_numpy(ptr).to(dev),
+                         torch.from_numpy(rel if rel.size else np.zeros(1, np.int64)).to(dev), code, k, norm=norm, defmin=defmin)
+    mean = mean.cpu().numpy()
+    best = int(np.argmax(mean))   # np.argmax: the first of equal maxima
+    return {"weights": list(trials[best])}, [(list(w), float(s)) for w, s in zip(trials, mean)]
+
+
 class Fusion:
     """Same constructor as the reference's (meerqat/ir/fuse.py:158-186).  ``runs``: dicts, ranx ``Run`` objects or
-    paths to JSON runs; ``qrels`` is only used by the ranx-backed metric report / ``fit``."""
+    paths to JSON runs; ``qrels`` (a dict, a ranx ``Qrels`` or a path) is used by ``fit`` and by the metric line of ``test``."""
 
     def __init__(self, qrels=None, runs=None, norm="zmuv", method="wsum", output=None, defmin=False, device="cuda:0"):
         self.qrels = qrels
@@ -164,13 +228,32 @@ class Fusion:
             output.mkdir(exist_ok=True)
         self.output = output
 
-    def fit(self, metric="mrr@100"):
-        try:
-            import ranx  # noqa: F401
-        except ImportError as e:
-            raise ImportError("Fusion.fit is ranx.optimize_fusion (a metric-driven grid search over the weights); "
-                              "it is evaluation tooling outside this build and needs ranx installed") from e
-        raise NotImplementedError("Fusion.fit: run the reference's fit, then pass best_params to Fusion.test here")
+    def fit(self, metric="mrr@100", step=0.1):
+        """Finds the best fusion weights (meerqat/ir/fuse.py:193-217 -> ``ranx.optimize_fusion(method="wsum")``): every trial
+        of ranx's grid is fused and scored on the device in one launch (``mq_fuse_fit_wsum_f64``); the first trial that reaches
+        the best ``metric`` wins and is written to ``{norm}_{method}_best_params.yaml`` like the reference does.  Returns
+        ``{(norm, method): (best_params, report)}`` (the reference returns None and prints)."""
+        import yaml
+        from .metrics import parse_metric
+        norms = [self.norm] if self.norm is None or isinstance(self.norm, str) else self.norm
+        methods = [self.method] if self.method is None or isinstance(self.method, str) else self.method
+        if self.qrels is None:
+            raise ValueError("Fusion.fit needs qrels")
+        out = {}
+        for norm in norms:
+            for method in methods:
+                if method != "wsum":
+                    raise NotImplementedError(f"method '{method}': only 'wsum' (the shipped configs' method) is implemented")
+                best_params, report = fit_wsum(self.runs, _as_dict(self.qrels), norm=norm, defmin=self.defmin,
+                                               metric=metric, step=step, device=self.device)
+                lines = "\n".join(f"  {tuple(w)}: {s:.6f}" for w, s in report)
+                print(f"Norm: {norm}, Method: {method}. Best parameters: {best_params}.\n{metric} of every trial:\n{lines}")
+                if self.output is not None:
+                    with open(self.output / f"{norm}_{method}_best_params.yaml", "wt") as file:
+                        yaml.dump(json.loads(json.dumps(best_params)), file)
+                out[(norm, method)] = (best_params, report)
+        self.best = out
+        return out
 
     def test(self, best_params, metrics=None):
         if self.method != "wsum":
@@ -179,14 +262,14 @@ class Fusion:
         fused = fuse_runs(self.runs, weights, norm=self.norm, defmin=self.defmin, device=self.device)
         if self.output is not None:
             dump_run(fused, self.output / "test_run.json")
+        if self.qrels is not None:
+            from .metrics import evaluate
+            if metrics is None:
+                metrics = ["mrr@100", "precision@1", "precision@20", "hit_rate@20"]
+            self.test_scores = evaluate(_as_dict(self.qrels), fused, metrics, device=self.device)
+            print(" & ".join(f"{m}: {v:.3f}" for m, v in self.test_scores.items()))
         try:
             import ranx
         except ImportError:
             return fused
-        combined = ranx.Run(fused.to_dict() if isinstance(fused, ArrayRun) else fused, name="fusion")
-        if self.qrels is not None:
-            if metrics is None:
-                metrics = ["mrr@100", "precision@1", "precision@20", "hit_rate@20"]
-            qrels = self.qrels if isinstance(self.qrels, ranx.Qrels) else ranx.Qrels(_as_dict(self.qrels))
-            print(ranx.evaluate(qrels, combined, metrics))
-        return combined
+        return ranx.Run(fused.to_dict() if isinstance(fused, ArrayRun) else fused, name="fusion")

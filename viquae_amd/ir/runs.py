@@ -22,6 +22,24 @@ import numpy as np
 MAX_PARTS = 32  # MQ_RUN_JSON_MAX_PARTS
 
 
+def _json_key(q):
+    """A question id as the JSON object key ``json.dump`` writes for it: str as is; int / float / bool / None coerced the way
+    ``json.encoder`` coerces dict keys (``{5: ...}`` -> ``"5"``, ``True`` -> ``"true"``, ``None`` -> ``"null"``)."""
+    if isinstance(q, str):
+        return json.dumps(q)
+    if q is True:
+        return '"true"'
+    if q is False:
+        return '"false"'
+    if q is None:
+        return '"null"'
+    if isinstance(q, int):
+        return json.dumps(int.__repr__(q))
+    if isinstance(q, float):
+        return json.dumps(json.dumps(q))      # float.__repr__, or NaN / Infinity as the encoder spells them
+    raise TypeError(f"keys must be str, int, float, bool or None, not {type(q).__name__}")
+
+
 class ArrayRun(MutableMapping):
     def __init__(self, mapping=None):
         self._entries = {}   # q_id -> dict | (block number, row)
@@ -158,13 +176,13 @@ class ArrayRun(MutableMapping):
                 chunks.append(b", ")
             sep = True
             if span[0] == "dicts":
-                chunks.append(", ".join(f"{json.dumps(q)}: {json.dumps(d)}" for q, d in span[1]).encode())
+                chunks.append(", ".join(f"{_json_key(q)}: {json.dumps(d)}" for q, d in span[1]).encode())
                 continue
             _, b, r0, q_ids = span
             ids, scores, _ = self._blocks[b]
             n = len(q_ids)
             ids, scores = ids[r0:r0 + n], scores[r0:r0 + n]
-            enc = [json.dumps(q).encode() for q in q_ids]
+            enc = [_json_key(q).encode() for q in q_ids]
             off = np.zeros(n + 1, dtype=np.int64)
             np.cumsum([len(x) for x in enc], out=off[1:])
             blob = b"".join(enc)

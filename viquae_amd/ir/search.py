@@ -123,6 +123,11 @@ class KnowledgeBase:
             index_name = column
         if kind != IndexKind.FAISS:
             raise NotImplementedError(f"{kind} indexes (sparse retrieval) are outside the MI355X build")
+        if index_kwarg.get("es"):
+            # the shipped BM25 configs (experiments/ir/viquae/bm25/config.json, bm25+arcface+clip+imagenet/config_*.json) still
+            # say `"es": true`, the spelling `kind: "ES"` replaced: an Elasticsearch index over a TEXT column, not a dense one
+            raise NotImplementedError(f"index '{index_name}' is an Elasticsearch (BM25) index ('es': true): sparse retrieval is "
+                                      "outside the MI355X build (dense FAISS-kind only)")
         for legacy in LEGACY_INDEX_KEYS:
             index_kwarg.pop(legacy, None)
         do_L2norm = self.add_or_load_faiss_index(column, index_name=index_name, **index_kwarg)

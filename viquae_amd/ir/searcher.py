@@ -8,7 +8,8 @@ strings), the article->passage fan-out through ``index_mapping`` with the 1e-8 p
 relevance judgement of retrieved passages against the reference KB (:442-457, ``find_relevant`` =
 meerqat/ir/metrics.py:79-124 for string answers).
 What differs: no Elasticsearch client is constructed (sparse kinds are outside this build); ``ranx`` is
-optional -- without it ``dataset_search`` returns plain dicts and skips the metric report; numerical
+not needed -- the metric report (``metrics.json`` / ``metrics.tex``, scores without ranx's statistical tests) is computed from
+the result arrays on the device (``viquae_amd/ir/metrics.py``), and so is ``Fusion.fit``; numerical
 (InfoSeek) question types are not judged here.  With several indexes the runs are fused like the reference
 does (:514-524) through ``viquae_amd.ir.fuse.Fusion`` (HIP kernels); the fused run is ``searcher.fusion``.
 
@@ -66,7 +67,9 @@ class PassageTexts:
         missing = [i for i in ids if i not in texts]
         if missing:
             if len(texts) + len(missing) > self.capacity:
+                # evicting drops ids of THIS request that were cached too: fetch the whole request again
                 texts.clear()
+                missing = list(dict.fromkeys(ids))
             if self._column is not None:
                 raw = self._column.take(missing).to_pylist()
             else:
@@ -220,6 +223,8 @@ class Searcher:
         self.fusion_kwargs = fusion_kwargs
         self.metrics_kwargs = dict(metrics=["mrr@100", "precision@1", "precision@20", "hit_rate@20"])
         self.metrics_kwargs.update(metrics_kwargs)
+        # where the metric report and the late fusion run: this process's GPU (one process per GPU under torch.distributed.run)
+        self.metric_device = f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
         self._csr = {}
 
     @property
@@ -493,9 +498,9 @@ class ArrowQueryColumns:
         return np.ascontiguousarray(flat.reshape(n, -1), dtype=np.float32)
 
 
-def dataset_search(dataset, k=100, metric_save_path=None, map_kwargs={}, **kwargs):
-    """Searcher over ``dataset.map``; saves qrels / runs (JSON) under ``metric_save_path``; with ``ranx`` installed
-    also computes and saves the metric report like the reference."""
+def dataset_search(dataset, k=100, metric_save_path=None, map_kwargs={}, report=True, **kwargs):
+    """Searcher over ``dataset.map``; saves qrels / runs (JSON) under ``metric_save_path``, computes and saves the
+    metric report like the reference (meerqat/ir/search.py:500-512), then runs the fusion subcommand (``fit`` or ``test``)."""
     searcher = Searcher(k=k, **kwargs)
     queries = ArrowQueryColumns(dataset, searcher)
     # the mapped dataset is not kept (neither does the reference keep it): no point in fingerprinting the searcher
@@ -538,24 +543,26 @@ def dataset_search(dataset, k=100, metric_save_path=None, map_kwargs={}, **kwarg
             json.dump(searcher.qnonrels, file)
         for index_name, run in searcher.runs.items():
             dump_run(run, metric_save_path / f"{index_name}.json")  # straight from the result arrays (mq_format_run_json)
-    try:
-        import ranx
-    except ImportError:
-        ranx = None
-    if ranx is not None:
-        qrels = ranx.Qrels(searcher.qrels)
-        runs = [ranx.Run(run.to_dict() if isinstance(run, ArrayRun) else run, name=name) for name, run in searcher.runs.items()]
-        report = ranx.compare(qrels, runs=runs, **searcher.metrics_kwargs)
-        print(report)
+    # the metric report (reference: search.py:500-512, ranx.compare) from the result arrays, on the device; scores only, no
+    # statistical tests (viquae_amd/ir/metrics.py)
+    # `report=False` (extra key) skips it: the search and the run files are then all the job does
+    searcher.report = None
+    if report:
+        from .metrics import compare
+        searcher.report = compare(searcher.qrels, searcher.runs, device=searcher.metric_device, **searcher.metrics_kwargs)
+        print(searcher.report)
         if metric_save_path is not None:
-            report.save(metric_save_path / "metrics.json")
+            searcher.report.save(metric_save_path / "metrics.json")
+            with open(metric_save_path / "metrics.tex", "wt") as file:
+                file.write(searcher.report.to_latex())
     # late fusion of the searches (reference: search.py:514-524), on the device
     if searcher.do_fusion:
         from .fuse import Fusion
         fusion_kwargs = dict(searcher.fusion_kwargs)
         subcommand = fusion_kwargs.pop("subcommand")
         subcommand_kwargs = fusion_kwargs.pop("subcommand_kwargs", {})
-        fuser = Fusion(qrels=searcher.qrels, runs=list(searcher.runs.values()), output=metric_save_path, **fusion_kwargs)
+        fuser = Fusion(qrels=searcher.qrels, runs=list(searcher.runs.values()), output=metric_save_path,
+                       **{"device": searcher.metric_device, **fusion_kwargs})
         searcher.fusion = getattr(fuser, subcommand)(**subcommand_kwargs)
     return searcher
 

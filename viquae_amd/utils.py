@@ -79,6 +79,41 @@ def _describe(obj, h):
     h.update(Hasher.hash(obj).encode())
 
 
+_CODE_FINGERPRINT = None
+
+
+def code_fingerprint():
+    """What computes the embeddings, as a string: the library's version and a hash of the built ``libmeerqat_hip.so`` plus the
+    Python sources between ``Dataset.map`` and the kernels (`datasets` hashes the mapped function's code; without
+    this a rebuilt library -- an arithmetic fix in encoder.hip -- would silently serve the stale cached column).  To force a
+    recompute regardless: ``map_kwargs={"load_from_cache_file": False}`` or a ``new_fingerprint`` of your own."""
+    global _CODE_FINGERPRINT
+    if _CODE_FINGERPRINT is None:
+        import hashlib
+        import os
+        from . import _lib
+        h = hashlib.sha256()
+        here = os.path.dirname(os.path.abspath(__file__))
+        files = [_lib.lib_path()] + [os.path.join(here, f) for f in ("pipeline.py", "encoders.py", "arcface.py", "ir/embedding.py",
+                                                                      "image/embedding.py", "image/preprocess.py")]
+        for path in files:
+            try:
+                with open(path, "rb") as file:
+                    while True:
+                        block = file.read(1 << 20)
+                        if not block:
+                            break
+                        h.update(block)
+            except OSError:
+                h.update(f"missing:{os.path.basename(str(path))}".encode())
+        try:
+            version = _lib.load().mq_version().decode()
+        except Exception:
+            version = "library not loaded"
+        _CODE_FINGERPRINT = f"{version}:{h.hexdigest()[:16]}"
+    return _CODE_FINGERPRINT
+
+
 def job_fingerprint(dataset, what, **parts):
     """A DETERMINISTIC ``new_fingerprint`` for ``Dataset.map`` of an embedding job (ADVICE r3 / VERDICT r4): the reference's
     ``dataset.map(embed, fn_kwargs=...)`` (meerqat/ir/embedding.py:272, meerqat/image/embedding.py:183) lets ``datasets`` hash the
@@ -89,5 +124,6 @@ def job_fingerprint(dataset, what, **parts):
     import hashlib
     h = hashlib.sha256()
     h.update(f"viquae_amd:{what}:{getattr(dataset, '_fingerprint', None)}".encode())
+    h.update(code_fingerprint().encode())
     _describe(parts, h)
     return h.hexdigest()[:16]
