@@ -79,8 +79,10 @@ def test_shipped_search_config_runs_to_the_end(rel, tmp_path, monkeypatch):
         (got_best, got_trials), = searcher.fusion.values()
         assert [w for w, _ in got_trials] == [list(w) for w, _ in trials]
         assert np.abs(np.array([s for _, s in got_trials]) - np.array([s for _, s in trials])).max() <= 1e-12
-        # the informative index must carry the weight
-        assert best["weights"][world["index_names"].index(world["informative"])] >= 0.5
+        # the informative index must carry weight (the first trial that reaches the best score wins: with planted passages many do),
+        # and the search cannot end below the best single run (the unit vectors are trials)
+        assert best["weights"][world["index_names"].index(world["informative"])] > 0
+        assert max(s for _, s in got_trials) >= max(report[name]["scores"]["mrr@100"] for name in runs) - 1e-12
 
 
 def _random_runs(seed, nq, n_runs, k, n_docs, empty_every=0):
