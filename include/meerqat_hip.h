@@ -270,6 +270,19 @@ int mq_topk_merge_records_f32(const void *records_dev, int nshards, int nq, int 
 #define MQ_EPI_BIAS_QUICKGELU 3 /* C = x*sigmoid(1.702x), x=A.W^T+b (CLIP MLP fc1)                            */
 #define MQ_EPI_BIAS_RESIDUAL 4  /* C = A.W^T + b + R               (BertSelfOutput/BertOutput dense + input)  */
 
+/* A/B switch of the split-bf16 GEMM kernels (both give bit-identical outputs).  First value from the environment, read ONCE
+ * (MQ_GEMM_WIDE); a running process flips it with mq_gemm_set_option (atomic), which returns the previous value (MQ_EINVAL for an
+ * unknown key).
+ *   MQ_GEMM_OPT_WIDE   1 (default): eight waves of 128 x 64 outputs, two per SIMD, fragments prefetched across the mid-step
+ *                      barrier, a two-step LDS-DMA lookahead that runs across tile boundaries (csrc/gemm_x3w.inc, round 6);
+ *                      0: sixteen waves of 64 x 64 (gemm_nt_x3s_kernel, rounds 2-5).
+ *   MQ_GEMM_OPT_STAGGER  (eight-wave kernel) start offset between the four phases of workgroups, in units of 1024 shader
+ *                      clocks; 0 = all workgroups start together.  Environment: MQ_GEMM_STAGGER */
+#define MQ_GEMM_OPT_WIDE 0
+#define MQ_GEMM_OPT_STAGGER 1
+#define MQ_GEMM_OPT_COUNT 2
+int mq_gemm_set_option(int key, int value);
+
 /* nn.Linear with a fused epilogue: A [M,K], W [N,K], bias [N] or NULL, R [M,N] or NULL, C [M,N].
  * K must be a multiple of 16; A and W 16-byte aligned. */
 int mq_gemm_nt_f32(const float *A_dev, const float *W_dev, const float *bias_dev, const float *residual_dev,

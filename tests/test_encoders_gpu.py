@@ -755,3 +755,44 @@ def test_pair_outputs_need_32_column_tiles():
     u = torch.zeros(4 * 1024, dtype=torch.int16, device="cuda")
     rc = lib.mq_layernorm_split_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), None, u.data_ptr(), u.data_ptr(), 4, 1022, 1e-5, None)
     assert rc == -4  # MQ_EUNSUPPORTED
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 6: the eight-wave 128 x 64 GEMM (csrc/gemm_x3w.inc) against the sixteen-wave one -- the same bits
+# ---------------------------------------------------------------------------------------------------
+from viquae_amd import encoders as E  # noqa: E402  (EPI_* in the parametrisation below)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 768), (300, 320, 96), (1000, 2304, 768), (257, 64, 3072),
+                                   (2048, 768, 3072), (77, 33 * 32, 128), (4096, 512, 768)])
+@pytest.mark.parametrize("epi,res,osp,tiled", [(E.EPI_NONE, None, False, True), (E.EPI_BIAS, None, False, True),
+                                                 (E.EPI_BIAS, None, True, False), (E.EPI_BIAS_GELU, None, True, True),
+                                                 (E.EPI_BIAS_QUICKGELU, None, False, True), (E.EPI_BIAS_RESIDUAL, "f32", False, True),
+                                                 (E.EPI_BIAS_RESIDUAL, "pair", False, True), (E.EPI_BIAS_RESIDUAL, "pair", True, True),
+                                                 (E.EPI_BIAS_RESIDUAL, "f32", True, False)])
+def test_wide_wave_gemm_is_bit_identical_to_the_sixteen_wave_gemm(M, N, K, epi, res, osp, tiled):
+    from viquae_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((M, K), generator=g, device="cuda") * 0.7
+    w = torch.randn((N, K), generator=g, device="cuda") * 0.05
+    b = torch.randn((N,), generator=g, device="cuda")
+    r = None
+    if res is not None:
+        r = torch.randn((M, N), generator=g, device="cuda")
+        if res == "pair":
+            r = E.SplitAct(*E.split_bf16(r))
+    asp = E.SplitAct(*E.split_bf16(a))
+    wsp = E.split_bf16_tiled(w) if tiled else E.split_bf16(w)
+    outs = []
+    for wide in (1, 0):
+        with _lib.gemm_option(_lib.GEMM_OPT_WIDE, wide):
+            c = E.gemm_nt(asp, w, b if epi != E.EPI_NONE else None, r, epi, wsplit=wsp, out_split=osp)
+        torch.cuda.synchronize()
+        outs.append(tuple(t.clone() for t in c.rowmajor()) if osp else (c.clone(),))   # rowmajor(): the M real rows of a pair
+    for x, y in zip(*outs):
+        assert torch.equal(x.view(torch.int16 if osp else torch.int32), y.view(torch.int16 if osp else torch.int32))
+    # and against fp64 (fp32-class accuracy of the three products)
+    if not osp and epi == E.EPI_BIAS:
+        ref = (a.double() @ w.double().T + b.double())
+        scale = (a.abs().double() @ w.abs().double().T).max().item()
+        assert (outs[0][0].double() - ref).abs().max().item() < 3e-5 * scale

@@ -90,6 +90,7 @@ SIGNATURES = {
     "mq_fuse_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "mq_fuse_wsum_f64": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_sz,
                                  c_ptr]),
+    "mq_gemm_set_option": (c_int, [c_int, c_int]),
     "mq_run_metrics_f64": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mq_fuse_fit_wsum_f64": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_int,
                                      c_int, c_ptr, c_ptr, c_ptr, c_sz, c_ptr]),
@@ -98,6 +99,24 @@ SIGNATURES = {
 
 
 KNN_OPT_SMALL_SCAN, KNN_OPT_SMALL_MIN_TILES, KNN_OPT_PARTITIONS, KNN_OPT_SMALL_WAVES = 0, 1, 2, 3  # MQ_KNN_OPT_* (include/meerqat_hip.h)
+
+
+GEMM_OPT_WIDE, GEMM_OPT_STAGGER = 0, 1  # MQ_GEMM_OPT_*
+
+
+class gemm_option:
+    """``with _lib.gemm_option(GEMM_OPT_WIDE, 0): ...`` -- A/B switch of the split-bf16 GEMM kernels for the block."""
+
+    def __init__(self, key, value):
+        self.key, self.value = key, value
+
+    def __enter__(self):
+        self.old = load().mq_gemm_set_option(self.key, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        load().mq_gemm_set_option(self.key, self.old)
+        return False
 
 
 class knn_option:

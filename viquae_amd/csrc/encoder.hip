@@ -17,6 +17,8 @@
 #include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 
 #include "../../include/meerqat_hip.h"
 #include "launch_attr.h"
@@ -599,6 +601,8 @@ __global__ __launch_bounds__(1024) void gemm_nt_x3s_kernel(const unsigned short*
     cur = nxt;
     }  // tiles
 }
+
+#include "gemm_x3w.inc"
 
 template <int EPI>
 __global__ __launch_bounds__(1024) void gemm_nt_x3_kernel(const float* __restrict__ A, const unsigned short* __restrict__ Wh,
@@ -1318,6 +1322,19 @@ __global__ __launch_bounds__(256) void clip_eos_pool_ln_kernel(const float* __re
 // TFLOP/s) and kept the plain one; with the operands stored tile by tile (round 3) the persistent launch is ahead on every
 // shape (tools/bench_gemm_shapes.py: QKV 1.982 -> 1.972 ms, out-proj 0.725 -> 0.699, FFN1 2.616 -> 2.586, FFN2 2.357 -> 2.324) and
 // on whole forwards (DPR 2048 x 100 104.0 -> 102.4 ms, pad-to-256 139.2 -> 137.8 ms).
+// MQ_GEMM_OPT_WIDE (mq_gemm_set_option; initial value from MQ_GEMM_WIDE in the environment, read once): 1 = the eight-wave
+// 128 x 64 kernel (gemm_x3w.inc, the default), 0 = gemm_nt_x3s_kernel (16 waves of 64 x 64).  Bit-identical results either way.
+std::atomic<int> g_gemm_opt[MQ_GEMM_OPT_COUNT];
+std::once_flag g_gemm_opt_once;
+void gemm_opt_init() {
+    std::call_once(g_gemm_opt_once, [] {
+        const char* e = getenv("MQ_GEMM_WIDE");
+        g_gemm_opt[MQ_GEMM_OPT_WIDE].store(e ? (atoi(e) != 0) : 1);
+        e = getenv("MQ_GEMM_STAGGER");
+        g_gemm_opt[MQ_GEMM_OPT_STAGGER].store(e ? atoi(e) : 0);
+    });
+}
+
 int gemm_persistent_wgs() {
     static const int wgs = [] {
         const char* e = getenv("MQ_GEMM_WGS");
@@ -1433,8 +1450,23 @@ static int gemm_x3s_launch(const uint16_t* Ah_dev, const uint16_t* Al_dev, const
     const int ntiles = ((ntm + 7) & ~7) * ntn;  // tile space padded to 8 row blocks (XCD placement, see the kernel)
     const dim3 grid((unsigned)(persist > 0 && ntiles > persist ? persist : ntiles), (unsigned)nsplit), block(1024);
     hipStream_t st = (hipStream_t)stream;
-#define MQ_LAUNCH2(E, S)                                                                                              \
+    gemm_opt_init();
+    const bool wide = g_gemm_opt[MQ_GEMM_OPT_WIDE].load() != 0 && (N & 3) == 0;  // its epilogue moves four consecutive columns per lane
+    const dim3 block_w(512);
+#define MQ_LAUNCHW(E, S, P)                                                                                            \
     {                                                                                                                 \
+        MQ_DYNAMIC_LDS_WITH(ENC_HIP, XW_LDS_BYTES, gemm_nt_x3w_kernel<E, S, P>); \
+        hipLaunchKernelGGL((gemm_nt_x3w_kernel<E, S, P>), grid, block_w, XW_LDS_BYTES, st, (const unsigned short*)Ah_dev,  \
+                           (const unsigned short*)Al_dev, (const unsigned short*)Wh_dev, (const unsigned short*)Wl_dev, \
+                           bias_dev, residual_dev, C_dev, (unsigned short*)Ch_dev, (unsigned short*)Cl_dev, M, N, K, ntm, ntn, wt, nsplit, \
+                           (const unsigned short*)residual_lo_dev, g_gemm_opt[MQ_GEMM_OPT_STAGGER].load()); \
+    }
+#define MQ_LAUNCH2(E, S)                                                                                              \
+    if (wide && E == EPI_BIAS_RESIDUAL && residual_lo_dev) {                                                          \
+        MQ_LAUNCHW(E, S, (E == EPI_BIAS_RESIDUAL))                                                                     \
+    } else if (wide) {                                                                                                \
+        MQ_LAUNCHW(E, S, false)                                                                                        \
+    } else {                                                                                                          \
         MQ_DYNAMIC_LDS_WITH(ENC_HIP, XS_LDS_BYTES, gemm_nt_x3s_kernel<E, S>); \
         hipLaunchKernelGGL((gemm_nt_x3s_kernel<E, S>), grid, block, XS_LDS_BYTES, st, (const unsigned short*)Ah_dev,    \
                            (const unsigned short*)Al_dev, (const unsigned short*)Wh_dev, (const unsigned short*)Wl_dev, \
@@ -1454,8 +1486,15 @@ static int gemm_x3s_launch(const uint16_t* Ah_dev, const uint16_t* Al_dev, const
     }
 #undef MQ_LAUNCH
 #undef MQ_LAUNCH2
+#undef MQ_LAUNCHW
     ENC_HIP(hipGetLastError());
     return MQ_OK;
+}
+
+int mq_gemm_set_option(int which, int value) {
+    if (which < 0 || which >= MQ_GEMM_OPT_COUNT) return MQ_EINVAL;
+    gemm_opt_init();
+    return g_gemm_opt[which].exchange(value);
 }
 
 int mq_gemm_nt_bf16x3s_f32(const uint16_t* Ah_dev, const uint16_t* Al_dev, const uint16_t* Wh_dev, const uint16_t* Wl_dev,
