@@ -86,7 +86,10 @@ def test_not_served_cases_keep_the_tile_kernel():
     assert ip.scan_kind(256, 100) == "stream" and ip.scan_kind(257, 100) == "tile"    # more than one query tile
     assert ip.scan_kind(256, 129) == "tile"                                            # k beyond the fused selection
     assert ip.scan_kind(10, 300) == "tile" and ip.scan_kind(10, 1800) == "none"        # k beyond the screen: row ranges (round 4) / exact rounds
-    assert l2.scan_kind(256, 100) == "tile"                                            # d = 768 + the two L2 columns: 13 K blocks
+    assert l2.scan_kind(256, 100) == "stream"                                          # d = 768 + the two L2 columns = 13 K blocks: the row term travels as fp32 (round 6)
+    from viquae_amd import _lib
+    with _lib.knn_option(_lib.KNN_OPT_SMALL_WAVES, 4):
+        assert l2.scan_kind(256, 100) == "tile"                                        # ... by the two-waves-per-SIMD instance only
     assert l2.scan_kind(19, 100) == "none"                                             # FAISS's small-batch L2 form
     small = _index(X[:60000], 0)
     assert small.scan_kind(256, 100) == "tile"                                         # fewer than eight 32-row tiles per workgroup
@@ -229,3 +232,65 @@ def test_centred_queries_through_the_streaming_kernel(d, shift):
     Do, Io = ok.knn(X, Q, 100)
     assert np.array_equal(I1, Io) and np.array_equal(D1, Do)
     assert stats[0] == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 6: the L2 metric at d = 768 (13 K blocks of bf16 columns) through the streaming kernel -- the row term -||x||^2 / 2 enters
+# the accumulation chain as fp32 (csrc/knn_small8.inc, ROWTERM) instead of through two more columns
+# ---------------------------------------------------------------------------------------------------------------------
+def _stream_and_tile(idx, Q, k):
+    from viquae_amd import _lib
+    assert idx.scan_kind(len(Q), k) == "stream"
+    D1, I1 = idx.search_batch(Q, k)
+    stats = idx.screen_stats(len(Q), k)
+    with _lib.knn_option(_lib.KNN_OPT_SMALL_SCAN, 0):
+        assert idx.scan_kind(len(Q), k) == "tile"
+        D0, I0 = idx.search_batch(Q, k)
+    return (D1, I1), (D0, I0), stats
+
+
+@pytest.mark.parametrize("n,nq,k", [(66000, 256, 100), (65549, 199, 100), (131072, 20, 1), (70017, 64, 128), (200000, 256, 10)])
+def test_l2_at_768_columns_streams_and_equals_tile_scan_and_oracle(n, nq, k):
+    from oracle import knn as ok
+    rng = np.random.default_rng(n + nq)
+    X = rng.standard_normal((n, 768), dtype=np.float32)
+    Q = rng.standard_normal((nq, 768), dtype=np.float32)
+    Q[0] = X[n // 3]                      # an exact copy: the clamp at distance 0
+    X[n - 1] = Q[1] * np.float32(1.0001)  # the best row of a query is the shard's LAST row (ragged last tile when n % 32 != 0)
+    idx = _index(X, 1)
+    (D1, I1), (D0, I0), stats = _stream_and_tile(idx, Q, k)
+    assert np.array_equal(I1, I0) and np.array_equal(D1, D0)
+    Do, Io = ok.knn(X, Q, k, metric=1)
+    assert np.array_equal(I1, Io) and np.array_equal(D1, Do)
+    assert I1[0, 0] == n // 3 and I1[1, 0] == n - 1
+    assert stats[0] == 0 and stats[1] >= nq * k
+
+
+def test_l2_at_768_columns_ties_norm_spread_and_l2norm_factory():
+    from oracle import knn as ok
+    rng = np.random.default_rng(5)
+    # integer lattice with duplicated rows: massive exact ties, the lower id must win; rows of very different norms (the row term
+    # decides the order, not the inner product)
+    X = rng.integers(-3, 4, (66000, 768)).astype(np.float32)
+    X[1000:1100] = X[2000:2100]
+    X[40000:41000] *= np.float32(0.25)
+    X[50000:50500] *= np.float32(4.0)
+    Q = rng.integers(-3, 4, (64, 768)).astype(np.float32)
+    Q[:8] = X[1000:1008]
+    for tie in ("id_asc", "id_desc"):
+        idx = _index(X, 1, tie_order=tie)
+        assert idx.scan_kind(64, 100) == "stream"
+        D, I = idx.search_batch(Q, 100)
+        Do, Io = ok.knn(X, Q, 100, metric=1, tie_order=tie)
+        assert np.array_equal(I, Io) and np.array_equal(D, Do), tie
+    Xn = rng.standard_normal((66000, 768), dtype=np.float32) * rng.uniform(0.1, 30, (66000, 1)).astype(np.float32)
+    Qn = rng.standard_normal((100, 768), dtype=np.float32)
+    idx = _index(Xn, 1, factory="L2norm,Flat")
+    assert idx.scan_kind(100, 50) == "stream"
+    D, I = idx.search_batch(Qn, 50)
+    Do, Io = ok.knn(Xn, Qn, 50, metric=1, l2norm=True)
+    assert np.array_equal(I, Io) and np.array_equal(D, Do)
+    idx = _index(Xn, 1)                   # norms from 3 to 800: -||x||^2 / 2 spans five orders of magnitude
+    D, I = idx.search_batch(Qn, 50)
+    Do, Io = ok.knn(Xn, Qn, 50, metric=1)
+    assert np.array_equal(I, Io) and np.array_equal(D, Do)

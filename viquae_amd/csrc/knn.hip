@@ -114,6 +114,12 @@ __device__ __forceinline__ void dma16s_nt(const void* sbase, unsigned voff, unsi
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// a 4-byte-per-lane LDS-DMA piece (256 bytes per full wave; inactive lanes move nothing): LDS destination = lds_dst + lane * 4
+__device__ __forceinline__ void dma4s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ unsigned key_row(u64 key) { return 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull); }
 
 // ------------------------------------------------------------------------------------------------
@@ -1128,11 +1134,21 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus, int metric = -1) {
 // one slab per stripe slot (S = 256 = TQ: the workgroup of slab s owns query s), at most 12 K blocks of queries in registers,
 // k within the stripe bound, and enough 32-row tiles per slab for the ring to pay.  MQ_KNN_OPT_SMALL_SCAN = 0 switches it off,
 // MQ_KNN_OPT_SMALL_MIN_TILES = <n> lowers the tiles-per-slab floor (tests) -- mq_knn_set_option.
-bool small_scan_serves(const Geometry& g, int64_t N, int dp, int k) {
+// `rowterm` (out): the L2 metric whose two row-term columns sit alone in a 13th K block (d a multiple of 64, dp = d + 64 = 832):
+// the two-waves-per-SIMD kernel reads 12 K blocks and takes the term as fp32 (knn_small8.inc).
+bool small_scan_serves(const Geometry& g, int64_t N, int d, int metric, int k, int* nkb_out = nullptr, bool* rowterm_out = nullptr) {
     const int enabled = knn_opt(MQ_KNN_OPT_SMALL_SCAN), floor_opt = knn_opt(MQ_KNN_OPT_SMALL_MIN_TILES);
     const int min_tiles = floor_opt > 0 ? floor_opt : SM_MIN_TILES_PER_SLAB;
     if (!enabled || g.nqt != 1 || g.S != TQ || g.ms != SMAX_SLOTS || g.sps != 1) return false;
-    if (dp / SBK > SM_MAX_NKB || k > KF) return false;
+    int nkb = screen_dp(d, metric) / SBK;
+    bool rowterm = false;
+    if (nkb == SM_MAX_NKB + 1 && metric == MQ_METRIC_L2 && d % SBK == 0 && knn_opt(MQ_KNN_OPT_SMALL_WAVES) == 8) {
+        nkb = SM_MAX_NKB;
+        rowterm = true;
+    }
+    if (nkb > SM_MAX_NKB || k > KF) return false;
+    if (nkb_out) *nkb_out = nkb;
+    if (rowterm_out) *rowterm_out = rowterm;
     return (N + SM_ROWS - 1) / SM_ROWS >= (int64_t)g.S * (min_tiles > 1 ? min_tiles : 1);
 }
 
@@ -1140,6 +1156,12 @@ template <int NKB>
 int launch_small_scan_n(const SmallArgs& sa, int S, hipStream_t st) {
     constexpr int lds = sm_nst(NKB) * (NKB * SM_PIECE + 2 * SM_AUX) + 2 * TQ * 4 + SM_AUX;
     if (knn_opt(MQ_KNN_OPT_SMALL_WAVES) == 8) {  // two waves per SIMD (knn_small8.inc)
+        if (NKB == SM_MAX_NKB && sa.sqn) {  // the L2 row term as fp32 beside 12 K blocks
+            constexpr int lds_rt = lds + sm_nst(SM_MAX_NKB) * SM_AUX;  // + the ring slots' row terms
+            MQ_DYNAMIC_LDS(lds_rt, screen_small8_kernel<SM_MAX_NKB, true>);
+            hipLaunchKernelGGL((screen_small8_kernel<SM_MAX_NKB, true>), dim3((unsigned)S), dim3(512), lds_rt, st, sa);
+            return MQ_OK;
+        }
         MQ_DYNAMIC_LDS(lds, screen_small8_kernel<NKB>);
         hipLaunchKernelGGL(screen_small8_kernel<NKB>, dim3((unsigned)S), dim3(512), lds, st, sa);
         return MQ_OK;
@@ -1360,7 +1382,7 @@ int mq_knn_screen_scan_kind(int64_t N, int d, int nq, int k, int metric) {
     if (const PartPlan pl = partition_plan(N, k); pl.P) { N = pl.per; k = PART_K; }  // the scan of each row range
     if (k > SCREEN_MAX_K) return MQ_SCAN_KIND_NONE;
     const Geometry g = geometry(N, d, nq, k, num_cus(), true_metric(metric));
-    return small_scan_serves(g, N, screen_dp(d, metric), k) ? MQ_SCAN_KIND_STREAM : MQ_SCAN_KIND_TILE;
+    return small_scan_serves(g, N, d, metric, k) ? MQ_SCAN_KIND_STREAM : MQ_SCAN_KIND_TILE;
 }
 
 // "L2norm," arithmetic of a call's query transform: 0 = none, MQ_L2NORM_NUMPY, MQ_L2NORM_FAISS (the flag alone means FAISS form too)
@@ -1721,12 +1743,16 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         a.dbg = dbg_ptr();
         a.N = N; a.dp = dp; a.nqt = g.nqt; a.S = g.S; a.k = k; a.qpx = g.qpx_screen; a.nchunks = g.nchunks;
         if (ev_scan_begin) MQ_HIP(hipEventRecord((hipEvent_t)ev_scan_begin, st));
-        if (small_scan_serves(g, N, dp, k)) {
-            // one query tile: the streaming kernel with the queries in registers (knn_small.inc)
+        int small_nkb = 0;
+        bool small_rowterm = false;
+        if (small_scan_serves(g, N, d, metric, k, &small_nkb, &small_rowterm)) {
+            // one query tile: the streaming kernel with the queries in registers (knn_small8.inc / knn_small.inc)
             SmallArgs sa;
             sa.s = a;
             sa.ntiles = (N + SM_ROWS - 1) / SM_ROWS;
-            const int rc = launch_small_scan(sa, dp / SBK, g.S, st);
+            sa.sqn = small_rowterm ? sqnorm_dev : nullptr;
+            sa.nkb_copy = dp / SBK;
+            const int rc = launch_small_scan(sa, small_nkb, g.S, st);
             if (rc != MQ_OK) return rc;
         } else {
             MQ_DYNAMIC_LDS(S_LDS_TOTAL, screen_scan_kernel);
@@ -1748,7 +1774,7 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
         const int* layout_word = g.nqt == 1 ? (const int*)(ovf + 1) : (const int*)nullptr;
         const unsigned* gthr = (const unsigned*)(ws + g.off_gthr);
         const unsigned* smax = (const unsigned*)(ws + g.off_smax);
-        if (small_scan_serves(g, N, dp, k) && knn_opt(MQ_KNN_OPT_SMALL_WAVES) == 8)  // (checked against the word the scan left)
+        if (small_scan_serves(g, N, d, metric, k) && knn_opt(MQ_KNN_OPT_SMALL_WAVES) == 8)  // (checked against the word the scan left)
             hipLaunchKernelGGL(cand_select_kernel<CSEL_WALK_HALVES>, dim3((unsigned)nq), dim3(256), 0, st, pools, pcount, margin, gthr,
                                smax, g.ms, ovf, nq, g.S, k, cand, ccount, layout_word);
         else if (g.S >= 64)
