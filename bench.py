@@ -837,7 +837,13 @@ def main():
                     fusion_search = fusion_config_search.main(rows=rows)
                 except Exception as e:
                     fusion_search = {"error": repr(e)}
+                try:
+                    import small_batch_l2
+                    l2_small = small_batch_l2.main(rows=rows)
+                except Exception as e:
+                    l2_small = {"error": repr(e)}
                 rec.setdefault("secondary", {}).update({
+                    "small_batch_l2": l2_small,
                     "fusion_config_search": fusion_search,
                     "reference_call_surface": surface,
                     "encode_call_surface": encode_surface,

@@ -74,5 +74,28 @@ def test_fusion_refuses_what_it_does_not_implement():
     f = hfuse.Fusion(runs=[{"q": {"1": 1.0}}, {"q": {"1": 2.0}}], norm="gzmuv", method="rrf")
     with pytest.raises(NotImplementedError):
         f.test({"weights": [0.5, 0.5]})
-    with pytest.raises((ImportError, NotImplementedError)):
+    with pytest.raises(ValueError):          # the weight search needs relevance judgements
         f.fit()
+    f = hfuse.Fusion(qrels={"q": {"1": 1}}, runs=[{"q": {"1": 1.0}}, {"q": {"1": 2.0}}], norm="gzmuv", method="rrf")
+    with pytest.raises(NotImplementedError):  # only ranx's `wsum` grid is restated
+        f.fit()
+
+
+def test_wsum_trial_set_is_the_restatement_of_ranx_grid():
+    """Host logic of Fusion.fit: the trial set (ranx fusion/wsum.py + common.py as published, float-sum quirk included) equals
+    the oracle's, and so do the parsed metrics and the CSR form of the qrels the device takes."""
+    pytest.importorskip("torch")
+    import numpy as np
+    from oracle import fuse as ofuse
+    from viquae_amd.ir import fuse as hfuse, metrics as M
+    for n, count in ((2, 11), (3, 62), (4, 256)):
+        trials = hfuse.wsum_trials(n)
+        assert trials == ofuse.wsum_trials(n) and len(trials) == count
+        assert all(sum(t) == 1.0 for t in trials) and trials[0][-1] == 1.0 and trials[-1][0] == 1.0
+    assert M.parse_metric("mrr@100") == (0, 100) and M.parse_metric("precision") == (1, 0) and M.parse_metric("hit_rate@20") == (2, 20)
+    with pytest.raises(NotImplementedError):
+        M.parse_metric("ndcg@10")
+    ptr, rel = M.qrels_to_csr({"a": {"7": 1, "3": 1, "9": 0}, "c": {"x": 1}}, ["a", "b", "c"])
+    assert ptr.tolist() == [0, 2, 2, 3] and rel[:2].tolist() == [3, 7] and rel[2] > 1 << 61   # a relevant document no run can hold
+    q_ids, ids, lookup = M.run_tables({"a": {"7": 2.0, "1": 1.0}, "b": {}})
+    assert q_ids == ["a", "b"] and ids.tolist() == [[7, 1], [-1, -1]] and lookup is None

@@ -18,6 +18,7 @@ import torch
 from .. import _lib
 from .runs import ArrayRun
 
+_EMPTY = np.zeros(0, dtype=np.int64)
 METRIC_CODES = {"mrr": 0, "precision": 1, "hit_rate": 2, "recall": 3}   # MQ_RANK_METRIC_*
 MAX_METRICS = 16
 DEFAULT_METRICS = ["mrr@100", "precision@1", "precision@20", "hit_rate@20"]
@@ -43,7 +44,12 @@ def qrels_to_csr(qrels, q_ids, doc_lookup=None):
     for n, q in enumerate(q_ids):
         rel = []
         unknown = 0
-        for d, r in (qrels.get(q) or {}).items():
+        judged = qrels.get(q)
+        if not judged:
+            rows.append(_EMPTY)
+            ptr[n + 1] = ptr[n]
+            continue
+        for d, r in judged.items():
             if r < 1:
                 continue
             if doc_lookup is not None:
@@ -64,7 +70,7 @@ def qrels_to_csr(qrels, q_ids, doc_lookup=None):
 def run_tables(run, q_ids=None):
     """(q_ids, ids int64 [nq, K], doc_lookup | None) of a run given as ``ArrayRun`` or ``{q: {doc: score}}`` (best first)."""
     if isinstance(run, ArrayRun):
-        tabs = run.tables(q_ids)
+        tabs = run.tables(q_ids, ids_only=True)
         if tabs is not None:
             return tabs[0], tabs[1], None
     if q_ids is None:

@@ -222,9 +222,10 @@ class ArrayRun(MutableMapping):
                 f.write(c)
 
     # ---------------------------------------------------------------- fusion tables
-    def tables(self, q_ids=None):
+    def tables(self, q_ids=None, ids_only=False):
         """(q_ids, ids int64 [nq, K], scores float64 [nq, K]) with -1 / 0 in unused slots, when every entry is still a row of a
-        result block with numeric document ids; None otherwise (the caller then goes through the dicts)."""
+        result block with numeric document ids; None otherwise (the caller then goes through the dicts).  ``ids_only``: the
+        scores come back as None (the rank metrics only need the order)."""
         if q_ids is None:
             q_ids = list(self._entries)
         refs = [self._entries.get(q) for q in q_ids]
@@ -232,18 +233,23 @@ class ArrayRun(MutableMapping):
             return None
         K = max(self._blocks[b][0].shape[1] for b in {e[0] for e in refs})
         ids = np.full((len(refs), K), -1, dtype=np.int64)
-        scores = np.zeros((len(refs), K), dtype=np.float64)
+        scores = None if ids_only else np.zeros((len(refs), K), dtype=np.float64)
         blk = np.fromiter((e[0] for e in refs), dtype=np.int64, count=len(refs))
         row = np.fromiter((e[1] for e in refs), dtype=np.int64, count=len(refs))
         for b in np.unique(blk).tolist():
             sel = np.flatnonzero(blk == b)
             bi, bs, _ = self._blocks[b]
             ids[sel, :bi.shape[1]] = bi[row[sel]]
-            scores[sel, :bi.shape[1]] = bs[row[sel]]
-        # a row ends at its first negative id: clear what follows it
-        dead = np.cumsum(ids < 0, axis=1) > 0
-        ids[dead] = -1
-        scores[dead] = 0.0
+            if scores is not None:
+                scores[sel, :bi.shape[1]] = bs[row[sel]]
+        # a row ends at its first negative id: clear what follows it (nothing to do for full rows -- the usual case)
+        neg = ids < 0
+        if neg.any():
+            first = np.where(neg.any(axis=1), neg.argmax(axis=1), K)
+            dead = np.arange(K)[None, :] >= first[:, None]
+            ids[dead] = -1
+            if scores is not None:
+                scores[dead] = 0.0
         return q_ids, ids, scores
 
 
