@@ -319,7 +319,7 @@ def test_centred_query_margin_dominates_the_measured_screening_error(d, shift, m
 def test_centred_queries_policy():
     """When the index centres its queries as well: inner product only, a centre that carries a quarter of the squared norms, and
     either free columns (d % 64 in 1 ... 62) or a width beyond the streaming kernel's 768 columns (where the columns cost a K block:
-    three quarters); never d = 767 / 768."""
+    three quarters); never d = 767; d = 768 like the other multiples of 64 since round 6."""
     from viquae_amd.index import METRIC_IP_CENTRED, MI355XFlatIndex
 
     def metric_of(d, shift, metric=0, factory="Flat"):
@@ -330,7 +330,9 @@ def test_centred_queries_policy():
 
     assert metric_of(200, 9.0) == METRIC_IP_CENTRED and metric_of(200, 0.0) == 0          # no shared component: plain
     assert metric_of(1024, 20.0) == METRIC_IP_CENTRED and metric_of(2048, 30.0, factory="L2norm,Flat") == METRIC_IP_CENTRED
-    assert metric_of(768, 20.0) == 0 and metric_of(767, 20.0) == 0                            # the streaming kernel's last K block
+    assert metric_of(767, 20.0) == 0                                                       # a 13th K block would cost the streaming kernel
+    assert metric_of(768, 20.0) == METRIC_IP_CENTRED and metric_of(768, 5.0) == 0             # round 6: alone in the 13th block, the two columns
+                                                                                           # travel as fp32 beside twelve (when the centre dominates)
     assert metric_of(512, 20.0) == METRIC_IP_CENTRED and metric_of(512, 5.0) == 0             # a K block more: only when it dominates
     assert metric_of(200, 9.0, metric=1) == 1                                              # the L2 screen keeps its own row term
     X, _ = _anisotropic(3000, 200, 4, 1)

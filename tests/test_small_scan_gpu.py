@@ -294,3 +294,23 @@ def test_l2_at_768_columns_ties_norm_spread_and_l2norm_factory():
     D, I = idx.search_batch(Qn, 50)
     Do, Io = ok.knn(Xn, Qn, 50, metric=1)
     assert np.array_equal(I, Io) and np.array_equal(D, Do)
+
+
+def test_centred_queries_at_768_columns_stream():
+    """MQ_METRIC_IP_CENTRED at d = 768: the two row-term columns are alone in a 13th K block; the streaming kernel reads twelve and
+    takes h + l of each row's pair as the start of its accumulation chain.  A shared component that carries more than three quarters
+    of the squared norms switches the centred-query screen on by itself."""
+    from oracle import knn as ok
+    from viquae_amd.index import METRIC_IP_CENTRED
+    g = torch.Generator(device="cuda").manual_seed(768)
+    mu = torch.randn((1, 768), generator=g, device="cuda")
+    mu = 14.0 * mu / mu.norm()
+    X = (mu + 0.25 * torch.randn((70000, 768), generator=g, device="cuda")).cpu().numpy()
+    Q = (mu + 0.25 * torch.randn((256, 768), generator=g, device="cuda")).cpu().numpy()
+    idx = _index(X, 0)
+    assert idx._screen_metric == METRIC_IP_CENTRED
+    (D1, I1), (D0, I0), stats = _stream_and_tile(idx, Q, 100)
+    assert np.array_equal(I1, I0) and np.array_equal(D1, D0)
+    Do, Io = ok.knn(X, Q, 100)
+    assert np.array_equal(I1, Io) and np.array_equal(D1, Do)
+    assert stats[0] == 0

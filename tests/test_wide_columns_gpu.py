@@ -90,15 +90,16 @@ def test_wide_embeddings_with_a_shared_component(d, factory, metric):
     _check(X, Q, 100, metric, factory, False, "faiss" if "L2norm" in factory else None)
 
 
-@pytest.mark.parametrize("d,metric", [(2048, 0), (1024, 0), (1000, 1), (768, 1)])
+@pytest.mark.parametrize("d,metric", [(2048, 0), (1024, 0), (1000, 1), (832, 1), (768, 1)])
 def test_the_streaming_kernel_refuses_more_than_twelve_k_blocks(d, metric):
-    """The reference's 256-query batch over a shard large enough for the streaming kernel: beyond 768 bf16 columns (and for L2
-    at d = 768: two more columns -> 832) the tile kernel serves it -- same results, bit for bit, as the exact scan and the oracle."""
+    """The reference's 256-query batch over a shard large enough for the streaming kernel: beyond 768 bf16 columns the tile kernel
+    serves it -- same results, bit for bit, as the exact scan and the oracle.  The one exception since round 6: the L2 metric at
+    d = 768, whose 13th K block holds nothing but the two row-term columns -- the streaming kernel takes the term as fp32."""
     from oracle import knn as ok
     n = 66000
     X, Q = _data(n, d, 256, seed=d + 11)
     idx = _index(X, metric, "Flat", True)
-    assert idx.scan_kind(256, 100) == "tile"
+    assert idx.scan_kind(256, 100) == ("stream" if (d, metric) == (768, 1) else "tile")
     D, I = idx.search_batch(Q, 100)
     Do, Io = ok.knn(X, Q, 100, metric=metric)
     assert np.array_equal(I, Io) and np.array_equal(D, Do)

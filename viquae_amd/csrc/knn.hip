@@ -1134,7 +1134,7 @@ Geometry geometry(int64_t N, int d, int nq, int k, int cus, int metric = -1) {
 // one slab per stripe slot (S = 256 = TQ: the workgroup of slab s owns query s), at most 12 K blocks of queries in registers,
 // k within the stripe bound, and enough 32-row tiles per slab for the ring to pay.  MQ_KNN_OPT_SMALL_SCAN = 0 switches it off,
 // MQ_KNN_OPT_SMALL_MIN_TILES = <n> lowers the tiles-per-slab floor (tests) -- mq_knn_set_option.
-// `rowterm` (out): the L2 metric whose two row-term columns sit alone in a 13th K block (d a multiple of 64, dp = d + 64 = 832):
+// `rowterm` (out): the L2 metric / the centred inner product whose two row-term columns sit alone in a 13th K block (d a multiple of 64, dp = d + 64 = 832):
 // the two-waves-per-SIMD kernel reads 12 K blocks and takes the term as fp32 (knn_small8.inc).
 bool small_scan_serves(const Geometry& g, int64_t N, int d, int metric, int k, int* nkb_out = nullptr, bool* rowterm_out = nullptr) {
     const int enabled = knn_opt(MQ_KNN_OPT_SMALL_SCAN), floor_opt = knn_opt(MQ_KNN_OPT_SMALL_MIN_TILES);
@@ -1142,7 +1142,8 @@ bool small_scan_serves(const Geometry& g, int64_t N, int d, int metric, int k, i
     if (!enabled || g.nqt != 1 || g.S != TQ || g.ms != SMAX_SLOTS || g.sps != 1) return false;
     int nkb = screen_dp(d, metric) / SBK;
     bool rowterm = false;
-    if (nkb == SM_MAX_NKB + 1 && metric == MQ_METRIC_L2 && d % SBK == 0 && knn_opt(MQ_KNN_OPT_SMALL_WAVES) == 8) {
+    if (nkb == SM_MAX_NKB + 1 && (metric == MQ_METRIC_L2 || metric == MQ_METRIC_IP_CENTRED) && d % SBK == 0 &&
+        knn_opt(MQ_KNN_OPT_SMALL_WAVES) == 8) {
         nkb = SM_MAX_NKB;
         rowterm = true;
     }
@@ -1156,7 +1157,7 @@ template <int NKB>
 int launch_small_scan_n(const SmallArgs& sa, int S, hipStream_t st) {
     constexpr int lds = sm_nst(NKB) * (NKB * SM_PIECE + 2 * SM_AUX) + 2 * TQ * 4 + SM_AUX;
     if (knn_opt(MQ_KNN_OPT_SMALL_WAVES) == 8) {  // two waves per SIMD (knn_small8.inc)
-        if (NKB == SM_MAX_NKB && sa.sqn) {  // the L2 row term as fp32 beside 12 K blocks
+        if (NKB == SM_MAX_NKB && sa.rowterm) {  // the row term as fp32 beside 12 K blocks
             constexpr int lds_rt = lds + sm_nst(SM_MAX_NKB) * SM_AUX;  // + the ring slots' row terms
             MQ_DYNAMIC_LDS(lds_rt, screen_small8_kernel<SM_MAX_NKB, true>);
             hipLaunchKernelGGL((screen_small8_kernel<SM_MAX_NKB, true>), dim3((unsigned)S), dim3(512), lds_rt, st, sa);
@@ -1750,7 +1751,8 @@ int mq_knn_search_screened_f32(const float* packed_dev, const float* sqnorm_dev,
             SmallArgs sa;
             sa.s = a;
             sa.ntiles = (N + SM_ROWS - 1) / SM_ROWS;
-            sa.sqn = small_rowterm ? sqnorm_dev : nullptr;
+            sa.rowterm = small_rowterm ? 1 : 0;
+            sa.sqn = (small_rowterm && metric == MQ_METRIC_L2) ? sqnorm_dev : nullptr;
             sa.nkb_copy = dp / SBK;
             const int rc = launch_small_scan(sa, small_nkb, g.S, st);
             if (rc != MQ_OK) return rc;

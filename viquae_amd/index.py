@@ -315,8 +315,9 @@ class MI355XFlatIndex(BaseIndex):
         1024-d ``clip-RN50`` columns) makes the margin follow ||q|| while the scores spread like ||q - c|| ||x - c||; the
         centred-query screen removes that at the price of two more bf16 columns.  It is chosen when those columns are free
         (d % 64 in 1 ... 62) or the index is wider than the streaming kernel's 768 columns anyway -- and, where they cost a K block
-        (d = 64 ... 704, multiples of 64), when the centre carries three quarters of the squared norm; never for d = 767 / 768,
-        where a 13th K block would cost the one-query-tile search its streaming kernel.  MQ_KNN_CENTER_QUERIES=0 / 1 overrides."""
+        (d = 64 ... 768, multiples of 64), when the centre carries three quarters of the squared norm; never for d = 767, where a
+        13th K block would cost the one-query-tile search its streaming kernel (at d = 768 the two columns sit alone in that block
+        and the streaming kernel takes the row term as fp32, round 6).  MQ_KNN_CENTER_QUERIES=0 / 1 overrides."""
         import torch
         if self._torch_device is None:
             self._torch_device = _resolve_device(self.device)
@@ -338,7 +339,9 @@ class MI355XFlatIndex(BaseIndex):
             env = os.environ.get("MQ_KNN_CENTER_QUERIES")
             if env is not None:
                 want = env != "0"
-            if want and not (dp_plain <= 12 < dp_cols and env is None):
+            # d = 767: the 13th K block would cost the one-query-tile search its streaming kernel; d = 768: the two columns sit ALONE
+            # in the 13th block and that kernel takes the row term as fp32 beside twelve (round 6, csrc/knn_small8.inc)
+            if want and not (dp_plain <= 12 < dp_cols and int(d) % 64 != 0 and env is None):
                 self._screen_metric = METRIC_IP_CENTRED
         self._xmax2 = torch.zeros(4 + int(d), dtype=torch.float32, device=self._torch_device)
         if center is not None:
