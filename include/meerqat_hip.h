@@ -530,6 +530,39 @@ int mq_image_preprocess_u8(const uint8_t *src_dev, const int64_t *geom_dev, int 
                            const float *std3_host, float *out_dev, void *ws_dev, size_t ws_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Baseline-JPEG decoding split between host and GPU (csrc/jpeg.hip): replaces, per image,
+ * `Image.open(path).convert('RGB')` of `load_image` (meerqat/data/loading.py:108-124, called by meerqat/image/embedding.py:127)
+ * for the files it covers -- 8-bit Huffman-coded sequential JPEGs (SOF0 / SOF1) with ONE interleaved scan, grey or YCbCr with
+ * luma sampling 1x1 / 2x1 / 1x2 / 2x2 and chroma 1x1 -- with the same RGB bytes as Pillow 12 / libjpeg-turbo (ISLOW inverse DCT,
+ * fancy upsampling, fixed-point colour tables; oracle/jpeg.py, pinned against Pillow).  Everything else, and any irregularity of
+ * the entropy-coded data, is declined and stays Pillow's: the caller keeps the reference's errors and warnings.
+ *
+ * mq_jpeg_probe (HOST, needs no GPU): file bytes -> info_host[MQ_JPEG_INFO] = {height, width, components, 8 x 8 blocks,
+ *   staging bytes (header + the larger of the coefficient blocks and the RGB image, a multiple of 16), luma sampling h * 16 + v
+ *   (0 for grey)}.  MQ_OK | MQ_EUNSUPPORTED (a JPEG of another kind) | MQ_EINVAL (not a JPEG / damaged headers).
+ * mq_jpeg_read_coefficients (HOST): Huffman-decodes the scan into staging_host (4-byte aligned, >= the probe's staging bytes):
+ *   a MQ_JPEG_HEADER_BYTES header (int32 words: magic, height, width, components, hmax, vmax, MCUs across / down, then per
+ *   component h, v, blocks across / down, first block, [total blocks], real samples across / down; uint16 quantisation tables
+ *   [3][64] in natural order at byte 128) followed by the quantised coefficients, int16 [block][64] in natural order,
+ *   component after component.  MQ_EINVAL when the scan is irregular in any way (the staging area is then undefined).
+ *   A caller that decodes such a file by other means stores its H x W x 3 RGB bytes behind a header whose words 0-2 are
+ *   MQ_JPEG_MAGIC_RGB, height, width.
+ * mq_jpeg_decode_rgb_u8 (GPU): items_dev int64 [n_images][2] = (byte offset of an image's header, byte offset of its RGB
+ *   output) inside buf_dev (16-byte aligned offsets and buffer); max_blocks / max_pixels = the largest block / pixel count of
+ *   the batch.  The inverse DCT runs in place (the coefficient area is consumed); the H x W x 3 bytes are what
+ *   mq_image_preprocess_u8 / mq_warp_affine_faces_f32 read.
+ * ------------------------------------------------------------------------------------------- */
+#define MQ_JPEG_INFO 6
+#define MQ_JPEG_HEADER_BYTES 512
+#define MQ_JPEG_MAGIC_COEFFICIENTS 0x4745504A /* "JPEG" */
+#define MQ_JPEG_MAGIC_RGB 0x20424752          /* "RGB " */
+#define MQ_JPEG_MAX_PIXELS (1 << 26)
+int mq_jpeg_probe(const uint8_t *file_host, size_t nbytes, int64_t *info_host);
+int mq_jpeg_read_coefficients(const uint8_t *file_host, size_t nbytes, void *staging_host, size_t staging_cap);
+int mq_jpeg_decode_rgb_u8(uint8_t *buf_dev, const int64_t *items_dev, int n_images, int max_blocks, int64_t max_pixels,
+                          void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement aid (csrc/diag.hip; no reference counterpart, not on the product path): `workgroups` x 16 waves loop over
  * `iters` x 16 v_mfma_f32_32x32x16_bf16 on register operands (zero, or N(0,1)-like random when random_operands != 0), no
  * memory traffic: 2*32*32*16 * 16 * iters * 16 * workgroups FLOP per launch.  bench.py times it for the matrix-pipe rate

@@ -1,0 +1,84 @@
+"""oracle/jpeg.py (the restatement of libjpeg's baseline decoding: Huffman scans, ISLOW IDCT, fancy upsampling, YCbCr tables)
+against Pillow itself, bit for bit -- what ``load_image`` hands the image encoders (meerqat/data/loading.py:108-124).
+Files are written by Pillow's encoder here; tools/jpeg_pillow_parity.py runs the same comparison over 1000 files."""
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+
+Image = pytest.importorskip("PIL.Image")
+from oracle import jpeg as oj  # noqa: E402
+import jpeg_pillow_parity as jp  # noqa: E402
+
+
+def _pillow(data):
+    return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+
+
+def test_random_files_decode_like_pillow():
+    rng = np.random.default_rng(42)
+    kinds = set()
+    for i in range(40):
+        h, w = jp.sizes(rng)
+        h, w = min(h, 200), min(w, 200)
+        data, kw = jp.encode(rng, jp.picture(rng, h, w, grey=(i % 9 == 0)))
+        f = oj.read_coefficients(data)
+        kinds.add(tuple((c["h"], c["v"]) for c in f["components"]))
+        assert np.array_equal(oj.decode(data), _pillow(data)), (i, h, w, kw)
+    assert {((1, 1),), ((1, 1),) * 3, ((2, 1), (1, 1), (1, 1)), ((2, 2), (1, 1), (1, 1))} <= kinds
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (1, 7), (2, 2), (3, 5), (5, 3), (8, 8), (9, 17), (16, 16), (17, 33), (31, 2), (33, 4), (4, 6)])
+@pytest.mark.parametrize("subsampling", [0, 1, 2])
+def test_small_and_odd_sizes(h, w, subsampling):
+    """Edge handling: components no wider than two samples take the replicating upsamplers; odd sizes end inside an MCU."""
+    rng = np.random.default_rng(h * 100 + w)
+    im = Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), "RGB")
+    buf = io.BytesIO()
+    im.save(buf, "JPEG", quality=90, subsampling=subsampling)
+    assert np.array_equal(oj.decode(buf.getvalue()), _pillow(buf.getvalue()))
+
+
+def test_h1v2_sampling_file():
+    """4:4:0 (luma 1 x 2): Pillow's encoder does not write it, but a 4:2:2 stream IS a 4:4:0 stream of another shape -- two luma
+    blocks + Cb + Cr per MCU either way -- so the frame header of a 64 x 48 4:2:2 file (4 x 6 MCUs of 16 x 8) is rewritten to
+    32 x 96 with luma 1 x 2 (4 x 6 MCUs of 8 x 16).  The picture is scrambled; both decoders read the same valid file."""
+    rng = np.random.default_rng(3)
+    buf = io.BytesIO()
+    jp.picture(rng, 48, 64).save(buf, "JPEG", quality=85, subsampling=1)
+    data = bytearray(buf.getvalue())
+    at = data.find(b"\xff\xc0")
+    assert at > 0 and data[at + 9] == 3 and data[at + 11] == 0x21
+    data[at + 5:at + 9] = bytes([0, 96, 0, 32])   # height 96, width 32
+    data[at + 11] = 0x12                          # luma h = 1, v = 2
+    data = bytes(data)
+    f = oj.read_coefficients(data)
+    assert [(c["h"], c["v"]) for c in f["components"]] == [(1, 2), (1, 1), (1, 1)]
+    assert np.array_equal(oj.decode(data), _pillow(data))
+
+
+def test_restart_intervals_and_optimised_tables():
+    rng = np.random.default_rng(5)
+    im = jp.picture(rng, 70, 90)
+    for kw in (dict(restart_marker_blocks=1), dict(restart_marker_rows=1), dict(optimize=True), dict(quality=100), dict(quality=1)):
+        buf = io.BytesIO()
+        im.save(buf, "JPEG", **kw)
+        assert np.array_equal(oj.decode(buf.getvalue()), _pillow(buf.getvalue())), kw
+
+
+def test_progressive_is_declined():
+    buf = io.BytesIO()
+    jp.picture(np.random.default_rng(0), 40, 40).save(buf, "JPEG", progressive=True)
+    with pytest.raises(oj.Unsupported):
+        oj.decode(buf.getvalue())
+
+
+def test_idct_of_a_dc_only_block_is_flat():
+    c = np.zeros((3, 8, 8), dtype=np.int64)
+    c[:, 0, 0] = [-1024, 8, 1016]
+    out = oj.idct_islow(c)
+    assert [int(o[0, 0]) for o in out] == [0, 129, 255] and all((o == o[0, 0]).all() for o in out)

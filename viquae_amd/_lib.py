@@ -87,6 +87,9 @@ SIGNATURES = {
     "mq_image_plan": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "mq_image_preprocess_u8": (c_int, [c_ptr, c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_int, ctypes.c_double, c_ptr, c_ptr,
                                        c_ptr, c_ptr, c_sz, c_ptr]),
+    "mq_jpeg_probe": (c_int, [c_ptr, c_sz, c_ptr]),
+    "mq_jpeg_read_coefficients": (c_int, [c_ptr, c_sz, c_ptr, c_sz]),
+    "mq_jpeg_decode_rgb_u8": (c_int, [c_ptr, c_ptr, c_int, c_int, c_i64, c_ptr]),
     "mq_fuse_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "mq_fuse_wsum_f64": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_sz,
                                  c_ptr]),

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libmeerqat_hip.so")
-SOURCES = ["knn.hip", "encoder.hip", "conv.hip", "fuse.hip", "image.hip", "diag.hip", "runfmt.cpp"]
+SOURCES = ["knn.hip", "encoder.hip", "conv.hip", "fuse.hip", "image.hip", "jpeg.hip", "diag.hip", "runfmt.cpp"]
 ARCH = "gfx950"
 
 

@@ -1,0 +1,544 @@
+// jpeg.hip -- baseline-JPEG decoding split between the host and the GPU: what the reference gets, per image, from
+// `Image.open(path).convert('RGB')` (meerqat/data/loading.py:108-124, called by meerqat/image/embedding.py:127).
+// Pillow hands the file to libjpeg-turbo; bit for bit the same RGB bytes are produced here by
+//
+//   host   mq_jpeg_probe / mq_jpeg_read_coefficients: marker parsing + Huffman decoding of the ONE interleaved sequential scan
+//          (jdhuff.c's algorithm: look-ahead tables, HUFF_EXTEND, DC prediction, restart intervals) -- the part of a JPEG
+//          decoder that is a serial bit stream -- into quantised coefficient blocks inside the batch's staging buffer, behind
+//          a 512-byte header (sizes, sampling, quantisation tables);
+//   GPU    jpeg_idct_kernel: dequantisation + jidctint.c's ISLOW inverse DCT (13-bit fixed point, columns then rows,
+//          round-half-up descales, + 128, clamp), one thread per 8 x 8 block, IN PLACE (a block's 128 coefficient bytes become
+//          its 64 sample bytes);
+//          jpeg_rgb_kernel: jdsample.c's fancy chroma upsampling (h2v1, h2v2, h1v2 triangle filters with libjpeg's rounding
+//          constants and edge rules, replication when a component is no wider than two samples) + jdcolor.c's fixed-point
+//          YCbCr -> RGB, one thread per pixel, HWC uint8 at the image's offset of the packed source buffer that
+//          mq_image_preprocess_u8 reads.
+//
+// Byte / integer work; the kernels are bound by HBM (a 4:2:0 image: 3 bytes of coefficients read + 1.5 written + 1.5 read + 3
+// written per pixel) and are ~2 % of the CLIP tower's time per batch; the host side is what bounds the job (profiles/r06_notes.md
+// section 6).  Anything this decoder does not cover -- progressive / arithmetic / lossless / 12-bit files, CMYK, several scans,
+// other sampling factors, and ANY irregularity of the entropy-coded data (a marker inside the scan, a missing EOI, an invalid
+// code) -- is declined (MQ_EUNSUPPORTED / MQ_EINVAL) and the caller decodes that file with Pillow as before, so errors and
+// warnings stay the reference's.  Oracle: oracle/jpeg.py, pinned against Pillow (tests/test_jpeg_oracle_cpu.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/meerqat_hip.h"
+
+extern "C" void mq_internal_set_hip_error(int e);
+
+namespace {
+
+#define JPG_HIP(call)                                  \
+    do {                                               \
+        hipError_t _e = (call);                        \
+        if (_e != hipSuccess) { mq_internal_set_hip_error((int)_e); return MQ_EHIP; } \
+    } while (0)
+
+// header words (int32) in front of an image's coefficient blocks; the quantisation tables follow at byte 128
+enum { H_MAGIC = 0, H_HEIGHT, H_WIDTH, H_NCOMP, H_HMAX, H_VMAX, H_MCUX, H_MCUY, H_CH = 8, H_CV = 11, H_BW = 14, H_BH = 17,
+       H_FIRST = 20, H_BLOCKS = 23, H_DW = 24, H_DH = 27 };
+constexpr int HDR = MQ_JPEG_HEADER_BYTES;
+
+static const uint8_t NATURAL[64 + 16] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                         41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                         30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
+                                         63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};  // (jdhuff.c: a run past 63 stays inside)
+
+// ------------------------------------------------------------------------------------------------------------------
+// host: markers and the Huffman scan
+struct Huff {
+    uint16_t look[512];   // 9 leading bits -> (code length << 8) | symbol, 0 = longer than 9 bits
+    int16_t fast_ac[512]; // AC only: 9 leading bits hold a whole (run, size, value): (value << 8) | (run << 4) | (length + size), else 0
+    int32_t maxcode[18], valoff[17];
+    uint8_t vals[256];
+    bool defined;
+};
+
+static bool build_huff(Huff& t, const uint8_t* counts, const uint8_t* symbols, int nsym, bool ac) {
+    memset(&t, 0, sizeof(t));
+    uint8_t size[257];
+    uint32_t code[257];
+    int p = 0;
+    for (int l = 1; l <= 16; ++l)
+        for (int i = 0; i < counts[l - 1]; ++i) {
+            if (p >= 256) return false;
+            size[p++] = (uint8_t)l;
+        }
+    if (p != nsym) return false;
+    uint32_t c = 0;
+    int si = p ? size[0] : 0;
+    for (int k = 0; k < p;) {
+        while (k < p && size[k] == si) code[k++] = c++;
+        if (c > (1u << si)) return false;   // the codes of one length must fit that length
+        c <<= 1;
+        ++si;
+    }
+    int k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        if (counts[l - 1]) {
+            t.valoff[l] = k - (int)code[k];
+            k += counts[l - 1];
+            t.maxcode[l] = (int)code[k - 1];
+        } else t.maxcode[l] = -1;
+    }
+    t.maxcode[17] = 0x7FFFFFFF;
+    memcpy(t.vals, symbols, (size_t)nsym);
+    for (int i = 0; i < p; ++i)
+        if (size[i] <= 9) {
+            const int lo = (int)code[i] << (9 - size[i]);
+            for (int j = 0; j < (1 << (9 - size[i])); ++j) t.look[lo + j] = (uint16_t)((size[i] << 8) | symbols[i]);
+        }
+    if (ac)
+        for (int i = 0; i < 512; ++i) {
+            const uint16_t e = t.look[i];
+            if (!e) continue;
+            const int len = e >> 8, rs = e & 255, run = rs >> 4, mag = rs & 15;
+            if (mag && len + mag <= 9) {
+                int v = ((i << len) & 511) >> (9 - mag);
+                if (v < (1 << (mag - 1))) v += (int)((~0u) << mag) + 1;   // HUFF_EXTEND
+                if (v >= -128 && v <= 127) t.fast_ac[i] = (int16_t)(v * 256 + run * 16 + len + mag);
+            }
+        }
+    t.defined = true;
+    return true;
+}
+
+struct Bits {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t acc;   // the low `n` bits are valid
+    int n;
+    int fake;       // zero bits appended after the real data ran out (a marker or the end of the file)
+    inline void fill() {
+        while (n <= 56) {
+            unsigned b = 0;
+            if (p < end && p[0] != 0xFF) b = *p++;
+            else if (p + 1 < end && p[0] == 0xFF && p[1] == 0x00) { b = 0xFF; p += 2; }
+            else fake += 8;
+            acc = (acc << 8) | b;
+            n += 8;
+        }
+    }
+    inline unsigned peek(int k) const { return (unsigned)(acc >> (n - k)) & ((1u << k) - 1); }
+    inline void drop(int k) { n -= k; }
+};
+
+struct Frame {
+    int height, width, ncomp, hmax, vmax, mcux, mcuy;
+    int ch[3], cv[3], tq[3], bw[3], bh[3], first[3], id[3], blocks;
+};
+
+struct Parsed {
+    Frame f;
+    uint16_t qt[4][64];   // natural order
+    bool have_qt[4];
+    Huff dc[4], ac[4];
+    int restart;
+    int td[3], ta[3];
+    const uint8_t* scan;  // first entropy-coded byte
+};
+
+static inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
+
+// -> MQ_OK with `out` filled up to the start of the scan; MQ_EUNSUPPORTED: a valid-looking file of a kind not handled here;
+//    MQ_EINVAL: not a JPEG file / damaged headers
+static int parse(const uint8_t* d, size_t nbytes, Parsed& out) {
+    if (!d || nbytes < 4 || d[0] != 0xFF || d[1] != 0xD8) return MQ_EINVAL;
+    memset(&out.f, 0, sizeof(out.f));
+    memset(out.have_qt, 0, sizeof(out.have_qt));
+    for (int i = 0; i < 4; ++i) out.dc[i].defined = out.ac[i].defined = false;
+    out.restart = 0;
+    bool jfif = false, have_frame = false;
+    int adobe = -1;
+    size_t pos = 2;
+    for (;;) {
+        if (pos + 4 > nbytes || d[pos] != 0xFF) return MQ_EINVAL;
+        const int m = d[pos + 1];
+        if (m == 0xFF) { ++pos; continue; }   // fill byte
+        if (m == 0xD8 || m == 0xD9 || m == 0x01 || (m >= 0xD0 && m <= 0xD7) || m == 0x00) return MQ_EINVAL;
+        const size_t ln = (size_t)be16(d + pos + 2);
+        if (ln < 2 || pos + 2 + ln > nbytes) return MQ_EINVAL;
+        const uint8_t* s = d + pos + 4;
+        const size_t sl = ln - 2;
+        pos += 2 + ln;
+        if (m == 0xDB) {
+            size_t q = 0;
+            while (q < sl) {
+                const int pq = s[q] >> 4, t = s[q] & 15;
+                ++q;
+                if (t > 3 || pq > 1 || q + (pq ? 128u : 64u) > sl) return MQ_EINVAL;
+                for (int i = 0; i < 64; ++i) out.qt[t][NATURAL[i]] = pq ? (uint16_t)be16(s + q + 2 * i) : s[q + i];
+                q += pq ? 128 : 64;
+                out.have_qt[t] = true;
+            }
+        } else if (m == 0xC4) {
+            size_t q = 0;
+            while (q < sl) {
+                if (q + 17 > sl) return MQ_EINVAL;
+                const int tc = s[q] >> 4, th = s[q] & 15;
+                if (tc > 1 || th > 3) return MQ_EINVAL;
+                int ns = 0;
+                for (int i = 0; i < 16; ++i) ns += s[q + 1 + i];
+                if (ns > 256 || q + 17 + ns > sl) return MQ_EINVAL;
+                if (!build_huff(tc ? out.ac[th] : out.dc[th], s + q + 1, s + q + 17, ns, tc == 1)) return MQ_EINVAL;
+                q += 17 + (size_t)ns;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (have_frame || sl < 6) return MQ_EINVAL;
+            Frame& f = out.f;
+            if (s[0] != 8) return MQ_EUNSUPPORTED;
+            f.height = be16(s + 1);
+            f.width = be16(s + 3);
+            f.ncomp = s[5];
+            if (f.height < 1 || f.width < 1) return MQ_EUNSUPPORTED;   // (height 0 = defined by a DNL marker)
+            if (f.ncomp != 1 && f.ncomp != 3) return MQ_EUNSUPPORTED;
+            if (sl < 6 + 3u * f.ncomp) return MQ_EINVAL;
+            for (int c = 0; c < f.ncomp; ++c) {
+                f.id[c] = s[6 + 3 * c];
+                f.ch[c] = s[7 + 3 * c] >> 4;
+                f.cv[c] = s[7 + 3 * c] & 15;
+                f.tq[c] = s[8 + 3 * c];
+                if (f.ch[c] < 1 || f.ch[c] > 4 || f.cv[c] < 1 || f.cv[c] > 4 || f.tq[c] > 3) return MQ_EINVAL;
+            }
+            have_frame = true;
+        } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
+            return MQ_EUNSUPPORTED;   // progressive, lossless, arithmetic, differential
+        } else if (m == 0xCC) {
+            return MQ_EUNSUPPORTED;   // arithmetic conditioning
+        } else if (m == 0xDD) {
+            if (sl < 2) return MQ_EINVAL;
+            out.restart = be16(s);
+        } else if (m == 0xE0) {
+            if (sl >= 5 && !memcmp(s, "JFIF\0", 5)) jfif = true;
+        } else if (m == 0xEE) {
+            if (sl >= 12 && !memcmp(s, "Adobe", 5)) adobe = s[11];
+        } else if (m == 0xDA) {
+            if (!have_frame) return MQ_EINVAL;
+            Frame& f = out.f;
+            if (sl < 1 || s[0] != f.ncomp || sl < 4u + 2u * f.ncomp) return MQ_EUNSUPPORTED;   // one interleaved scan only
+            for (int c = 0; c < f.ncomp; ++c) {
+                if (s[1 + 2 * c] != f.id[c]) return MQ_EUNSUPPORTED;
+                out.td[c] = s[2 + 2 * c] >> 4;
+                out.ta[c] = s[2 + 2 * c] & 15;
+                if (out.td[c] > 3 || out.ta[c] > 3 || !out.dc[out.td[c]].defined || !out.ac[out.ta[c]].defined) return MQ_EINVAL;
+                if (!out.have_qt[f.tq[c]]) return MQ_EINVAL;
+            }
+            const uint8_t* t = s + 1 + 2 * f.ncomp;
+            if (t[0] != 0 || t[1] != 63 || t[2] != 0) return MQ_EUNSUPPORTED;
+            // colour space as jdapimin.c default_decompress_parms decides it: JFIF -> YCbCr; else Adobe's transform flag; else
+            // YCbCr unless the component ids spell "RGB"
+            if (f.ncomp == 3) {
+                if (!jfif && adobe >= 0 && adobe != 1) return MQ_EUNSUPPORTED;
+                if (!jfif && adobe < 0 && f.id[0] == 'R' && f.id[1] == 'G' && f.id[2] == 'B') return MQ_EUNSUPPORTED;
+            }
+            if (f.ncomp == 1) {
+                f.ch[0] = f.cv[0] = 1;   // a single-component scan is not interleaved: one block per MCU whatever the factors say
+            } else {
+                if (f.ch[1] != 1 || f.cv[1] != 1 || f.ch[2] != 1 || f.cv[2] != 1) return MQ_EUNSUPPORTED;
+                if (f.ch[0] > 2 || f.cv[0] > 2) return MQ_EUNSUPPORTED;
+            }
+            f.hmax = f.ch[0];
+            f.vmax = f.cv[0];
+            if ((int64_t)f.height * f.width > (int64_t)MQ_JPEG_MAX_PIXELS) return MQ_EUNSUPPORTED;
+            f.mcux = (f.width + 8 * f.hmax - 1) / (8 * f.hmax);
+            f.mcuy = (f.height + 8 * f.vmax - 1) / (8 * f.vmax);
+            int first = 0;
+            for (int c = 0; c < f.ncomp; ++c) {
+                f.bw[c] = f.mcux * f.ch[c];
+                f.bh[c] = f.mcuy * f.cv[c];
+                f.first[c] = first;
+                first += f.bw[c] * f.bh[c];
+            }
+            f.blocks = first;
+            out.scan = d + pos;
+            return MQ_OK;
+        }
+        // every other segment (APPn, COM, ...) is skipped
+    }
+}
+
+static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+static size_t staging_bytes(const Frame& f) {
+    const size_t coef = (size_t)f.blocks * 128, rgb = align16((size_t)f.height * f.width * 3);
+    return HDR + (coef > rgb ? coef : rgb);
+}
+
+static inline int decode_symbol(Bits& b, const Huff& t) {
+    const unsigned e = t.look[b.peek(9)];
+    if (e) { b.drop(e >> 8); return e & 255; }
+    const unsigned v = b.peek(16);
+    for (int l = 10; l <= 16; ++l) {
+        const int code = (int)(v >> (16 - l));
+        if (code <= t.maxcode[l]) { b.drop(l); return t.vals[(code + t.valoff[l]) & 255]; }
+    }
+    return -1;
+}
+
+static inline int extend(Bits& b, int s) {
+    const int v = (int)b.peek(s);
+    b.drop(s);
+    return v < (1 << (s - 1)) ? v + (int)((~0u) << s) + 1 : v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mq_jpeg_probe(const uint8_t* file_host, size_t nbytes, int64_t* info_host) {
+    if (!info_host) return MQ_EINVAL;
+    Parsed* ps = new Parsed;
+    const int rc = parse(file_host, nbytes, *ps);
+    if (rc == MQ_OK) {
+        const Frame& f = ps->f;
+        info_host[0] = f.height;
+        info_host[1] = f.width;
+        info_host[2] = f.ncomp;
+        info_host[3] = f.blocks;
+        info_host[4] = (int64_t)staging_bytes(f);
+        info_host[5] = f.ncomp == 1 ? 0 : f.hmax * 16 + f.vmax;
+    }
+    delete ps;
+    return rc;
+}
+
+int mq_jpeg_read_coefficients(const uint8_t* file_host, size_t nbytes, void* staging_host, size_t staging_cap) {
+    if (!staging_host || (reinterpret_cast<uintptr_t>(staging_host) & 3)) return MQ_EINVAL;
+    Parsed* ps = new Parsed;
+    int rc = parse(file_host, nbytes, *ps);
+    if (rc != MQ_OK) { delete ps; return rc; }
+    const Frame& f = ps->f;
+    if (staging_bytes(f) > staging_cap) { delete ps; return MQ_EINVAL; }
+    int32_t* hw = static_cast<int32_t*>(staging_host);
+    memset(hw, 0, HDR);
+    hw[H_HEIGHT] = f.height; hw[H_WIDTH] = f.width; hw[H_NCOMP] = f.ncomp; hw[H_HMAX] = f.hmax; hw[H_VMAX] = f.vmax;
+    hw[H_MCUX] = f.mcux; hw[H_MCUY] = f.mcuy; hw[H_BLOCKS] = f.blocks;
+    uint16_t* q = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(staging_host) + 128);
+    for (int c = 0; c < f.ncomp; ++c) {
+        hw[H_CH + c] = f.ch[c]; hw[H_CV + c] = f.cv[c]; hw[H_BW + c] = f.bw[c]; hw[H_BH + c] = f.bh[c]; hw[H_FIRST + c] = f.first[c];
+        hw[H_DW + c] = (f.width * f.ch[c] + f.hmax - 1) / f.hmax;    // downsampled_width / _height (jdmaster.c): the REAL samples
+        hw[H_DH + c] = (f.height * f.cv[c] + f.vmax - 1) / f.vmax;
+        memcpy(q + 64 * c, ps->qt[f.tq[c]], 128);
+    }
+    int16_t* coef = reinterpret_cast<int16_t*>(static_cast<uint8_t*>(staging_host) + HDR);
+    memset(coef, 0, (size_t)f.blocks * 128);
+
+    Bits b{ps->scan, file_host + nbytes, 0, 0, 0};
+    int pred[3] = {0, 0, 0};
+    int todo = ps->restart, rst = 0;
+    bool bad = false;
+    for (int my = 0; my < f.mcuy && !bad; ++my)
+        for (int mx = 0; mx < f.mcux && !bad; ++mx) {
+            if (ps->restart && todo == 0) {
+                // the interval's bits are used up: whatever is left of the last byte is padding; the marker must follow at once
+                if (b.n < b.fake || b.n - b.fake >= 8) { bad = true; break; }
+                if (!(b.p + 1 < b.end && b.p[0] == 0xFF && b.p[1] == 0xD0 + rst)) { bad = true; break; }
+                b.p += 2;
+                b.acc = 0; b.n = 0; b.fake = 0;
+                rst = (rst + 1) & 7;
+                pred[0] = pred[1] = pred[2] = 0;
+                todo = ps->restart;
+            }
+            for (int c = 0; c < f.ncomp; ++c) {
+                const Huff& dc = ps->dc[ps->td[c]];
+                const Huff& ac = ps->ac[ps->ta[c]];
+                for (int by = 0; by < f.cv[c]; ++by)
+                    for (int bx = 0; bx < f.ch[c]; ++bx) {
+                        int16_t* blk = coef + ((size_t)f.first[c] + (size_t)(my * f.cv[c] + by) * f.bw[c] + (mx * f.ch[c] + bx)) * 64;
+                        b.fill();
+                        int s = decode_symbol(b, dc);
+                        if (s < 0 || s > 11) { bad = true; goto done; }
+                        if (s) pred[c] += extend(b, s);
+                        blk[0] = (int16_t)pred[c];
+                        for (int k = 1; k < 64;) {
+                            b.fill();
+                            const int fa = ac.fast_ac[b.peek(9)];
+                            if (fa) {
+                                k += (fa >> 4) & 15;
+                                if (k > 63) { bad = true; goto done; }
+                                b.drop(fa & 15);
+                                blk[NATURAL[k++]] = (int16_t)(fa >> 8);
+                                continue;
+                            }
+                            const int rs = decode_symbol(b, ac);
+                            if (rs < 0) { bad = true; goto done; }
+                            const int r = rs >> 4;
+                            s = rs & 15;
+                            if (s == 0) {
+                                if (r != 15) break;   // end of block
+                                k += 16;
+                                continue;
+                            }
+                            k += r;
+                            if (k > 63) { bad = true; goto done; }   // (libjpeg warns and carries on: such a file is Pillow's to decode)
+                            blk[NATURAL[k++]] = (int16_t)extend(b, s);
+                        }
+                    }
+            }
+            --todo;
+        }
+done:
+    // nothing but the padding of the last byte may be left, and the next thing in the file is the end-of-image marker
+    if (!bad && (b.n < b.fake || b.n - b.fake >= 8)) bad = true;
+    if (!bad && !(b.p + 1 < b.end && b.p[0] == 0xFF && b.p[1] == 0xD9)) bad = true;
+    delete ps;
+    if (bad) return MQ_EINVAL;
+    hw[H_MAGIC] = MQ_JPEG_MAGIC_COEFFICIENTS;
+    return MQ_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// device
+namespace {
+
+constexpr int CONST_BITS = 13, PASS1_BITS = 2;
+
+template <int SHIFT>
+__device__ __forceinline__ void lll8(int& v0, int& v1, int& v2, int& v3, int& v4, int& v5, int& v6, int& v7) {
+    // one 8-point pass of jidctint.c jpeg_idct_islow (even part, odd part, butterflies), DESCALEd by SHIFT
+    int z1 = (v2 + v6) * 4433;
+    const int tmp2 = z1 + v6 * (-15137);
+    const int tmp3 = z1 + v2 * 6270;
+    const int tmp0 = (v0 + v4) << CONST_BITS;
+    const int tmp1 = (v0 - v4) << CONST_BITS;
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    int t0 = v7, t1 = v5, t2 = v3, t3 = v1;
+    z1 = t0 + t3;
+    int z2 = t1 + t2, z3 = t0 + t2, z4 = t1 + t3;
+    const int z5 = (z3 + z4) * 9633;
+    t0 *= 2446; t1 *= 16819; t2 *= 25172; t3 *= 12299;
+    z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
+    z3 += z5; z4 += z5;
+    t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+    constexpr int R = 1 << (SHIFT - 1);
+    v0 = (tmp10 + t3 + R) >> SHIFT; v7 = (tmp10 - t3 + R) >> SHIFT;
+    v1 = (tmp11 + t2 + R) >> SHIFT; v6 = (tmp11 - t2 + R) >> SHIFT;
+    v2 = (tmp12 + t1 + R) >> SHIFT; v5 = (tmp12 - t1 + R) >> SHIFT;
+    v3 = (tmp13 + t0 + R) >> SHIFT; v4 = (tmp13 - t0 + R) >> SHIFT;
+}
+
+// grid (block chunks, images), 128 threads: thread = one 8 x 8 block of the image, all components in one index space
+__global__ __launch_bounds__(128) void jpeg_idct_kernel(uint8_t* __restrict__ buf, const int64_t* __restrict__ items) {
+    const int img = blockIdx.y;
+    uint8_t* st = buf + items[2 * img];
+    const int32_t* hw = reinterpret_cast<const int32_t*>(st);
+    if (hw[H_MAGIC] != MQ_JPEG_MAGIC_COEFFICIENTS) return;
+    const int nblocks = hw[H_BLOCKS];
+    const int blk = blockIdx.x * 128 + threadIdx.x;
+    if (blk >= nblocks) return;
+    const int ncomp = hw[H_NCOMP];
+    int c = 0;
+    if (ncomp == 3) c = blk >= hw[H_FIRST + 2] ? 2 : (blk >= hw[H_FIRST + 1] ? 1 : 0);
+    const uint16_t* qt = reinterpret_cast<const uint16_t*>(st + 128) + 64 * c;
+    int4* p = reinterpret_cast<int4*>(st + HDR + (size_t)blk * 128);
+    int v[8][8];   // [row][column], natural order
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int4 cw = p[r];
+        const int4 qw = *reinterpret_cast<const int4*>(qt + 8 * r);
+        const int cc[4] = {cw.x, cw.y, cw.z, cw.w}, qq[4] = {qw.x, qw.y, qw.z, qw.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[r][2 * j] = (int)(short)(cc[j] & 0xFFFF) * (qq[j] & 0xFFFF);
+            v[r][2 * j + 1] = (cc[j] >> 16) * (int)((unsigned)qq[j] >> 16);
+        }
+    }
+#pragma unroll
+    for (int col = 0; col < 8; ++col)
+        lll8<CONST_BITS - PASS1_BITS>(v[0][col], v[1][col], v[2][col], v[3][col], v[4][col], v[5][col], v[6][col], v[7][col]);
+    uint2* o = reinterpret_cast<uint2*>(p);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        lll8<CONST_BITS + PASS1_BITS + 3>(v[r][0], v[r][1], v[r][2], v[r][3], v[r][4], v[r][5], v[r][6], v[r][7]);
+        unsigned w[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int s = v[r][j] + 128;
+            s = s < 0 ? 0 : (s > 255 ? 255 : s);
+            w[j >> 2] |= (unsigned)s << (8 * (j & 3));
+        }
+        o[r] = make_uint2(w[0], w[1]);   // the block's samples, 8 bytes per row, in the first half of its own coefficient bytes
+    }
+}
+
+struct Plane {
+    const uint8_t* base;  // the component's first block
+    int bw, dw, dh;
+    __device__ __forceinline__ int at(int y, int x) const {
+        return base[((size_t)(y >> 3) * bw + (x >> 3)) * 128 + ((y & 7) << 3) + (x & 7)];
+    }
+};
+
+__device__ __forceinline__ int upsampled(const Plane& p, int hexp, int vexp, int y, int x) {
+    if (hexp == 1 && vexp == 1) return p.at(y, x);
+    if (hexp == 2 && vexp == 1) {   // h2v1_fancy_upsample / h2v1_upsample
+        const int cx = x >> 1;
+        if (p.dw <= 2) return p.at(y, cx);
+        const int nb = (x & 1) ? (cx + 1 < p.dw ? cx + 1 : cx) : (cx > 0 ? cx - 1 : 0);
+        return (3 * p.at(y, cx) + p.at(y, nb) + ((x & 1) ? 2 : 1)) >> 2;
+    }
+    const int cy = y >> 1;
+    const int ny = (y & 1) ? (cy + 1 < p.dh ? cy + 1 : cy) : (cy > 0 ? cy - 1 : 0);   // the row above the first / below the last real row is that row
+    if (hexp == 1) return (3 * p.at(cy, x) + p.at(ny, x) + ((y & 1) ? 2 : 1)) >> 2;    // h1v2_fancy_upsample
+    const int cx = x >> 1;
+    if (p.dw <= 2) return p.at(cy, cx);                                                 // h2v2_upsample
+    const int nx = (x & 1) ? (cx + 1 < p.dw ? cx + 1 : cx) : (cx > 0 ? cx - 1 : 0);
+    const int s0 = 3 * p.at(cy, cx) + p.at(ny, cx), s1 = 3 * p.at(cy, nx) + p.at(ny, nx);
+    return (3 * s0 + s1 + ((x & 1) ? 7 : 8)) >> 4;                                     // h2v2_fancy_upsample
+}
+
+// grid (pixel chunks, images), 256 threads: thread = one pixel
+__global__ __launch_bounds__(256) void jpeg_rgb_kernel(uint8_t* __restrict__ buf, const int64_t* __restrict__ items) {
+    const int img = blockIdx.y;
+    const uint8_t* st = buf + items[2 * img];
+    uint8_t* dst = buf + items[2 * img + 1];
+    const int32_t* hw = reinterpret_cast<const int32_t*>(st);
+    const int h = hw[H_HEIGHT], w = hw[H_WIDTH];
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if (px >= h * w) return;
+    if (hw[H_MAGIC] == MQ_JPEG_MAGIC_RGB) {   // a file Pillow decoded on the host: its RGB bytes sit behind the header
+        const uint8_t* s = st + HDR + (size_t)px * 3;
+        dst[(size_t)px * 3] = s[0]; dst[(size_t)px * 3 + 1] = s[1]; dst[(size_t)px * 3 + 2] = s[2];
+        return;
+    }
+    if (hw[H_MAGIC] != MQ_JPEG_MAGIC_COEFFICIENTS) return;
+    const int y = px / w, x = px - y * w;
+    const uint8_t* blocks = st + HDR;
+    Plane p0{blocks, hw[H_BW], hw[H_DW], hw[H_DH]};
+    const int Y = p0.at(y, x);
+    int r = Y, g = Y, b = Y;
+    if (hw[H_NCOMP] == 3) {
+        const int hexp = hw[H_HMAX], vexp = hw[H_VMAX];   // chroma is 1 x 1: its expansion is the luma's factor
+        Plane p1{blocks + (size_t)hw[H_FIRST + 1] * 128, hw[H_BW + 1], hw[H_DW + 1], hw[H_DH + 1]};
+        Plane p2{blocks + (size_t)hw[H_FIRST + 2] * 128, hw[H_BW + 2], hw[H_DW + 2], hw[H_DH + 2]};
+        const int cb = upsampled(p1, hexp, vexp, y, x) - 128, cr = upsampled(p2, hexp, vexp, y, x) - 128;
+        // jdcolor.c: FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554, ONE_HALF = 32768
+        r = Y + ((91881 * cr + 32768) >> 16);
+        g = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+        b = Y + ((116130 * cb + 32768) >> 16);
+        r = r < 0 ? 0 : (r > 255 ? 255 : r);
+        g = g < 0 ? 0 : (g > 255 ? 255 : g);
+        b = b < 0 ? 0 : (b > 255 ? 255 : b);
+    }
+    dst[(size_t)px * 3] = (uint8_t)r; dst[(size_t)px * 3 + 1] = (uint8_t)g; dst[(size_t)px * 3 + 2] = (uint8_t)b;
+}
+
+}  // namespace
+
+extern "C" int mq_jpeg_decode_rgb_u8(uint8_t* buf_dev, const int64_t* items_dev, int n_images, int max_blocks, int64_t max_pixels,
+                                     void* stream) {
+    if (n_images == 0) return MQ_OK;
+    if (!buf_dev || !items_dev || n_images < 0 || max_blocks < 0 || max_pixels < 1 || max_pixels > MQ_JPEG_MAX_PIXELS ||
+        n_images > 65535 || (reinterpret_cast<uintptr_t>(buf_dev) & 15))
+        return MQ_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (max_blocks > 0)
+        hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((max_blocks + 127) / 128), (unsigned)n_images), dim3(128), 0, st, buf_dev, items_dev);
+    hipLaunchKernelGGL(jpeg_rgb_kernel, dim3((unsigned)((max_pixels + 255) / 256), (unsigned)n_images), dim3(256), 0, st, buf_dev, items_dev);
+    JPG_HIP(hipGetLastError());
+    return MQ_OK;
+}
