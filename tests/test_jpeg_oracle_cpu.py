@@ -82,3 +82,86 @@ def test_idct_of_a_dc_only_block_is_flat():
     c[:, 0, 0] = [-1024, 8, 1016]
     out = oj.idct_islow(c)
     assert [int(o[0, 0]) for o in out] == [0, 129, 255] and all((o == o[0, 0]).all() for o in out)
+
+
+# ---- the host half of the split decoder (csrc/jpeg.hip: mq_jpeg_probe / mq_jpeg_read_coefficients; no GPU needed) ----------
+def _staged(data):
+    from viquae_amd.image import jpeg as dj
+    p = dj.probe(data)
+    assert p is not None
+    st = np.zeros(p[4], dtype=np.uint8)
+    assert dj.stage(data, st.ctypes.data, st.size)
+    return p, st
+
+
+def test_host_coefficients_equal_the_oracles():
+    rng = np.random.default_rng(7)
+    for i in range(40):
+        h, w = jp.sizes(rng)
+        data, kw = jp.encode(rng, jp.picture(rng, min(h, 200), min(w, 200), grey=(i % 7 == 0)))
+        (hh, ww, ncomp, blocks, nbytes), st = _staged(data)
+        f = oj.read_coefficients(data)
+        hw = st[:128].view(np.int32)
+        assert (hh, ww, ncomp) == (h if h <= 200 else 200, w if w <= 200 else 200, len(f["components"])) and hw[23] == blocks
+        coef = st[512:512 + blocks * 128].view(np.int16).reshape(-1, 64)
+        for c, comp in enumerate(f["components"]):
+            first, bw, bh = hw[20 + c], hw[14 + c], hw[17 + c]
+            assert np.array_equal(coef[first:first + bw * bh].reshape(bh, bw, 64), comp["coef"][:bh, :bw]), (i, c, kw)
+            assert np.array_equal(st[128 + 128 * c:256 + 128 * c].view(np.uint16).astype(np.int64), f["qt"][comp["tq"]])
+        # the oracle's arithmetic on the library's coefficients = Pillow's pixels
+        assert nbytes % 16 == 0 and nbytes >= 512 + max(blocks * 128, hh * ww * 3)
+
+
+def test_host_decoder_declines_what_it_does_not_cover():
+    from viquae_amd.image import jpeg as dj
+    im = jp.picture(np.random.default_rng(0), 40, 56)
+    buf = io.BytesIO()
+    im.save(buf, "JPEG", progressive=True)
+    assert dj.probe(buf.getvalue()) is None
+    buf = io.BytesIO()
+    im.convert("CMYK").save(buf, "JPEG")
+    assert dj.probe(buf.getvalue()) is None
+    buf = io.BytesIO()
+    im.save(buf, "PNG")
+    assert dj.probe(buf.getvalue()) is None
+    assert dj.probe(b"") is None and dj.probe(b"\xff\xd8\xff") is None
+
+
+def test_blocks_outside_the_16_bit_domain_are_left_to_pillow():
+    """libjpeg-turbo's vector inverse DCT wraps / saturates in 16-bit lanes where the C code (and the device kernel) carry 32 bits:
+    a block whose coefficients could leave 16 bits in the column pass (damaged data) is declined.  Made here by raising a
+    quantisation table entry of a good file: the scan is untouched, the dequantised values are 255 x larger."""
+    from viquae_amd.image import jpeg as dj
+    buf = io.BytesIO()
+    jp.picture(np.random.default_rng(4), 48, 48).save(buf, "JPEG", quality=50)
+    data = bytearray(buf.getvalue())
+    p = dj.probe(bytes(data))
+    st = np.zeros(p[4], dtype=np.uint8)
+    assert dj.stage(bytes(data), st.ctypes.data, st.size)
+    at = data.find(b"\xff\xdb")
+    data[at + 5] = 255   # the DC entry of the first table
+    assert not dj.stage(bytes(data), st.ctypes.data, st.size)
+
+
+def test_irregular_scans_are_left_to_pillow():
+    """A truncated file, a missing end-of-image marker, a flipped bit that derails the Huffman stream, a marker in the middle of
+    the scan: ``stage`` reports failure (the caller falls back to Pillow, whose behaviour is the reference's)."""
+    from viquae_amd.image import jpeg as dj
+    buf = io.BytesIO()
+    jp.picture(np.random.default_rng(2), 64, 80).save(buf, "JPEG", quality=85)
+    good = buf.getvalue()
+    p = dj.probe(good)
+    st = np.zeros(p[4], dtype=np.uint8)
+    assert dj.stage(good, st.ctypes.data, st.size)
+    for bad in (good[:len(good) // 2], good[:-2], good[:-2] + b"\xff\xd0", good[:-300] + b"\xff\xd9"):
+        assert not dj.stage(bad, st.ctypes.data, st.size)
+    derailed = 0
+    for k in range(40):
+        b = bytearray(good)
+        b[len(good) - 400 + 9 * k] ^= 0x10
+        if not dj.stage(bytes(b), st.ctypes.data, st.size):
+            derailed += 1
+        else:   # a flip that only changes some coefficients (Huffman streams resynchronise): a regular scan, the same pixels as Pillow's
+            assert np.array_equal(oj.decode(bytes(b)), _pillow(bytes(b))), k
+    assert 5 <= derailed < 40
+    assert not dj.stage(good, st.ctypes.data, 100)   # a staging area that is too small

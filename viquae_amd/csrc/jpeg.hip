@@ -352,6 +352,11 @@ int mq_jpeg_read_coefficients(const uint8_t* file_host, size_t nbytes, void* sta
                         if (s < 0 || s > 11) { bad = true; goto done; }
                         if (s) pred[c] += extend(b, s);
                         blk[0] = (int16_t)pred[c];
+                        // per column of the block, a bound on what the column pass of the inverse DCT can return: see the
+                        // note behind the loop
+                        const uint16_t* qn = ps->qt[f.tq[c]];
+                        if (pred[c] < -32768 || pred[c] > 32767) { bad = true; goto done; }
+                        int64_t colb[8] = {(int64_t)(pred[c] < 0 ? -pred[c] : pred[c]) * qn[0] * 256, 0, 0, 0, 0, 0, 0, 0};
                         for (int k = 1; k < 64;) {
                             b.fill();
                             const int fa = ac.fast_ac[b.peek(9)];
@@ -359,7 +364,9 @@ int mq_jpeg_read_coefficients(const uint8_t* file_host, size_t nbytes, void* sta
                                 k += (fa >> 4) & 15;
                                 if (k > 63) { bad = true; goto done; }
                                 b.drop(fa & 15);
-                                blk[NATURAL[k++]] = (int16_t)(fa >> 8);
+                                const int v = fa >> 8, at = NATURAL[k++];
+                                blk[at] = (int16_t)v;
+                                colb[at & 7] += (int64_t)(v < 0 ? -v : v) * qn[at] * (at < 8 ? 256 : 356);
                                 continue;
                             }
                             const int rs = decode_symbol(b, ac);
@@ -373,7 +380,23 @@ int mq_jpeg_read_coefficients(const uint8_t* file_host, size_t nbytes, void* sta
                             }
                             k += r;
                             if (k > 63) { bad = true; goto done; }   // (libjpeg warns and carries on: such a file is Pillow's to decode)
-                            blk[NATURAL[k++]] = (int16_t)extend(b, s);
+                            const int v = extend(b, s), at = NATURAL[k++];
+                            blk[at] = (int16_t)v;
+                            colb[at & 7] += (int64_t)(v < 0 ? -v : v) * qn[at] * (at < 8 ? 256 : 356);
+                        }
+                        // libjpeg-turbo's vector code keeps the inverse DCT's operands and the column pass's results in 16-bit
+                        // lanes (and wraps or saturates there); the C code it replaces, and jpeg_idct_kernel below, work in 32
+                        // bits.  They agree while nothing leaves 16 bits.  Column j's results are sums of its eight operands
+                        // weighted by 1 (row 0) or sqrt(2) cos(.) <= 1.39, times 2^PASS1_BITS: at most colb[j] / 64; the row
+                        // pass adds columns 0 + 4, 3 + 7 and 1 + 5 in 16 bits (the column pass the same rows of operands,
+                        // which are smaller).  Blocks of encoded pictures -- full-amplitude noise excepted -- stay far below;
+                        // a file with a block beyond the bound (damaged data, as a rule) is Pillow's.
+                        {
+                            constexpr int64_t LIM = 32767 * 64;
+                            if (colb[2] > LIM || colb[6] > LIM || colb[0] + colb[4] > LIM || colb[3] + colb[7] > LIM || colb[1] + colb[5] > LIM) {
+                                bad = true;
+                                goto done;
+                            }
                         }
                     }
             }
