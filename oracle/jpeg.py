@@ -423,3 +423,26 @@ def decode(data):
     if len(planes) == 1:
         return np.repeat(planes[0][:, :, None], 3, axis=2)
     return ycc_to_rgb(*planes)
+
+
+def decode_staging(buf):
+    """The staging area csrc/jpeg.hip's host half writes for one file (include/meerqat_hip.h, mq_jpeg_read_coefficients: a
+    512-byte header, then int16 coefficient blocks in natural order) -> uint8 [height, width, 3]: the arithmetic of ``decode`` on
+    the LIBRARY's coefficients (CPU tests of the host half; the device half is compared with Pillow on the GPU)."""
+    buf = np.asarray(buf, dtype=np.uint8)
+    hw = buf[:128].view(np.int32)
+    height, width, ncomp, hmax, vmax = (int(v) for v in hw[1:6])
+    if int(hw[0]) == 0x20424752:   # MQ_JPEG_MAGIC_RGB: decoded by other means, stored as is
+        return buf[512:512 + height * width * 3].reshape(height, width, 3).copy()
+    assert int(hw[0]) == 0x4745504A, "not a staging area"
+    planes = []
+    for c in range(ncomp):
+        ch, cv, bw, bh, first, dw, dh = (int(hw[i + c]) for i in (8, 11, 14, 17, 20, 24, 27))
+        q = buf[128 + 128 * c:256 + 128 * c].view(np.uint16).astype(np.int64)
+        coef = buf[512 + first * 128:512 + (first + bw * bh) * 128].view(np.int16).astype(np.int64) .reshape(-1, 64) * q[None, :]
+        px = idct_islow(coef.reshape(-1, 8, 8)).reshape(bh, bw, 8, 8)
+        plane = px.transpose(0, 2, 1, 3).reshape(bh * 8, bw * 8)
+        planes.append(upsample(plane[:dh, :dw], hmax // ch, vmax // cv)[:height, :width])
+    if ncomp == 1:
+        return np.repeat(planes[0][:, :, None], 3, axis=2)
+    return ycc_to_rgb(*planes)

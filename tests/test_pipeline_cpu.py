@@ -1,5 +1,6 @@
 """CPU: the host logic of the encode pipeline (viquae_amd/pipeline.py) -- the tokenizer fast path against the tokenizer's own
 output, and the lookahead scheduler (order, back-pressure, worker failures).  No GPU work."""
+import io
 import threading
 import time
 
@@ -188,7 +189,7 @@ def test_decode_pool_writes_rgb_bytes_into_the_shared_slots(tmp_path):
             slot = pool.take_slot()
             assert slot == rep % 2
             with pytest.warns(UserWarning, match="trunc.jpg"):
-                failed = pool.decode(slot, offs)
+                failed = pool.decode(slot, offs, staged=set())    # every file as RGB bytes (the JPEG files too: Pillow)
             assert failed == {9}
             buf = pool.tensors[slot].numpy()
             for i in kept:
@@ -197,6 +198,89 @@ def test_decode_pool_writes_rgb_bytes_into_the_shared_slots(tmp_path):
                 h, w = sizes[i]
                 assert want[i].shape == (h, w, 3)
                 assert np.array_equal(buf[offs[i]:offs[i] + h * w * 3].reshape(h, w, 3), want[i]), i
+    finally:
+        pool.close()
+
+
+def test_decode_pool_stages_jpeg_scans_for_the_device(tmp_path):
+    """JPEG files the split decoder covers leave the workers as staging areas (header + quantised coefficients, csrc/jpeg.hip) at
+    the offsets of `viquae_amd.image.jpeg.plan_layout`; the oracle's inverse DCT / upsampling / colour conversion on those areas
+    gives Pillow's pixels.  A progressive file and a PNG go the Pillow way (RGB bytes); a JPEG whose scan is damaged but which
+    Pillow still decodes is stored as RGB inside its staging area; a truncated one fails like before."""
+    from PIL import Image, ImageFile
+    from oracle import jpeg as oj
+    from viquae_amd.image import jpeg as dj
+    from viquae_amd.image.decode_pool import DecodePool
+    rng = np.random.default_rng(1)
+    paths = []
+    for i, kw in enumerate([dict(subsampling=2), dict(subsampling=0, quality=95), dict(subsampling=1, optimize=True), dict(progressive=True),
+                            dict(quality=30, restart_marker_blocks=2), None, dict(), dict()]):
+        h, w = int(rng.integers(20, 90)), int(rng.integers(20, 90))
+        a = np.clip(rng.normal(128, 50, (h, w, 3)), 0, 255).astype(np.uint8)
+        p = str(tmp_path / (f"{i}.jpg" if kw is not None else f"{i}.png"))
+        im = Image.fromarray(a)
+        if i == 6:
+            im = im.convert("L")
+        im.save(p, **(kw or {}))
+        paths.append(p)
+    data = open(paths[7], "rb").read()
+    (tmp_path / "cut.jpg").write_bytes(data[: len(data) * 2 // 3])     # fails in Pillow as well
+    paths.append(str(tmp_path / "cut.jpg"))
+    sos = data.find(b"\xff\xda")
+    damaged = None
+    for pos in range(sos + 20, len(data) - 2):                          # a damaged scan that Pillow still decodes (with a warning)
+        d = bytearray(data)
+        d[pos:pos + 2] = b"\xff\xd3"                                     # a restart marker where none belongs
+        p = dj.probe(bytes(d))
+        st = np.zeros(p[4], dtype=np.uint8)
+        if not dj.stage(bytes(d), st.ctypes.data, st.size):
+            try:
+                Image.open(io.BytesIO(bytes(d))).convert("RGB")
+                damaged = bytes(d)
+                break
+            except OSError:
+                continue
+    assert damaged is not None
+    (tmp_path / "damaged.jpg").write_bytes(damaged)
+    paths.append(str(tmp_path / "damaged.jpg"))
+    want = [None if p.endswith("cut.jpg") else np.asarray(Image.open(p).convert("RGB")) for p in paths]
+    pool = DecodePool(2, 1 << 21, n_slots=2)
+    try:
+        sizes = pool.sizes(paths)
+        assert all(s is not None for s in sizes)
+        assert set(pool.last_jpeg) == {0, 1, 2, 4, 6, 7, 8, 9}          # not the progressive file, not the PNG
+        geom = np.zeros((len(paths), 12), dtype=np.int64)
+        geom[:, 1:3] = sizes
+        totals = np.zeros(5, dtype=np.int64)
+        layout = dj.plan_layout(geom, totals, dict(pool.last_jpeg))
+        assert layout["h2d_bytes"] <= pool.slot_bytes and totals[0] > layout["h2d_bytes"] and (geom[:, 0] % 16 == 0).all()
+        slot = pool.take_slot()
+        with pytest.warns(UserWarning, match="cut.jpg"):
+            failed = pool.decode(slot, {i: int(layout["staging"].get(i, geom[i, 0])) for i in range(len(paths))})
+        assert failed == {8}
+        buf = pool.tensors[slot].numpy()
+        for i, (h, w) in enumerate(sizes):
+            if i == 8:
+                continue
+            if i in layout["staging"]:
+                o = layout["staging"][i]
+                got = oj.decode_staging(buf[o:o + pool.last_jpeg[i][1]])
+                magic = int(buf[o:o + 4].view(np.int32)[0])
+                assert magic == (dj.MAGIC_RGB if i == 9 else 0x4745504A)
+            else:
+                got = buf[geom[i, 0]:geom[i, 0] + h * w * 3].reshape(h, w, 3)
+            assert np.array_equal(got, want[i]), i
+        # a batch whose staging areas do not fit: the caller demotes the JPEG files to Pillow's RGB bytes
+        sizes = pool.sizes(paths[:3])
+        offs, o = {}, 0
+        for i, (h, w) in enumerate(sizes):
+            offs[i] = o
+            o += -(-(h * w * 3) // 16) * 16
+        slot = pool.take_slot()
+        assert pool.decode(slot, offs, staged=set()) == set()
+        buf = pool.tensors[slot].numpy()
+        for i, (h, w) in enumerate(sizes):
+            assert np.array_equal(buf[offs[i]:offs[i] + h * w * 3].reshape(h, w, 3), want[i])
     finally:
         pool.close()
 

@@ -9,6 +9,11 @@ forked workers each own a contiguous chunk of a batch's files and work in two ph
   decode   given each image's byte offset in staging slot s (from mq_image_plan, computed by the parent between the phases),
            decode + convert to RGB and write the H x W x 3 bytes straight into the slot -- nothing crosses a pipe but offsets
 
+JPEG files the library's split decoder covers (viquae_amd/image/jpeg.py, csrc/jpeg.hip; MQ_IMAGE_DEVICE_JPEG=0 switches it off) are
+only Huffman-decoded here: the worker writes their quantised coefficients into the slot and the GPU does the inverse DCT,
+the chroma upsampling and the colour conversion -- the same bytes as Pillow's, for about a third of the host time per file.  A
+file whose scan turns out irregular is decoded by Pillow after all and stored as RGB in the same place.
+
 The slots are anonymous shared mappings created BEFORE the fork (so every worker has them) and registered with the HIP
 runtime as page-locked, which makes the host -> device copy of a packed batch a plain asynchronous DMA.  Workers never touch the
 GPU.  A worker reproduces `meerqat.data.loading.load_image` (:108-119): unreadable or empty images are reported and become
@@ -27,8 +32,23 @@ _SLOTS = []   # the staging mappings; inherited by the forked workers
 _MAX_OPEN = 128  # lazily opened images a worker keeps between the `sizes` and the `decode` phase
 
 
+def _jpeg_bytes(path):
+    """The whole file if it starts like a JPEG, else None (any error: None -- the Pillow path reports it in its own words)."""
+    try:
+        with open(path, "rb") as f:
+            head = f.read(2)
+            if head != b"\xff\xd8":
+                return None
+            return head + f.read()
+    except OSError:
+        return None
+
+
 def _worker(conn, slots):
+    import io
     from PIL import Image
+    from . import jpeg as dj
+    device_jpeg = dj.enabled()
     opened = {}
     while True:
         try:
@@ -44,6 +64,13 @@ def _worker(conn, slots):
             out = []
             for n, path in enumerate(paths):
                 try:
+                    data = _jpeg_bytes(path) if device_jpeg else None
+                    info = dj.probe(data) if data is not None else None
+                    if info is not None:   # (height, width, components, blocks, staging bytes): the scan is decoded in `decode`
+                        opened[base + n] = ("jpeg", data, path, info)
+                        out.append(((info[0], info[1]), None, (info[3], info[4])))
+                        continue
+                    del data
                     # Lazily opened images keep their file descriptor until they are decoded.  Only a bounded number stays open
                     # between the two phases (a worker with a 1000-image chunk would pass the usual RLIMIT_NOFILE of 1024, and
                     # the EMFILE would be reported as an unreadable image): the rest is closed here and reopened in `decode`.
@@ -51,29 +78,46 @@ def _worker(conn, slots):
                     w, h = im.size
                     if w < 1 or h < 1:
                         im.close()
-                        out.append((None, f"Empty image '{path}'"))
+                        out.append((None, f"Empty image '{path}'", None))
                         continue
                     if len(opened) >= _MAX_OPEN:
                         im.close()
                         im = None
                     opened[base + n] = (im, path)
-                    out.append(((h, w), None))
+                    out.append(((h, w), None, None))
                 except OSError as e:
                     if e.errno in (errno.EMFILE, errno.ENFILE, errno.ENOMEM):
                         raise  # resource exhaustion is not "this image is unreadable"
-                    out.append((None, f"Caught exception '{e}' with image '{path}'"))
+                    out.append((None, f"Caught exception '{e}' with image '{path}'", None))
                 except Exception as e:  # noqa: BLE001 - load_image catches everything too
-                    out.append((None, f"Caught exception '{e}' with image '{path}'"))
+                    out.append((None, f"Caught exception '{e}' with image '{path}'", None))
             conn.send(out)
         elif kind == "decode":
-            _, slot, items = msg   # items: (index in the batch, byte offset in the slot)
+            _, slot, items = msg   # items: (index in the batch, byte offset in the slot, offset is a JPEG staging area)
             buf = np.frombuffer(slots[slot], dtype=np.uint8)
             failed = []
-            for idx, off in items:
-                im, path = opened.pop(idx)
+            for idx, off, staged in items:
+                entry = opened.pop(idx)
+                held = None
+                if entry[0] == "jpeg" and not staged:
+                    held, entry = entry[1], (None, entry[2])   # decoded by Pillow below, like the files of every other format
+                if entry[0] == "jpeg":
+                    _, data, path, info = entry
+                    try:
+                        if not dj.stage(data, buf.ctypes.data + off, info[4]):
+                            # an irregular scan (truncated, damaged, a marker inside): Pillow decides what this file is
+                            im = Image.open(io.BytesIO(data))
+                            a = np.asarray(im if im.mode == "RGB" else im.convert("RGB"))
+                            if a.shape[:2] != (info[0], info[1]):
+                                raise RuntimeError(f"Pillow decodes {a.shape[:2]}, the frame header says {info[:2]}")
+                            dj.stage_rgb(a, buf, off)
+                    except Exception as e:  # noqa: BLE001
+                        failed.append((idx, f"Caught exception '{e}' with image '{path}'"))
+                    continue
+                im, path = entry
                 try:
                     if im is None:
-                        im = Image.open(path)
+                        im = Image.open(path if held is None else io.BytesIO(held))
                     # load_image's `.convert('RGB')` is the identity on an RGB file: skip its full-size copy there
                     a = np.asarray(im if im.mode == "RGB" else im.convert("RGB"))
                     n = a.shape[0] * a.shape[1] * 3
@@ -112,6 +156,7 @@ class DecodePool:
             self.pinned.append(ok)
         self.next_slot = 0
         self._chunks = None
+        self.last_jpeg = {}
 
     def _recv(self, conn, what):
         if not conn.poll(600):
@@ -119,17 +164,21 @@ class DecodePool:
         return conn.recv()
 
     def sizes(self, paths):
-        """-> [(h, w) or None] per file; warnings for the unreadable ones (load_image's wording)."""
+        """-> [(h, w) or None] per file; warnings for the unreadable ones (load_image's wording).  ``self.last_jpeg`` names the
+        files that go through the split JPEG decoder."""
         n, w = len(paths), len(self.conns)
         per = -(-n // w)
         self._chunks = [(c, c * per, min(n, (c + 1) * per)) for c in range(w) if c * per < n]
         for c, lo, hi in self._chunks:
             self.conns[c].send(("sizes", lo, paths[lo:hi]))
         out = []
+        self.last_jpeg = {}   # index in the batch -> (blocks, staging bytes) of the files whose scan the workers will decode
         for c, lo, hi in self._chunks:
-            for size, err in self._recv(self.conns[c], "sizes"):
+            for size, err, jpeg in self._recv(self.conns[c], "sizes"):
                 if err:
                     warnings.warn(err)
+                if jpeg is not None:
+                    self.last_jpeg[len(out)] = jpeg
                 out.append(size)
         return out
 
@@ -138,10 +187,13 @@ class DecodePool:
         self.next_slot = (s + 1) % len(self.maps)
         return s
 
-    def decode(self, slot, offsets):
-        """offsets: {index in the batch: byte offset in `slot`} for the images to decode -> set of indices that failed."""
+    def decode(self, slot, offsets, staged=None):
+        """offsets: {index in the batch: byte offset in `slot`} for the images to decode (RGB bytes, or the staging area of a
+        ``last_jpeg`` file) -> set of indices that failed.  ``staged``: the indices whose offset IS a staging area (default: every
+        ``last_jpeg`` file); a ``last_jpeg`` file outside it is decoded by Pillow to RGB bytes like any other file."""
+        staged = set(self.last_jpeg) if staged is None else staged
         for c, lo, hi in self._chunks:
-            self.conns[c].send(("decode", slot, [(i, int(offsets[i])) for i in range(lo, hi) if i in offsets]))
+            self.conns[c].send(("decode", slot, [(i, int(offsets[i]), i in staged) for i in range(lo, hi) if i in offsets]))
         failed = set()
         for c, lo, hi in self._chunks:
             for idx, err in self._recv(self.conns[c], "decode"):

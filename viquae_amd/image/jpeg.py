@@ -46,6 +46,35 @@ def stage_rgb(rgb, buf, off):
     buf[off + HEADER:off + HEADER + h * w * 3] = rgb.reshape(-1)
 
 
+def plan_layout(geom, totals, jpeg_rows):
+    """The packed source buffer of a batch with split-decoded JPEG files in it.  ``geom`` / ``totals`` come from
+    ``mq_image_plan`` (every image's RGB bytes one after the other); ``jpeg_rows`` = {row of geom: (blocks, staging bytes)}.
+    Rewrites ``geom[:, 0]`` and ``totals[0]`` IN PLACE for the layout
+
+        [ RGB of the host-decoded images | staging areas of the JPEG files | RGB of the JPEG files ]
+          \_______________ copied from the host ________________________/   \__ written by the GPU __/
+
+    -> dict(h2d_bytes, staging = {row: offset}, items int64 [n, 2], max_blocks, max_pixels)."""
+    rows = sorted(jpeg_rows)
+    off = 0
+    for r in range(len(geom)):
+        if r not in jpeg_rows:
+            geom[r, 0] = off
+            off += (int(geom[r, 1]) * int(geom[r, 2]) * 3 + 15) & ~15
+    staging = {}
+    for r in rows:
+        staging[r] = off
+        off += int(jpeg_rows[r][1])
+    h2d = off
+    for r in rows:
+        geom[r, 0] = off
+        off += (int(geom[r, 1]) * int(geom[r, 2]) * 3 + 15) & ~15
+    totals[0] = off
+    return {"h2d_bytes": h2d, "staging": staging,
+            "items": np.array([[staging[r], int(geom[r, 0])] for r in rows], dtype=np.int64).reshape(-1, 2),
+            "max_blocks": max(int(jpeg_rows[r][0]) for r in rows), "max_pixels": max(int(geom[r, 1]) * int(geom[r, 2]) for r in rows)}
+
+
 def decode_staged(buf_dev, items, max_blocks, max_pixels, stream=None):
     """items int64 [n, 2] (header offset, RGB offset) inside the uint8 device tensor ``buf_dev``; enqueues the kernels."""
     import torch

@@ -132,18 +132,28 @@ class CLIPImageProcessorHIP:
             pack(0, B)
         return self.run_packed(packed, geom, totals, B, out=out)
 
-    def run_packed(self, packed, geom, totals, B, out=None, sync=True):
+    def run_packed(self, packed, geom, totals, B, out=None, sync=True, jpeg=None):
         """The device half of :meth:`preprocess`: ``packed`` = a (page-locked) uint8 CPU tensor that already holds the B decoded
         images at the byte offsets ``geom[:, 0]`` of :meth:`plan` (the image pipeline's decode workers write them there
         directly, viquae_amd/image/decode_pool.py) -> {"pixel_values": float32 [B, 3, crop_h, crop_w] on the device}.
         ``sync=False``: nothing is waited for -- the copy and the kernels are only enqueued on the current stream; the caller
-        keeps ``packed`` untouched, and the returned ``"_keep"`` tensors alive, until an event recorded after the call fires."""
+        keeps ``packed`` untouched, and the returned ``"_keep"`` tensors alive, until an event recorded after the call fires.
+        ``jpeg``: the layout of :func:`viquae_amd.image.jpeg.plan_layout` when some of the images are JPEG files whose scans the
+        workers decoded into staging areas -- only the first ``h2d_bytes`` of ``packed`` are copied, and ``mq_jpeg_decode_rgb_u8``
+        produces those images' RGB bytes on the device before the resize kernels read them."""
         lib = _lib.load()
         dev = torch.device(self.device if self.device is not None else "cuda")
         if out is None:
             out = torch.empty((B, 3, self.crop_h, self.crop_w), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            src = packed[:int(totals[0])].to(dev, non_blocking=True)
+            keep = ()
+            if jpeg is None:
+                src = packed[:int(totals[0])].to(dev, non_blocking=True)
+            else:
+                from . import jpeg as dj
+                src = torch.empty(int(totals[0]), dtype=torch.uint8, device=dev)
+                src[:jpeg["h2d_bytes"]].copy_(packed[:jpeg["h2d_bytes"]], non_blocking=True)
+                keep = (dj.decode_staged(src, jpeg["items"], jpeg["max_blocks"], jpeg["max_pixels"]),)
             gdev = torch.from_numpy(geom).to(dev, non_blocking=True)
             ws = torch.empty(max(int(totals[1]), 256), dtype=torch.uint8, device=dev)
             flags = (1 if self.do_rescale else 0) | (2 if self.do_normalize else 0)
@@ -153,7 +163,7 @@ class CLIPImageProcessorHIP:
                                                   ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream),
                        "mq_image_preprocess_u8")
             if not sync:
-                return {"pixel_values": out, "_keep": (src, gdev, ws)}
+                return {"pixel_values": out, "_keep": (src, gdev, ws) + keep}
             # the pinned staging buffer and the workspace may be recycled as soon as this returns
             torch.cuda.current_stream(dev).synchronize()
         return {"pixel_values": out}

@@ -477,18 +477,32 @@ class ImageEmbedPipeline:
         if not kept:
             return kept, set(), None, None
         geom, totals = self.transform.plan(np.array([sizes[i] for i in kept], dtype=np.int64))
-        if int(totals[0]) > self.decode.slot_bytes:
+        # JPEG files whose scans the workers decode (decode_pool.last_jpeg): staging areas instead of RGB bytes in the slot, their
+        # RGB produced on the device (viquae_amd/image/jpeg.py)
+        jrows = {row: self.decode.last_jpeg[k] for row, k in enumerate(kept) if k in self.decode.last_jpeg}
+        layout = None
+        if jrows:
+            from .image import jpeg as dj
+            layout = dj.plan_layout(geom, totals, jrows)
+        if layout is not None and int(layout["h2d_bytes"]) > self.decode.slot_bytes:
+            # coefficients take 2 bytes per sample: a batch of 4:4:4 files can outgrow a slot its RGB bytes fit -- the workers
+            # then decode this batch's files with Pillow, as they do for every other format
+            geom, totals = self.transform.plan(np.array([sizes[i] for i in kept], dtype=np.int64))
+            jrows, layout = {}, None
+        if int(layout["h2d_bytes"] if layout else totals[0]) > self.decode.slot_bytes:
             return None  # larger images than the slots were sized for: this batch takes the thread (or caller's pool) path
         slot = self.decode.take_slot()
         busy = self._slot_busy.pop(slot, None)
         if busy is not None:      # the copy that last read this slot (two batches ago) must be over before it is rewritten
             busy[0].synchronize()
-        failed = self.decode.decode(slot, {k: int(g[0]) for k, g in zip(kept, geom)})
+        failed = self.decode.decode(slot, {k: int(layout["staging"][row] if row in jrows else g[0]) for row, (k, g) in enumerate(zip(kept, geom))},
+                                    staged={k for row, k in enumerate(kept) if row in jrows})
+        self.stats["jpeg_scans_decoded_by_workers"] = self.stats.get("jpeg_scans_decoded_by_workers", 0) + len(jrows)
         self.stats["decode_s"] += time.perf_counter() - t0
         with torch.cuda.device(self.device), torch.cuda.stream(self.side):
             # enqueued only: the DMA of this slot and the resize kernels run while the workers decode the NEXT batch into the
             # other slot
-            got = self.transform.run_packed(self.decode.tensors[slot], geom, totals, len(kept), sync=False)
+            got = self.transform.run_packed(self.decode.tensors[slot], geom, totals, len(kept), sync=False, jpeg=layout)
             ev = torch.cuda.Event()
             ev.record(self.side)
         self._slot_busy[slot] = (ev, got.pop("_keep", None))
