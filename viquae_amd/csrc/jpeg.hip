@@ -48,15 +48,17 @@ static const uint8_t NATURAL[64 + 16] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24,
 
 // ------------------------------------------------------------------------------------------------------------------
 // host: markers and the Huffman scan
+constexpr int LOOK = 10;   // bits of look-ahead of the decoding tables
 struct Huff {
-    uint16_t look[512];   // 9 leading bits -> (code length << 8) | symbol, 0 = longer than 9 bits
-    int16_t fast_ac[512]; // AC only: 9 leading bits hold a whole (run, size, value): (value << 8) | (run << 4) | (length + size), else 0
+    // leading LOOK bits -> bits 0-4: code length (0 = the code is longer than LOOK bits), 5-8: run, 9-12: size (the symbol's two
+    // nibbles), bit 13: the value's `size` bits were inside the look-ahead too and bits 16-31 hold it, HUFF_EXTENDed
+    uint32_t tab[1 << LOOK];
     int32_t maxcode[18], valoff[17];
     uint8_t vals[256];
     bool defined;
 };
 
-static bool build_huff(Huff& t, const uint8_t* counts, const uint8_t* symbols, int nsym, bool ac) {
+static bool build_huff(Huff& t, const uint8_t* counts, const uint8_t* symbols, int nsym) {
     memset(&t, 0, sizeof(t));
     uint8_t size[257];
     uint32_t code[257];
@@ -85,22 +87,21 @@ static bool build_huff(Huff& t, const uint8_t* counts, const uint8_t* symbols, i
     }
     t.maxcode[17] = 0x7FFFFFFF;
     memcpy(t.vals, symbols, (size_t)nsym);
-    for (int i = 0; i < p; ++i)
-        if (size[i] <= 9) {
-            const int lo = (int)code[i] << (9 - size[i]);
-            for (int j = 0; j < (1 << (9 - size[i])); ++j) t.look[lo + j] = (uint16_t)((size[i] << 8) | symbols[i]);
-        }
-    if (ac)
-        for (int i = 0; i < 512; ++i) {
-            const uint16_t e = t.look[i];
-            if (!e) continue;
-            const int len = e >> 8, rs = e & 255, run = rs >> 4, mag = rs & 15;
-            if (mag && len + mag <= 9) {
-                int v = ((i << len) & 511) >> (9 - mag);
-                if (v < (1 << (mag - 1))) v += (int)((~0u) << mag) + 1;   // HUFF_EXTEND
-                if (v >= -128 && v <= 127) t.fast_ac[i] = (int16_t)(v * 256 + run * 16 + len + mag);
+    for (int i = 0; i < p; ++i) {
+        const int len = size[i];
+        if (len > LOOK) continue;
+        const int rs = symbols[i], mag = rs & 15;
+        const int lo = (int)code[i] << (LOOK - len);
+        for (int j = 0; j < (1 << (LOOK - len)); ++j) {
+            uint32_t e = (uint32_t)len | ((uint32_t)(rs >> 4) << 5) | ((uint32_t)mag << 9);
+            if (mag && len + mag <= LOOK) {
+                int v = (j >> (LOOK - len - mag)) & ((1 << mag) - 1);   // the `mag` bits behind the code
+                if (v < (1 << (mag - 1))) v += (int)((~0u) << mag) + 1;  // HUFF_EXTEND
+                e |= 0x2000u | ((uint32_t)(uint16_t)(int16_t)v << 16);
             }
+            t.tab[lo + j] = e;
         }
+    }
     t.defined = true;
     return true;
 }
@@ -112,6 +113,17 @@ struct Bits {
     int n;
     int fake;       // zero bits appended after the real data ran out (a marker or the end of the file)
     inline void fill() {
+        if (n > 32) return;   // a symbol and its value take 31 bits at most
+        if (p + 4 <= end) {
+            const uint32_t w = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+            const uint32_t x = ~w;
+            if (((x - 0x01010101u) & ~x & 0x80808080u) == 0) {   // no 0xFF among the four bytes: nothing to unstuff, no marker
+                acc = (acc << 32) | w;
+                n += 32;
+                p += 4;
+                return;
+            }
+        }
         while (n <= 56) {
             unsigned b = 0;
             if (p < end && p[0] != 0xFF) b = *p++;
@@ -182,7 +194,7 @@ static int parse(const uint8_t* d, size_t nbytes, Parsed& out) {
                 int ns = 0;
                 for (int i = 0; i < 16; ++i) ns += s[q + 1 + i];
                 if (ns > 256 || q + 17 + ns > sl) return MQ_EINVAL;
-                if (!build_huff(tc ? out.ac[th] : out.dc[th], s + q + 1, s + q + 17, ns, tc == 1)) return MQ_EINVAL;
+                if (!build_huff(tc ? out.ac[th] : out.dc[th], s + q + 1, s + q + 17, ns)) return MQ_EINVAL;
                 q += 17 + (size_t)ns;
             }
         } else if (m == 0xC0 || m == 0xC1) {
@@ -266,11 +278,10 @@ static size_t staging_bytes(const Frame& f) {
     return HDR + (coef > rgb ? coef : rgb);
 }
 
-static inline int decode_symbol(Bits& b, const Huff& t) {
-    const unsigned e = t.look[b.peek(9)];
-    if (e) { b.drop(e >> 8); return e & 255; }
+// a code longer than the look-ahead: -> its symbol, -1 when no code matches
+static inline int decode_slow(Bits& b, const Huff& t) {
     const unsigned v = b.peek(16);
-    for (int l = 10; l <= 16; ++l) {
+    for (int l = LOOK + 1; l <= 16; ++l) {
         const int code = (int)(v >> (16 - l));
         if (code <= t.maxcode[l]) { b.drop(l); return t.vals[(code + t.valoff[l]) & 255]; }
     }
@@ -348,55 +359,70 @@ int mq_jpeg_read_coefficients(const uint8_t* file_host, size_t nbytes, void* sta
                     for (int bx = 0; bx < f.ch[c]; ++bx) {
                         int16_t* blk = coef + ((size_t)f.first[c] + (size_t)(my * f.cv[c] + by) * f.bw[c] + (mx * f.ch[c] + bx)) * 64;
                         b.fill();
-                        int s = decode_symbol(b, dc);
-                        if (s < 0 || s > 11) { bad = true; goto done; }
-                        if (s) pred[c] += extend(b, s);
+                        {
+                            const uint32_t e = dc.tab[b.peek(LOOK)];
+                            if (e & 0x2000u) {
+                                b.drop((int)(e & 31) + (int)((e >> 9) & 15));
+                                pred[c] += (int)(int16_t)(e >> 16);
+                            } else {
+                                int s;
+                                if (e & 31) { b.drop((int)(e & 31)); s = (int)((e >> 9) & 15) | ((int)((e >> 5) & 15) << 4); }
+                                else s = decode_slow(b, dc);
+                                if (s < 0 || s > 11) { bad = true; goto done; }
+                                if (s) pred[c] += extend(b, s);
+                            }
+                        }
                         blk[0] = (int16_t)pred[c];
-                        // per column of the block, a bound on what the column pass of the inverse DCT can return: see the
-                        // note behind the loop
+                        // per column of the block, the sum of its DEQUANTISED magnitudes: see the note behind the loop
                         const uint16_t* qn = ps->qt[f.tq[c]];
                         if (pred[c] < -32768 || pred[c] > 32767) { bad = true; goto done; }
-                        int64_t colb[8] = {(int64_t)(pred[c] < 0 ? -pred[c] : pred[c]) * qn[0] * 256, 0, 0, 0, 0, 0, 0, 0};
+                        unsigned colsum[8] = {(unsigned)(pred[c] < 0 ? -pred[c] : pred[c]) * qn[0], 0, 0, 0, 0, 0, 0, 0};
+                        unsigned big = colsum[0];
                         for (int k = 1; k < 64;) {
                             b.fill();
-                            const int fa = ac.fast_ac[b.peek(9)];
-                            if (fa) {
-                                k += (fa >> 4) & 15;
-                                if (k > 63) { bad = true; goto done; }
-                                b.drop(fa & 15);
-                                const int v = fa >> 8, at = NATURAL[k++];
-                                blk[at] = (int16_t)v;
-                                colb[at & 7] += (int64_t)(v < 0 ? -v : v) * qn[at] * (at < 8 ? 256 : 356);
-                                continue;
+                            const uint32_t e = ac.tab[b.peek(LOOK)];
+                            int run, v;
+                            if (e & 0x2000u) {   // code and value inside the look-ahead
+                                b.drop((int)(e & 31) + (int)((e >> 9) & 15));
+                                run = (int)((e >> 5) & 15);
+                                v = (int)(int16_t)(e >> 16);
+                            } else {
+                                int s;
+                                if (e & 31) {
+                                    b.drop((int)(e & 31));
+                                    run = (int)((e >> 5) & 15);
+                                    s = (int)((e >> 9) & 15);
+                                } else {
+                                    const int rs = decode_slow(b, ac);
+                                    if (rs < 0) { bad = true; goto done; }
+                                    run = rs >> 4;
+                                    s = rs & 15;
+                                }
+                                if (s == 0) {
+                                    if (run != 15) break;   // end of block
+                                    k += 16;
+                                    continue;
+                                }
+                                v = extend(b, s);
                             }
-                            const int rs = decode_symbol(b, ac);
-                            if (rs < 0) { bad = true; goto done; }
-                            const int r = rs >> 4;
-                            s = rs & 15;
-                            if (s == 0) {
-                                if (r != 15) break;   // end of block
-                                k += 16;
-                                continue;
-                            }
-                            k += r;
+                            k += run;
                             if (k > 63) { bad = true; goto done; }   // (libjpeg warns and carries on: such a file is Pillow's to decode)
-                            const int v = extend(b, s), at = NATURAL[k++];
+                            const int at = NATURAL[k++];
                             blk[at] = (int16_t)v;
-                            colb[at & 7] += (int64_t)(v < 0 ? -v : v) * qn[at] * (at < 8 ? 256 : 356);
+                            { const unsigned t = (unsigned)(v < 0 ? -v : v) * qn[at]; big = t > big ? t : big; colsum[at & 7] += t; }
                         }
                         // libjpeg-turbo's vector code keeps the inverse DCT's operands and the column pass's results in 16-bit
                         // lanes (and wraps or saturates there); the C code it replaces, and jpeg_idct_kernel below, work in 32
                         // bits.  They agree while nothing leaves 16 bits.  Column j's results are sums of its eight operands
-                        // weighted by 1 (row 0) or sqrt(2) cos(.) <= 1.39, times 2^PASS1_BITS: at most colb[j] / 64; the row
-                        // pass adds columns 0 + 4, 3 + 7 and 1 + 5 in 16 bits (the column pass the same rows of operands,
-                        // which are smaller).  Blocks of encoded pictures -- full-amplitude noise excepted -- stay far below;
-                        // a file with a block beyond the bound (damaged data, as a rule) is Pillow's.
-                        {
-                            constexpr int64_t LIM = 32767 * 64;
-                            if (colb[2] > LIM || colb[6] > LIM || colb[0] + colb[4] > LIM || colb[3] + colb[7] > LIM || colb[1] + colb[5] > LIM) {
-                                bad = true;
-                                goto done;
-                            }
+                        // weighted by 1 (row 0) or sqrt(2) cos(.) <= 1.39, times 2^PASS1_BITS: at most 5.56 colsum[j]; the
+                        // row pass adds columns 0 + 4, 3 + 7 and 1 + 5 in 16 bits (the column pass the same rows of operands,
+                        // which are smaller).  32767 / 5.56 = 5893.  A block of an encoded picture stays far below (a
+                        // full-contrast edge along the block: ~2700 in one column); a file with a block beyond the bound
+                        // (damaged data, as a rule) is Pillow's.
+                        if (big > 5890 || colsum[2] > 5890 || colsum[6] > 5890 || colsum[0] + colsum[4] > 5890 ||
+                            colsum[3] + colsum[7] > 5890 || colsum[1] + colsum[5] > 5890) {
+                            bad = true;
+                            goto done;
                         }
                     }
             }
