@@ -11,7 +11,7 @@
 //          its 64 sample bytes);
 //          jpeg_rgb_kernel: jdsample.c's fancy chroma upsampling (h2v1, h2v2, h1v2 triangle filters with libjpeg's rounding
 //          constants and edge rules, replication when a component is no wider than two samples) + jdcolor.c's fixed-point
-//          YCbCr -> RGB, one thread per pixel, HWC uint8 at the image's offset of the packed source buffer that
+//          YCbCr -> RGB, one thread per 2 x 2 pixels (one chroma sample's footprint in a 4:2:0 file), HWC uint8 at the image's offset of the packed source buffer that
 //          mq_image_preprocess_u8 reads.
 //
 // Byte / integer work; the kernels are bound by HBM (a 4:2:0 image: 3 bytes of coefficients read + 1.5 written + 1.5 read + 3
@@ -540,54 +540,120 @@ __device__ __forceinline__ int upsampled(const Plane& p, int hexp, int vexp, int
     return (3 * s0 + s1 + ((x & 1) ? 7 : 8)) >> 4;                                     // h2v2_fancy_upsample
 }
 
-// grid (pixel chunks, images), 256 threads: thread = one pixel
+__device__ __forceinline__ unsigned ycc_rgb(int Y, int cb, int cr) {
+    // jdcolor.c: FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554, ONE_HALF = 32768
+    cb -= 128;
+    cr -= 128;
+    int r = Y + ((91881 * cr + 32768) >> 16);
+    int g = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+    int b = Y + ((116130 * cb + 32768) >> 16);
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    g = g < 0 ? 0 : (g > 255 ? 255 : g);
+    b = b < 0 ? 0 : (b > 255 ? 255 : b);
+    return (unsigned)r | ((unsigned)g << 8) | ((unsigned)b << 16);
+}
+
+// two pixels (x even, x + 1) of one row: six consecutive bytes
+__device__ __forceinline__ void store_pair(uint8_t* dst, size_t at, unsigned a, unsigned b, bool second) {
+    if (second && !(at & 1)) {
+        uint16_t* d = reinterpret_cast<uint16_t*>(dst + at);
+        d[0] = (uint16_t)a;
+        d[1] = (uint16_t)((a >> 16) | (b << 8));
+        d[2] = (uint16_t)(b >> 8);
+        return;
+    }
+    dst[at] = (uint8_t)a; dst[at + 1] = (uint8_t)(a >> 8); dst[at + 2] = (uint8_t)(a >> 16);
+    if (second) { dst[at + 3] = (uint8_t)b; dst[at + 4] = (uint8_t)(b >> 8); dst[at + 5] = (uint8_t)(b >> 16); }
+}
+
+// grid (chunks of 256 quads, images), 256 threads: thread = one 2 x 2 quad of output pixels (x, y even).  For 4:2:0 files -- the
+// usual case -- a quad is ONE chroma sample's footprint: its 3 x 3 neighbourhood of each chroma plane is read once (9 + 9 bytes),
+// the vertical 3 : 1 sums are shared by the quad's two columns, the luma comes as two 2-byte loads; neighbouring lanes write
+// neighbouring 6-byte pieces of two rows.  (One thread per pixel, the first version, spent its time on the address arithmetic of
+// nine single-byte loads per pixel: 3.8 ms per 3072-image batch against 0.8 ms for the inverse DCT.)  Every other sampling takes
+// the general per-pixel form of the filters.
 __global__ __launch_bounds__(256) void jpeg_rgb_kernel(uint8_t* __restrict__ buf, const int64_t* __restrict__ items) {
     const int img = blockIdx.y;
     const uint8_t* st = buf + items[2 * img];
     uint8_t* dst = buf + items[2 * img + 1];
     const int32_t* hw = reinterpret_cast<const int32_t*>(st);
     const int h = hw[H_HEIGHT], w = hw[H_WIDTH];
-    const int px = blockIdx.x * 256 + threadIdx.x;
-    if (px >= h * w) return;
-    if (hw[H_MAGIC] == MQ_JPEG_MAGIC_RGB) {   // a file Pillow decoded on the host: its RGB bytes sit behind the header
-        const uint8_t* s = st + HDR + (size_t)px * 3;
-        dst[(size_t)px * 3] = s[0]; dst[(size_t)px * 3 + 1] = s[1]; dst[(size_t)px * 3 + 2] = s[2];
+    const int qw = (w + 1) >> 1, qh = (h + 1) >> 1;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= qw * qh) return;
+    const int qy = q / qw, qx = q - qy * qw;
+    const int y = 2 * qy, x = 2 * qx;
+    const bool right = x + 1 < w, below = y + 1 < h;
+    const size_t at0 = ((size_t)y * w + x) * 3, at1 = at0 + (size_t)w * 3;
+    const int magic = hw[H_MAGIC];
+    if (magic == MQ_JPEG_MAGIC_RGB) {   // a file Pillow decoded on the host: its RGB bytes sit behind the header
+        const uint8_t* s = st + HDR;
+        for (int i = 0; i < (right ? 6 : 3); ++i) {
+            dst[at0 + i] = s[at0 + i];
+            if (below) dst[at1 + i] = s[at1 + i];
+        }
         return;
     }
-    if (hw[H_MAGIC] != MQ_JPEG_MAGIC_COEFFICIENTS) return;
-    const int y = px / w, x = px - y * w;
+    if (magic != MQ_JPEG_MAGIC_COEFFICIENTS) return;
     const uint8_t* blocks = st + HDR;
-    Plane p0{blocks, hw[H_BW], hw[H_DW], hw[H_DH]};
-    const int Y = p0.at(y, x);
-    int r = Y, g = Y, b = Y;
-    if (hw[H_NCOMP] == 3) {
+    const int ncomp = hw[H_NCOMP];
+    const Plane py{blocks, hw[H_BW], hw[H_DW], hw[H_DH]};
+    // luma of the quad: (y, x) and (y, x + 1) share a block row (x is even), likewise the row below
+    const uint8_t* yp = blocks + ((size_t)(y >> 3) * py.bw + (x >> 3)) * 128 + ((y & 7) << 3) + (x & 7);
+    const unsigned ya = *reinterpret_cast<const uint16_t*>(yp);
+    const unsigned yb = (y & 7) != 7 ? *reinterpret_cast<const uint16_t*>(yp + 8)
+                                     : *reinterpret_cast<const uint16_t*>(yp + (size_t)py.bw * 128 - 56);   // (the row exists: blocks are padded to MCUs)
+    const int Y00 = ya & 255, Y01 = ya >> 8, Y10 = yb & 255, Y11 = yb >> 8;
+    unsigned p00, p01, p10, p11;
+    if (ncomp == 1) {
+        p00 = Y00 * 0x010101u; p01 = Y01 * 0x010101u; p10 = Y10 * 0x010101u; p11 = Y11 * 0x010101u;
+    } else {
         const int hexp = hw[H_HMAX], vexp = hw[H_VMAX];   // chroma is 1 x 1: its expansion is the luma's factor
-        Plane p1{blocks + (size_t)hw[H_FIRST + 1] * 128, hw[H_BW + 1], hw[H_DW + 1], hw[H_DH + 1]};
-        Plane p2{blocks + (size_t)hw[H_FIRST + 2] * 128, hw[H_BW + 2], hw[H_DW + 2], hw[H_DH + 2]};
-        const int cb = upsampled(p1, hexp, vexp, y, x) - 128, cr = upsampled(p2, hexp, vexp, y, x) - 128;
-        // jdcolor.c: FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554, ONE_HALF = 32768
-        r = Y + ((91881 * cr + 32768) >> 16);
-        g = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
-        b = Y + ((116130 * cb + 32768) >> 16);
-        r = r < 0 ? 0 : (r > 255 ? 255 : r);
-        g = g < 0 ? 0 : (g > 255 ? 255 : g);
-        b = b < 0 ? 0 : (b > 255 ? 255 : b);
+        const Plane p1{blocks + (size_t)hw[H_FIRST + 1] * 128, hw[H_BW + 1], hw[H_DW + 1], hw[H_DH + 1]};
+        const Plane p2{blocks + (size_t)hw[H_FIRST + 2] * 128, hw[H_BW + 2], hw[H_DW + 2], hw[H_DH + 2]};
+        if (hexp == 2 && vexp == 2 && p1.dw > 2) {
+            // h2v2_fancy_upsample around chroma sample (qy, qx); rows / columns beyond the component's REAL samples are the edge ones
+            const int r0 = qy > 0 ? qy - 1 : 0, r2 = qy + 1 < p1.dh ? qy + 1 : qy;
+            const int c0 = qx > 0 ? qx - 1 : 0, c2 = qx + 1 < p1.dw ? qx + 1 : qx;
+            int cbv[4], crv[4];
+#pragma unroll
+            for (int comp = 0; comp < 2; ++comp) {
+                const Plane& pl = comp ? p2 : p1;
+                const int a0 = pl.at(r0, c0), a1 = pl.at(r0, qx), a2 = pl.at(r0, c2);
+                const int b0 = pl.at(qy, c0), b1 = pl.at(qy, qx), b2 = pl.at(qy, c2);
+                const int d0 = pl.at(r2, c0), d1 = pl.at(r2, qx), d2 = pl.at(r2, c2);
+                const int t0 = 3 * b0 + a0, t1 = 3 * b1 + a1, t2 = 3 * b2 + a2;   // upper output row: the row above is the farther one
+                const int u0 = 3 * b0 + d0, u1 = 3 * b1 + d1, u2 = 3 * b2 + d2;   // lower output row
+                int* o = comp ? crv : cbv;
+                o[0] = (3 * t1 + t0 + 8) >> 4; o[1] = (3 * t1 + t2 + 7) >> 4;
+                o[2] = (3 * u1 + u0 + 8) >> 4; o[3] = (3 * u1 + u2 + 7) >> 4;
+            }
+            p00 = ycc_rgb(Y00, cbv[0], crv[0]); p01 = ycc_rgb(Y01, cbv[1], crv[1]);
+            p10 = ycc_rgb(Y10, cbv[2], crv[2]); p11 = ycc_rgb(Y11, cbv[3], crv[3]);
+        } else {
+            const int x1 = right ? x + 1 : x, y1 = below ? y + 1 : y;   // (clamped: the values of absent pixels are not stored)
+            p00 = ycc_rgb(Y00, upsampled(p1, hexp, vexp, y, x), upsampled(p2, hexp, vexp, y, x));
+            p01 = ycc_rgb(Y01, upsampled(p1, hexp, vexp, y, x1), upsampled(p2, hexp, vexp, y, x1));
+            p10 = ycc_rgb(Y10, upsampled(p1, hexp, vexp, y1, x), upsampled(p2, hexp, vexp, y1, x));
+            p11 = ycc_rgb(Y11, upsampled(p1, hexp, vexp, y1, x1), upsampled(p2, hexp, vexp, y1, x1));
+        }
     }
-    dst[(size_t)px * 3] = (uint8_t)r; dst[(size_t)px * 3 + 1] = (uint8_t)g; dst[(size_t)px * 3 + 2] = (uint8_t)b;
+    store_pair(dst, at0, p00, p01, right);
+    if (below) store_pair(dst, at1, p10, p11, right);
 }
 
 }  // namespace
 
-extern "C" int mq_jpeg_decode_rgb_u8(uint8_t* buf_dev, const int64_t* items_dev, int n_images, int max_blocks, int64_t max_pixels,
+extern "C" int mq_jpeg_decode_rgb_u8(uint8_t* buf_dev, const int64_t* items_dev, int n_images, int max_blocks, int64_t max_quads,
                                      void* stream) {
     if (n_images == 0) return MQ_OK;
-    if (!buf_dev || !items_dev || n_images < 0 || max_blocks < 0 || max_pixels < 1 || max_pixels > MQ_JPEG_MAX_PIXELS ||
+    if (!buf_dev || !items_dev || n_images < 0 || max_blocks < 0 || max_quads < 1 || max_quads > MQ_JPEG_MAX_PIXELS ||
         n_images > 65535 || (reinterpret_cast<uintptr_t>(buf_dev) & 15))
         return MQ_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (max_blocks > 0)
         hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((max_blocks + 127) / 128), (unsigned)n_images), dim3(128), 0, st, buf_dev, items_dev);
-    hipLaunchKernelGGL(jpeg_rgb_kernel, dim3((unsigned)((max_pixels + 255) / 256), (unsigned)n_images), dim3(256), 0, st, buf_dev, items_dev);
+    hipLaunchKernelGGL(jpeg_rgb_kernel, dim3((unsigned)((max_quads + 255) / 256), (unsigned)n_images), dim3(256), 0, st, buf_dev, items_dev);
     JPG_HIP(hipGetLastError());
     return MQ_OK;
 }
