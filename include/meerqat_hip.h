@@ -548,8 +548,8 @@ int mq_image_preprocess_u8(const uint8_t *src_dev, const int64_t *geom_dev, int 
  *   A caller that decodes such a file by other means stores its H x W x 3 RGB bytes behind a header whose words 0-2 are
  *   MQ_JPEG_MAGIC_RGB, height, width.
  * mq_jpeg_decode_rgb_u8 (GPU): items_dev int64 [n_images][2] = (byte offset of an image's header, byte offset of its RGB
- *   output) inside buf_dev (16-byte aligned offsets and buffer); max_blocks / max_quads = the largest block count and the
- *   largest ceil(height / 2) * ceil(width / 2) of the batch (the colour kernel runs one thread per 2 x 2 pixels).  The inverse DCT runs in place (the coefficient area is consumed); the H x W x 3 bytes are what
+ *   output) inside buf_dev (16-byte aligned offsets and buffer); max_blocks / max_strips = the largest block count and the
+ *   largest ceil(height / 2) * ceil(width / 8) of the batch (the colour kernel runs one thread per 8 x 2 pixels).  The inverse DCT runs in place (the coefficient area is consumed); the H x W x 3 bytes are what
  *   mq_image_preprocess_u8 / mq_warp_affine_faces_f32 read.
  * ------------------------------------------------------------------------------------------- */
 #define MQ_JPEG_INFO 6
@@ -559,7 +559,7 @@ int mq_image_preprocess_u8(const uint8_t *src_dev, const int64_t *geom_dev, int 
 #define MQ_JPEG_MAX_PIXELS (1 << 26)
 int mq_jpeg_probe(const uint8_t *file_host, size_t nbytes, int64_t *info_host);
 int mq_jpeg_read_coefficients(const uint8_t *file_host, size_t nbytes, void *staging_host, size_t staging_cap);
-int mq_jpeg_decode_rgb_u8(uint8_t *buf_dev, const int64_t *items_dev, int n_images, int max_blocks, int64_t max_quads,
+int mq_jpeg_decode_rgb_u8(uint8_t *buf_dev, const int64_t *items_dev, int n_images, int max_blocks, int64_t max_strips,
                           void *stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -93,6 +93,6 @@ def test_host_decoded_image_is_copied_through():
     n = len(host) + ((37 * 53 * 3 + 15) & ~15)
     buf = torch.zeros(n, dtype=torch.uint8, device="cuda")
     buf[:len(host)] = torch.from_numpy(host).cuda()
-    dj.decode_staged(buf, np.array([[0, len(host)]], dtype=np.int64), 0, dj.quads(37, 53))
+    dj.decode_staged(buf, np.array([[0, len(host)]], dtype=np.int64), 0, dj.strips(37, 53))
     torch.cuda.synchronize()
     assert np.array_equal(buf[len(host):len(host) + 37 * 53 * 3].cpu().numpy().reshape(37, 53, 3), rgb)

@@ -47,7 +47,7 @@ for n, r in enumerate(refs):   # one Huffman decode per distinct file, then copi
 pristine = host.cuda()
 buf = torch.empty(off, dtype=torch.uint8, device="cuda")
 items = np.array(list(zip(st_off, rgb_off)), dtype=np.int64)
-mb, mp = max(i[3] for i in infos), max(dj.quads(i[0], i[1]) for i in infos)
+mb, mp = max(i[3] for i in infos), max(dj.strips(i[0], i[1]) for i in infos)
 times = []
 for it in range(12):
     buf[:h2d].copy_(pristine)

@@ -11,7 +11,7 @@
 //          its 64 sample bytes);
 //          jpeg_rgb_kernel: jdsample.c's fancy chroma upsampling (h2v1, h2v2, h1v2 triangle filters with libjpeg's rounding
 //          constants and edge rules, replication when a component is no wider than two samples) + jdcolor.c's fixed-point
-//          YCbCr -> RGB, one thread per 2 x 2 pixels (one chroma sample's footprint in a 4:2:0 file), HWC uint8 at the image's offset of the packed source buffer that
+//          YCbCr -> RGB, one thread per 8 x 2 pixels (a luma block's row pair, four chroma samples of a 4:2:0 file), HWC uint8 at the image's offset of the packed source buffer that
 //          mq_image_preprocess_u8 reads.
 //
 // Byte / integer work; the kernels are bound by HBM (a 4:2:0 image: 3 bytes of coefficients read + 1.5 written + 1.5 read + 3
@@ -553,24 +553,48 @@ __device__ __forceinline__ unsigned ycc_rgb(int Y, int cb, int cr) {
     return (unsigned)r | ((unsigned)g << 8) | ((unsigned)b << 16);
 }
 
-// two pixels (x even, x + 1) of one row: six consecutive bytes
-__device__ __forceinline__ void store_pair(uint8_t* dst, size_t at, unsigned a, unsigned b, bool second) {
-    if (second && !(at & 1)) {
-        uint16_t* d = reinterpret_cast<uint16_t*>(dst + at);
-        d[0] = (uint16_t)a;
-        d[1] = (uint16_t)((a >> 16) | (b << 8));
-        d[2] = (uint16_t)(b >> 8);
+struct __attribute__((packed, aligned(4))) Words6 { unsigned w[6]; };
+
+// up to eight pixels (24-bit values) of one row -> 3 n consecutive bytes at dst + at
+__device__ __forceinline__ void store_row(uint8_t* dst, size_t at, const unsigned (&p)[8], int n) {
+    if (n == 8 && !(at & 3)) {
+        Words6 o;
+        o.w[0] = p[0] | (p[1] << 24);
+        o.w[1] = (p[1] >> 8) | (p[2] << 16);
+        o.w[2] = (p[2] >> 16) | (p[3] << 8);
+        o.w[3] = p[4] | (p[5] << 24);
+        o.w[4] = (p[5] >> 8) | (p[6] << 16);
+        o.w[5] = (p[6] >> 16) | (p[7] << 8);
+        *reinterpret_cast<Words6*>(dst + at) = o;
         return;
     }
-    dst[at] = (uint8_t)a; dst[at + 1] = (uint8_t)(a >> 8); dst[at + 2] = (uint8_t)(a >> 16);
-    if (second) { dst[at + 3] = (uint8_t)b; dst[at + 4] = (uint8_t)(b >> 8); dst[at + 5] = (uint8_t)(b >> 16); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < n) { dst[at + 3 * i] = (uint8_t)p[i]; dst[at + 3 * i + 1] = (uint8_t)(p[i] >> 8); dst[at + 3 * i + 2] = (uint8_t)(p[i] >> 16); }
 }
 
-// grid (chunks of 256 quads, images), 256 threads: thread = one 2 x 2 quad of output pixels (x, y even).  For 4:2:0 files -- the
-// usual case -- a quad is ONE chroma sample's footprint: its 3 x 3 neighbourhood of each chroma plane is read once (9 + 9 bytes),
-// the vertical 3 : 1 sums are shared by the quad's two columns, the luma comes as two 2-byte loads; neighbouring lanes write
-// neighbouring 6-byte pieces of two rows.  (One thread per pixel, the first version, spent its time on the address arithmetic of
-// nine single-byte loads per pixel: 3.8 ms per 3072-image batch against 0.8 ms for the inverse DCT.)  Every other sampling takes
+// six chroma samples of one row around the strip's four (columns cx - 1 .. cx + 4, those beyond the component's REAL samples
+// replaced by the edge ones): one 4-byte load (the four share a block row: cx is a multiple of 4) + the two neighbours
+__device__ __forceinline__ void chroma_row(const Plane& pl, int row, int cx, int (&v)[6]) {
+    const uint8_t* rp = pl.base + ((size_t)(row >> 3) * pl.bw + (cx >> 3)) * 128 + ((row & 7) << 3) + (cx & 7);
+    const unsigned m = *reinterpret_cast<const unsigned*>(rp);
+    const int e = pl.dw - 1 - cx;   // index of the last real sample among the four (>= 0)
+    const int m0 = m & 255, m1 = (m >> 8) & 255, m2 = (m >> 16) & 255, m3 = m >> 24;
+    const int last = e >= 3 ? m3 : (e == 2 ? m2 : (e == 1 ? m1 : m0));
+    v[1] = m0;
+    v[2] = e >= 1 ? m1 : last;
+    v[3] = e >= 2 ? m2 : last;
+    v[4] = e >= 3 ? m3 : last;
+    v[0] = cx > 0 ? pl.at(row, cx - 1) : m0;
+    v[5] = e >= 4 ? pl.at(row, cx + 4) : last;
+}
+
+// grid (chunks of 256 strips, images), 256 threads: thread = an 8 x 2 strip of output pixels (x a multiple of 8, y even).  For
+// 4:2:0 files -- the usual case -- that is one luma block's width and four chroma samples: three rows of six chroma samples per
+// plane come in as one 4-byte + two 1-byte loads each, the vertical 3 : 1 sums are shared by all the strip's pixels, the luma is two
+// 8-byte loads, and a row of the strip leaves as ONE 24-byte store when its address is 4-byte aligned (always, when the width is
+// a multiple of 4).  32 memory instructions per 16 pixels; the first version (one thread per pixel, nine single-byte loads and three
+// single-byte stores each) took 3.8 ms per 3072-image batch, one thread per 2 x 2 pixels 2.85 ms.  Every other sampling takes
 // the general per-pixel form of the filters.
 __global__ __launch_bounds__(256) void jpeg_rgb_kernel(uint8_t* __restrict__ buf, const int64_t* __restrict__ items) {
     const int img = blockIdx.y;
@@ -578,17 +602,18 @@ __global__ __launch_bounds__(256) void jpeg_rgb_kernel(uint8_t* __restrict__ buf
     uint8_t* dst = buf + items[2 * img + 1];
     const int32_t* hw = reinterpret_cast<const int32_t*>(st);
     const int h = hw[H_HEIGHT], w = hw[H_WIDTH];
-    const int qw = (w + 1) >> 1, qh = (h + 1) >> 1;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= qw * qh) return;
-    const int qy = q / qw, qx = q - qy * qw;
-    const int y = 2 * qy, x = 2 * qx;
-    const bool right = x + 1 < w, below = y + 1 < h;
+    const int sw = (w + 7) >> 3, qh = (h + 1) >> 1;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= sw * qh) return;
+    const int qy = t / sw, sx = t - qy * sw;
+    const int y = 2 * qy, x = 8 * sx;
+    const int n = w - x < 8 ? w - x : 8;   // pixels of the strip inside the image
+    const bool below = y + 1 < h;
     const size_t at0 = ((size_t)y * w + x) * 3, at1 = at0 + (size_t)w * 3;
     const int magic = hw[H_MAGIC];
     if (magic == MQ_JPEG_MAGIC_RGB) {   // a file Pillow decoded on the host: its RGB bytes sit behind the header
         const uint8_t* s = st + HDR;
-        for (int i = 0; i < (right ? 6 : 3); ++i) {
+        for (int i = 0; i < 3 * n; ++i) {
             dst[at0 + i] = s[at0 + i];
             if (below) dst[at1 + i] = s[at1 + i];
         }
@@ -598,62 +623,78 @@ __global__ __launch_bounds__(256) void jpeg_rgb_kernel(uint8_t* __restrict__ buf
     const uint8_t* blocks = st + HDR;
     const int ncomp = hw[H_NCOMP];
     const Plane py{blocks, hw[H_BW], hw[H_DW], hw[H_DH]};
-    // luma of the quad: (y, x) and (y, x + 1) share a block row (x is even), likewise the row below
-    const uint8_t* yp = blocks + ((size_t)(y >> 3) * py.bw + (x >> 3)) * 128 + ((y & 7) << 3) + (x & 7);
-    const unsigned ya = *reinterpret_cast<const uint16_t*>(yp);
-    const unsigned yb = (y & 7) != 7 ? *reinterpret_cast<const uint16_t*>(yp + 8)
-                                     : *reinterpret_cast<const uint16_t*>(yp + (size_t)py.bw * 128 - 56);   // (the row exists: blocks are padded to MCUs)
-    const int Y00 = ya & 255, Y01 = ya >> 8, Y10 = yb & 255, Y11 = yb >> 8;
-    unsigned p00, p01, p10, p11;
+    // luma: the strip is one block's row, and the row below it (blocks are padded to MCUs: it exists even when the image ends)
+    const uint8_t* yp = blocks + ((size_t)(y >> 3) * py.bw + sx) * 128 + ((y & 7) << 3);
+    const uint2 ya = *reinterpret_cast<const uint2*>(yp);
+    const uint2 yb = *reinterpret_cast<const uint2*>(yp + 8);   // y is even: the next row is in the same block
+    int Y0[8], Y1[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        Y0[i] = (ya.x >> (8 * i)) & 255; Y0[4 + i] = (ya.y >> (8 * i)) & 255;
+        Y1[i] = (yb.x >> (8 * i)) & 255; Y1[4 + i] = (yb.y >> (8 * i)) & 255;
+    }
+    unsigned p0[8], p1[8];
     if (ncomp == 1) {
-        p00 = Y00 * 0x010101u; p01 = Y01 * 0x010101u; p10 = Y10 * 0x010101u; p11 = Y11 * 0x010101u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { p0[i] = Y0[i] * 0x010101u; p1[i] = Y1[i] * 0x010101u; }
     } else {
         const int hexp = hw[H_HMAX], vexp = hw[H_VMAX];   // chroma is 1 x 1: its expansion is the luma's factor
-        const Plane p1{blocks + (size_t)hw[H_FIRST + 1] * 128, hw[H_BW + 1], hw[H_DW + 1], hw[H_DH + 1]};
-        const Plane p2{blocks + (size_t)hw[H_FIRST + 2] * 128, hw[H_BW + 2], hw[H_DW + 2], hw[H_DH + 2]};
-        if (hexp == 2 && vexp == 2 && p1.dw > 2) {
-            // h2v2_fancy_upsample around chroma sample (qy, qx); rows / columns beyond the component's REAL samples are the edge ones
-            const int r0 = qy > 0 ? qy - 1 : 0, r2 = qy + 1 < p1.dh ? qy + 1 : qy;
-            const int c0 = qx > 0 ? qx - 1 : 0, c2 = qx + 1 < p1.dw ? qx + 1 : qx;
-            int cbv[4], crv[4];
+        const Plane pb{blocks + (size_t)hw[H_FIRST + 1] * 128, hw[H_BW + 1], hw[H_DW + 1], hw[H_DH + 1]};
+        const Plane pr{blocks + (size_t)hw[H_FIRST + 2] * 128, hw[H_BW + 2], hw[H_DW + 2], hw[H_DH + 2]};
+        if (hexp == 2 && vexp == 2 && pb.dw > 2) {
+            // h2v2_fancy_upsample: chroma row qy between its neighbours (beyond the component's REAL rows: the edge row)
+            const int cx = 4 * sx;
+            const int r0 = qy > 0 ? qy - 1 : 0, r2 = qy + 1 < pb.dh ? qy + 1 : qy;
+            int c0[2][8], c1[2][8];   // [Cb, Cr][pixel] of the upper / the lower row
 #pragma unroll
             for (int comp = 0; comp < 2; ++comp) {
-                const Plane& pl = comp ? p2 : p1;
-                const int a0 = pl.at(r0, c0), a1 = pl.at(r0, qx), a2 = pl.at(r0, c2);
-                const int b0 = pl.at(qy, c0), b1 = pl.at(qy, qx), b2 = pl.at(qy, c2);
-                const int d0 = pl.at(r2, c0), d1 = pl.at(r2, qx), d2 = pl.at(r2, c2);
-                const int t0 = 3 * b0 + a0, t1 = 3 * b1 + a1, t2 = 3 * b2 + a2;   // upper output row: the row above is the farther one
-                const int u0 = 3 * b0 + d0, u1 = 3 * b1 + d1, u2 = 3 * b2 + d2;   // lower output row
-                int* o = comp ? crv : cbv;
-                o[0] = (3 * t1 + t0 + 8) >> 4; o[1] = (3 * t1 + t2 + 7) >> 4;
-                o[2] = (3 * u1 + u0 + 8) >> 4; o[3] = (3 * u1 + u2 + 7) >> 4;
+                const Plane& pl = comp ? pr : pb;
+                int a[6], m[6], d[6];
+                chroma_row(pl, r0, cx, a);
+                chroma_row(pl, qy, cx, m);
+                chroma_row(pl, r2, cx, d);
+                int tu[6], tl[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { tu[i] = 3 * m[i] + a[i]; tl[i] = 3 * m[i] + d[i]; }   // the row above is the farther one for the upper output row
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    c0[comp][2 * j] = (3 * tu[j + 1] + tu[j] + 8) >> 4;
+                    c0[comp][2 * j + 1] = (3 * tu[j + 1] + tu[j + 2] + 7) >> 4;
+                    c1[comp][2 * j] = (3 * tl[j + 1] + tl[j] + 8) >> 4;
+                    c1[comp][2 * j + 1] = (3 * tl[j + 1] + tl[j + 2] + 7) >> 4;
+                }
             }
-            p00 = ycc_rgb(Y00, cbv[0], crv[0]); p01 = ycc_rgb(Y01, cbv[1], crv[1]);
-            p10 = ycc_rgb(Y10, cbv[2], crv[2]); p11 = ycc_rgb(Y11, cbv[3], crv[3]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { p0[i] = ycc_rgb(Y0[i], c0[0][i], c0[1][i]); p1[i] = ycc_rgb(Y1[i], c1[0][i], c1[1][i]); }
         } else {
-            const int x1 = right ? x + 1 : x, y1 = below ? y + 1 : y;   // (clamped: the values of absent pixels are not stored)
-            p00 = ycc_rgb(Y00, upsampled(p1, hexp, vexp, y, x), upsampled(p2, hexp, vexp, y, x));
-            p01 = ycc_rgb(Y01, upsampled(p1, hexp, vexp, y, x1), upsampled(p2, hexp, vexp, y, x1));
-            p10 = ycc_rgb(Y10, upsampled(p1, hexp, vexp, y1, x), upsampled(p2, hexp, vexp, y1, x));
-            p11 = ycc_rgb(Y11, upsampled(p1, hexp, vexp, y1, x1), upsampled(p2, hexp, vexp, y1, x1));
+            const int y1 = below ? y + 1 : y;
+#pragma unroll 1
+            for (int i = 0; i < 8; ++i) {   // (clamped: the values of absent pixels are not stored)
+                const int xi = x + i < w ? x + i : w - 1;
+                const unsigned u = ycc_rgb(py.at(y, xi), upsampled(pb, hexp, vexp, y, xi), upsampled(pr, hexp, vexp, y, xi));
+                const unsigned l = ycc_rgb(py.at(y1, xi), upsampled(pb, hexp, vexp, y1, xi), upsampled(pr, hexp, vexp, y1, xi));
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k == i) { p0[k] = u; p1[k] = l; }
+            }
         }
     }
-    store_pair(dst, at0, p00, p01, right);
-    if (below) store_pair(dst, at1, p10, p11, right);
+    store_row(dst, at0, p0, n);
+    if (below) store_row(dst, at1, p1, n);
 }
 
 }  // namespace
 
-extern "C" int mq_jpeg_decode_rgb_u8(uint8_t* buf_dev, const int64_t* items_dev, int n_images, int max_blocks, int64_t max_quads,
+extern "C" int mq_jpeg_decode_rgb_u8(uint8_t* buf_dev, const int64_t* items_dev, int n_images, int max_blocks, int64_t max_strips,
                                      void* stream) {
     if (n_images == 0) return MQ_OK;
-    if (!buf_dev || !items_dev || n_images < 0 || max_blocks < 0 || max_quads < 1 || max_quads > MQ_JPEG_MAX_PIXELS ||
+    if (!buf_dev || !items_dev || n_images < 0 || max_blocks < 0 || max_strips < 1 || max_strips > MQ_JPEG_MAX_PIXELS ||
         n_images > 65535 || (reinterpret_cast<uintptr_t>(buf_dev) & 15))
         return MQ_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (max_blocks > 0)
         hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((max_blocks + 127) / 128), (unsigned)n_images), dim3(128), 0, st, buf_dev, items_dev);
-    hipLaunchKernelGGL(jpeg_rgb_kernel, dim3((unsigned)((max_quads + 255) / 256), (unsigned)n_images), dim3(256), 0, st, buf_dev, items_dev);
+    hipLaunchKernelGGL(jpeg_rgb_kernel, dim3((unsigned)((max_strips + 255) / 256), (unsigned)n_images), dim3(256), 0, st, buf_dev, items_dev);
     JPG_HIP(hipGetLastError());
     return MQ_OK;
 }

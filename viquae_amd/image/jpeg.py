@@ -46,9 +46,9 @@ def stage_rgb(rgb, buf, off):
     buf[off + HEADER:off + HEADER + h * w * 3] = rgb.reshape(-1)
 
 
-def quads(h, w):
-    """2 x 2 pixel groups of an h x w image: the colour kernel's threads."""
-    return ((h + 1) // 2) * ((w + 1) // 2)
+def strips(h, w):
+    """8 x 2 pixel strips of an h x w image: the colour kernel's threads."""
+    return ((h + 1) // 2) * ((w + 7) // 8)
 
 
 def plan_layout(geom, totals, jpeg_rows):
@@ -59,7 +59,7 @@ def plan_layout(geom, totals, jpeg_rows):
         [ RGB of the host-decoded images | staging areas of the JPEG files | RGB of the JPEG files ]
           \_______________ copied from the host ________________________/   \__ written by the GPU __/
 
-    -> dict(h2d_bytes, staging = {row: offset}, items int64 [n, 2], max_blocks, max_quads)."""
+    -> dict(h2d_bytes, staging = {row: offset}, items int64 [n, 2], max_blocks, max_strips)."""
     rows = sorted(jpeg_rows)
     off = 0
     for r in range(len(geom)):
@@ -77,10 +77,10 @@ def plan_layout(geom, totals, jpeg_rows):
     totals[0] = off
     return {"h2d_bytes": h2d, "staging": staging,
             "items": np.array([[staging[r], int(geom[r, 0])] for r in rows], dtype=np.int64).reshape(-1, 2),
-            "max_blocks": max(int(jpeg_rows[r][0]) for r in rows), "max_quads": max(quads(int(geom[r, 1]), int(geom[r, 2])) for r in rows)}
+            "max_blocks": max(int(jpeg_rows[r][0]) for r in rows), "max_strips": max(strips(int(geom[r, 1]), int(geom[r, 2])) for r in rows)}
 
 
-def decode_staged(buf_dev, items, max_blocks, max_quads, stream=None):
+def decode_staged(buf_dev, items, max_blocks, max_strips, stream=None):
     """items int64 [n, 2] (header offset, RGB offset) inside the uint8 device tensor ``buf_dev``; enqueues the kernels."""
     import torch
     items = np.ascontiguousarray(items, dtype=np.int64).reshape(-1, 2)
@@ -88,7 +88,7 @@ def decode_staged(buf_dev, items, max_blocks, max_quads, stream=None):
         return None
     idev = torch.from_numpy(items).to(buf_dev.device, non_blocking=True)
     st = stream if stream is not None else torch.cuda.current_stream(buf_dev.device).cuda_stream
-    _lib.check(_lib.load().mq_jpeg_decode_rgb_u8(buf_dev.data_ptr(), idev.data_ptr(), len(items), int(max_blocks), int(max_quads), st),
+    _lib.check(_lib.load().mq_jpeg_decode_rgb_u8(buf_dev.data_ptr(), idev.data_ptr(), len(items), int(max_blocks), int(max_strips), st),
                "mq_jpeg_decode_rgb_u8")
     return idev
 
@@ -122,6 +122,6 @@ def decode_files(datas, device=None):
         buf = torch.empty(max(off, 16), dtype=torch.uint8, device=dev)
         buf[:h2d].copy_(host[:h2d], non_blocking=True)
         decode_staged(buf, np.array(list(zip(st_off, rgb_off)), dtype=np.int64), max(p[3] for p in infos),
-                      max(quads(p[0], p[1]) for p in infos))
+                      max(strips(p[0], p[1]) for p in infos))
         torch.cuda.current_stream(dev).synchronize()
     return [buf[o:o + p[0] * p[1] * 3].view(p[0], p[1], 3) for p, o in zip(infos, rgb_off)]

@@ -153,7 +153,7 @@ class CLIPImageProcessorHIP:
                 from . import jpeg as dj
                 src = torch.empty(int(totals[0]), dtype=torch.uint8, device=dev)
                 src[:jpeg["h2d_bytes"]].copy_(packed[:jpeg["h2d_bytes"]], non_blocking=True)
-                keep = (dj.decode_staged(src, jpeg["items"], jpeg["max_blocks"], jpeg["max_quads"]),)
+                keep = (dj.decode_staged(src, jpeg["items"], jpeg["max_blocks"], jpeg["max_strips"]),)
             gdev = torch.from_numpy(geom).to(dev, non_blocking=True)
             ws = torch.empty(max(int(totals[1]), 256), dtype=torch.uint8, device=dev)
             flags = (1 if self.do_rescale else 0) | (2 if self.do_normalize else 0)
