@@ -30,6 +30,7 @@ _SLOTS = []   # the staging mappings; inherited by the forked workers
 
 
 _MAX_OPEN = 128  # lazily opened images a worker keeps between the `sizes` and the `decode` phase
+_MAX_HELD = 64 << 20  # bytes of JPEG files a worker keeps between the phases (beyond that: read again in `decode`)
 
 
 def _jpeg_bytes(path):
@@ -62,12 +63,14 @@ def _worker(conn, slots):
             _, base, paths = msg
             opened.clear()
             out = []
+            held = 0
             for n, path in enumerate(paths):
                 try:
                     data = _jpeg_bytes(path) if device_jpeg else None
                     info = dj.probe(data) if data is not None else None
                     if info is not None:   # (height, width, components, blocks, staging bytes): the scan is decoded in `decode`
-                        opened[base + n] = ("jpeg", data, path, info)
+                        held += len(data)
+                        opened[base + n] = ("jpeg", data if held <= _MAX_HELD else None, path, info)
                         out.append(((info[0], info[1]), None, (info[3], info[4])))
                         continue
                     del data
@@ -104,6 +107,9 @@ def _worker(conn, slots):
                 if entry[0] == "jpeg":
                     _, data, path, info = entry
                     try:
+                        if data is None:   # (not kept between the phases: _MAX_HELD)
+                            with open(path, "rb") as f:
+                                data = f.read()
                         if not dj.stage(data, buf.ctypes.data + off, info[4]):
                             # an irregular scan (truncated, damaged, a marker inside): Pillow decides what this file is
                             im = Image.open(io.BytesIO(data))
