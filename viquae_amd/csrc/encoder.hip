@@ -777,6 +777,57 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     ln_store(v, C, lane, g, b, eps, Y ? Y + (size_t)row * C : nullptr, Yh, Yl, (size_t)row);
 }
 
+// layernorm_kernel's split output with FULL-LINE stores.  In the pair layout a row's 32 columns of one K block are 64 bytes, and
+// rows r .. r + 3 (this workgroup's four waves) are 256 consecutive bytes: the four rows' (hi, lo) values go through LDS as packed
+// words and leave as 16-byte pieces, sixteen lanes covering two whole 128-byte lines of one array -- layernorm_kernel's own pair
+// stores are 4 bytes per lane in 64-byte runs 16 KiB apart.  The arithmetic (and every bit of the output) is ln_store's.
+constexpr int LNP_STRIDE = 64 * LN_MAXPER + 32;   // words per row in LDS: rows 32 banks apart
+__global__ __launch_bounds__(256) void layernorm_pairs_kernel(const float* __restrict__ X, const float* __restrict__ g,
+                                                              const float* __restrict__ b, float* __restrict__ Y,
+                                                              unsigned short* __restrict__ Yh, unsigned short* __restrict__ Yl, int M, int C,
+                                                              float eps) {
+    __shared__ __attribute__((aligned(16))) unsigned words[4 * LNP_STRIDE];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = blockIdx.x * 4, row = row0 + w;
+    if (row < M) {   // wave-uniform
+        float v[LN_MAXPER];
+#pragma unroll
+        for (int t = 0; t < LN_MAXPER; ++t) { const int c = lane + 64 * t; v[t] = (c < C) ? X[(size_t)row * C + c] : 0.f; }
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < LN_MAXPER; ++t) { const int c = lane + 64 * t; if (c < C) s += v[t]; }
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < LN_MAXPER; ++t) { const int c = lane + 64 * t; if (c < C) { const float d = v[t] - mean; q += d * d; } }
+        const float var = wave_sum(q) / (float)C;
+        const float inv = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int t = 0; t < LN_MAXPER; ++t) {
+            const int c = lane + 64 * t;
+            if (c < C) {
+                const float y = (v[t] - mean) * inv * g[c] + b[c];
+                if (Y) Y[(size_t)row * C + c] = y;
+                words[w * LNP_STRIDE + c] = split_bits(y);
+            }
+        }
+    }
+    __syncthreads();
+    // piece p of the workgroup: array (hi / lo), K block, row of the four, eight columns
+    const int per_array = (C >> 5) * 16;
+    for (int p = threadIdx.x; p < 2 * per_array; p += 256) {
+        const int arr = p >= per_array, rem = arr ? p - per_array : p;
+        const int cb = rem >> 4, r = (rem >> 2) & 3, part = rem & 3;
+        if (row0 + r >= M) continue;
+        const uint4* src = reinterpret_cast<const uint4*>(words + r * LNP_STRIDE + cb * 32 + part * 8);
+        const uint4 a = src[0], c4 = src[1];
+        uint4 o;
+        if (arr) { o.x = (a.x >> 16) | (a.y & 0xFFFF0000u); o.y = (a.z >> 16) | (a.w & 0xFFFF0000u); o.z = (c4.x >> 16) | (c4.y & 0xFFFF0000u); o.w = (c4.z >> 16) | (c4.w & 0xFFFF0000u); }
+        else { o.x = (a.x & 0xFFFFu) | (a.y << 16); o.y = (a.z & 0xFFFFu) | (a.w << 16); o.z = (c4.x & 0xFFFFu) | (c4.y << 16); o.w = (c4.z & 0xFFFFu) | (c4.w << 16); }
+        *reinterpret_cast<uint4*>((arr ? Yl : Yh) + pair_index((size_t)(row0 + r), cb * 32 + part * 8, C)) = o;
+    }
+}
+
 // BertEmbeddings (meerqat/models/bert.py:153-214): (word[id] + type[tt]) + pos[t], then LayerNorm
 __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const long long* __restrict__ ids, const long long* __restrict__ tts,
                                                             const float* __restrict__ word, const float* __restrict__ pos,
@@ -1543,8 +1594,13 @@ int mq_layernorm_split_f32(const float* X_dev, const float* gamma_dev, const flo
     if (!X_dev || !gamma_dev || !beta_dev || M < 0 || C <= 0) return MQ_EINVAL;
     if ((!Y_dev && !Yh_dev) || (!Yh_dev != !Yl_dev)) return MQ_EINVAL;
     if (C > 64 * LN_MAXPER || (Yh_dev && (C & 31))) return MQ_EUNSUPPORTED;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X_dev, gamma_dev,
-                       beta_dev, Y_dev, (unsigned short*)Yh_dev, (unsigned short*)Yl_dev, M, C, eps);
+    static const bool via_lds = [] { const char* e = getenv("MQ_LN_PAIR_VIA_LDS"); return !e || atoi(e) != 0; }();
+    if (Yh_dev && via_lds)
+        hipLaunchKernelGGL(layernorm_pairs_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X_dev, gamma_dev,
+                           beta_dev, Y_dev, (unsigned short*)Yh_dev, (unsigned short*)Yl_dev, M, C, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X_dev, gamma_dev,
+                           beta_dev, Y_dev, (unsigned short*)Yh_dev, (unsigned short*)Yl_dev, M, C, eps);
     ENC_HIP(hipGetLastError());
     return MQ_OK;
 }
