@@ -532,8 +532,8 @@ int mq_image_preprocess_u8(const uint8_t *src_dev, const int64_t *geom_dev, int 
 /* ---------------------------------------------------------------------------------------------
  * Baseline-JPEG decoding split between host and GPU (csrc/jpeg.hip): replaces, per image,
  * `Image.open(path).convert('RGB')` of `load_image` (meerqat/data/loading.py:108-124, called by meerqat/image/embedding.py:127)
- * for the files it covers -- 8-bit Huffman-coded sequential JPEGs (SOF0 / SOF1) with ONE interleaved scan, grey or YCbCr with
- * luma sampling 1x1 / 2x1 / 1x2 / 2x2 and chroma 1x1 -- with the same RGB bytes as Pillow 12 / libjpeg-turbo (ISLOW inverse DCT,
+ * for the files it covers -- 8-bit Huffman-coded JPEGs, sequential (SOF0 / SOF1) with ONE interleaved scan or progressive (SOF2)
+ * with a complete, regular progression, grey or YCbCr with luma sampling 1x1 / 2x1 / 1x2 / 2x2 and chroma 1x1 -- with the same RGB bytes as Pillow 12 / libjpeg-turbo (ISLOW inverse DCT,
  * fancy upsampling, fixed-point colour tables; oracle/jpeg.py, pinned against Pillow).  Everything else, and any irregularity of
  * the entropy-coded data, is declined and stays Pillow's: the caller keeps the reference's errors and warnings.
  *

@@ -25,7 +25,9 @@ Pinned: ``tests/test_jpeg_oracle_cpu.py`` and ``tools/jpeg_pillow_parity.py`` co
 on files written by Pillow's encoder (qualities 5 .. 100, 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0 / grey, optimised tables or not, restart
 intervals, sizes that are not multiples of the MCU, down to 1 x 1) -- see ``profiles/r06_notes.md`` section 6 for the count.
 Not restated (``Unsupported`` is raised; a product would hand such a file to Pillow): progressive and arithmetic-coded files,
-12-bit samples, CMYK / YCCK, RGB-coded files, sampling factors other than the ones above.
+12-bit samples, CMYK / YCCK, RGB-coded files, sampling factors other than the ones above.  (The library's host half also reads
+PROGRESSIVE scans; those are pinned without a Python restatement of jdphuff.c: ``decode_staging`` -- this file's inverse DCT,
+upsampling and colour conversion on the library's final coefficients -- against Pillow's pixels, tests/test_jpeg_oracle_cpu.py.)
 
 Scalar Python only in the bit reader (a few microseconds per symbol); everything after the coefficients is numpy."""
 import numpy as np

@@ -96,3 +96,21 @@ def test_host_decoded_image_is_copied_through():
     dj.decode_staged(buf, np.array([[0, len(host)]], dtype=np.int64), 0, dj.strips(37, 53))
     torch.cuda.synchronize()
     assert np.array_equal(buf[len(host):len(host) + 37 * 53 * 3].cpu().numpy().reshape(37, 53, 3), rgb)
+
+
+def test_progressive_files():
+    import jpeg_pillow_parity as jp
+    from viquae_amd.image import jpeg as dj
+    rng = np.random.default_rng(21)
+    files = []
+    for i in range(24):
+        h, w = jp.sizes(rng)
+        im = jp.picture(rng, min(h, 260), min(w, 260), grey=(i % 8 == 5))
+        kw = dict(quality=int(rng.choice([20, 50, 75, 90, 100])), progressive=True)
+        if im.mode == "RGB":
+            kw["subsampling"] = i % 3
+        buf = io.BytesIO()
+        im.save(buf, "JPEG", **kw)
+        files.append(buf.getvalue())
+    for n, (d, g) in enumerate(zip(files, dj.decode_files(files))):
+        assert np.array_equal(g.cpu().numpy(), _pillow(d)), n

@@ -116,9 +116,6 @@ def test_host_decoder_declines_what_it_does_not_cover():
     from viquae_amd.image import jpeg as dj
     im = jp.picture(np.random.default_rng(0), 40, 56)
     buf = io.BytesIO()
-    im.save(buf, "JPEG", progressive=True)
-    assert dj.probe(buf.getvalue()) is None
-    buf = io.BytesIO()
     im.convert("CMYK").save(buf, "JPEG")
     assert dj.probe(buf.getvalue()) is None
     buf = io.BytesIO()
@@ -165,3 +162,32 @@ def test_irregular_scans_are_left_to_pillow():
             assert np.array_equal(oj.decode(bytes(b)), _pillow(bytes(b))), k
     assert 5 <= derailed < 40
     assert not dj.stage(good, st.ctypes.data, 100)   # a staging area that is too small
+
+
+def test_progressive_files_through_the_host_decoder():
+    """Progressive files (SOF2: DC / AC first and refinement scans, end-of-band runs, successive approximation): the library's
+    final coefficients through the oracle's inverse DCT / upsampling / colour = Pillow's pixels."""
+    from viquae_amd.image import jpeg as dj
+    rng = np.random.default_rng(11)
+    for i in range(36):
+        h, w = jp.sizes(rng)
+        im = jp.picture(rng, min(h, 160), min(w, 160), grey=(i % 9 == 4))
+        kw = dict(quality=int(rng.choice([10, 30, 50, 75, 85, 95, 100])), progressive=True)
+        if im.mode == "RGB":
+            kw["subsampling"] = i % 3
+        if i % 5 == 0:
+            kw["restart_marker_blocks"] = 1 + i % 3
+        buf = io.BytesIO()
+        im.save(buf, "JPEG", **kw)
+        data = buf.getvalue()
+        assert b"\xff\xc2" in data
+        _, st = _staged(data)
+        assert np.array_equal(oj.decode_staging(st), _pillow(data)), (i, kw)
+    # an INCOMPLETE progression (the last scans cut off, an end-of-image marker put in their place) decodes in Pillow -- with
+    # libjpeg's inter-block smoothing -- and is declined here
+    sos = [k for k in range(len(data) - 1) if data[k] == 0xFF and data[k + 1] == 0xDA]
+    assert len(sos) >= 6
+    cut = data[:sos[-2]] + b"\xff\xd9"
+    p = dj.probe(cut)
+    st = np.zeros(p[4], dtype=np.uint8)
+    assert _pillow(cut).shape == _pillow(data).shape and not dj.stage(cut, st.ctypes.data, st.size)

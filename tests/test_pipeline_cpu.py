@@ -205,7 +205,7 @@ def test_decode_pool_writes_rgb_bytes_into_the_shared_slots(tmp_path):
 def test_decode_pool_stages_jpeg_scans_for_the_device(tmp_path):
     """JPEG files the split decoder covers leave the workers as staging areas (header + quantised coefficients, csrc/jpeg.hip) at
     the offsets of `viquae_amd.image.jpeg.plan_layout`; the oracle's inverse DCT / upsampling / colour conversion on those areas
-    gives Pillow's pixels.  A progressive file and a PNG go the Pillow way (RGB bytes); a JPEG whose scan is damaged but which
+    gives Pillow's pixels (a progressive file among them).  A PNG goes the Pillow way (RGB bytes); a JPEG whose scan is damaged but which
     Pillow still decodes is stored as RGB inside its staging area; a truncated one fails like before."""
     from PIL import Image, ImageFile
     from oracle import jpeg as oj
@@ -248,7 +248,7 @@ def test_decode_pool_stages_jpeg_scans_for_the_device(tmp_path):
     try:
         sizes = pool.sizes(paths)
         assert all(s is not None for s in sizes)
-        assert set(pool.last_jpeg) == {0, 1, 2, 4, 6, 7, 8, 9}          # not the progressive file, not the PNG
+        assert set(pool.last_jpeg) == {0, 1, 2, 3, 4, 6, 7, 8, 9}       # not the PNG
         geom = np.zeros((len(paths), 12), dtype=np.int64)
         geom[:, 1:3] = sizes
         totals = np.zeros(5, dtype=np.int64)

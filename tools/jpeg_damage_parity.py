@@ -1,7 +1,8 @@
 """Damaged JPEG files: which of them the split decoder (csrc/jpeg.hip) accepts, and whether the accepted ones still decode like
 Pillow.  One bit of the entropy-coded data of a good file is flipped per trial; `stage` (mq_jpeg_read_coefficients) either
-declines (the product then uses Pillow) or accepts, and the accepted files' pixels -- oracle/jpeg.py's arithmetic, which the
-device kernels reproduce (tests/test_jpeg_gpu.py) -- are compared with Pillow's.
+declines (the product then uses Pillow) or accepts, and the accepted files' pixels -- oracle/jpeg.py's arithmetic on the
+library's coefficients, which the device kernels reproduce (tests/test_jpeg_gpu.py) -- are compared with Pillow's.  Baseline and
+progressive files.
 
     python tools/jpeg_damage_parity.py [files=12] [flips per file=300]"""
 import io
@@ -32,6 +33,8 @@ def main():
             kw["subsampling"] = seed % 3
         if seed % 12 in (4, 9):
             kw["restart_marker_blocks"] = 2
+        if seed % 12 in (2, 5, 7, 9, 10):
+            kw["progressive"] = True
         buf = io.BytesIO()
         jp.picture(rng, 64 + (seed % 12) * 13, 80 + (seed % 12) * 7, grey=grey).save(buf, "JPEG", **kw)
         good = buf.getvalue()
@@ -56,7 +59,7 @@ def main():
                 perr += 1
                 print("Pillow raises on an accepted file:", e, "seed", seed, "pos", pos)
                 continue
-            if np.array_equal(ref, oj.decode(b)):
+            if np.array_equal(ref, oj.decode_staging(st)):   # the oracle's arithmetic on the library's coefficients
                 same += 1
             else:
                 diff += 1

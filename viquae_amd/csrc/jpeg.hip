@@ -2,10 +2,11 @@
 // `Image.open(path).convert('RGB')` (meerqat/data/loading.py:108-124, called by meerqat/image/embedding.py:127).
 // Pillow hands the file to libjpeg-turbo; bit for bit the same RGB bytes are produced here by
 //
-//   host   mq_jpeg_probe / mq_jpeg_read_coefficients: marker parsing + Huffman decoding of the ONE interleaved sequential scan
-//          (jdhuff.c's algorithm: look-ahead tables, HUFF_EXTEND, DC prediction, restart intervals) -- the part of a JPEG
-//          decoder that is a serial bit stream -- into quantised coefficient blocks inside the batch's staging buffer, behind
-//          a 512-byte header (sizes, sampling, quantisation tables);
+//   host   mq_jpeg_probe / mq_jpeg_read_coefficients: marker parsing + Huffman decoding -- the ONE interleaved scan of a sequential
+//          file (jdhuff.c's algorithm: look-ahead tables, HUFF_EXTEND, DC prediction, restart intervals) or all the scans of a
+//          progressive one (jdphuff.c: DC / AC first and refinement scans, end-of-band runs, successive approximation) -- the
+//          part of a JPEG decoder that is a serial bit stream -- into quantised coefficient blocks inside the batch's staging
+//          buffer, behind a 512-byte header (sizes, sampling, quantisation tables);
 //   GPU    jpeg_idct_kernel: dequantisation + jidctint.c's ISLOW inverse DCT (13-bit fixed point, columns then rows,
 //          round-half-up descales, + 128, clamp), one thread per 8 x 8 block, IN PLACE (a block's 128 coefficient bytes become
 //          its 64 sample bytes);
@@ -16,8 +17,8 @@
 //
 // Byte / integer work; the kernels are bound by HBM (a 4:2:0 image: 3 bytes of coefficients read + 1.5 written + 1.5 read + 3
 // written per pixel) and are ~2 % of the CLIP tower's time per batch; the host side is what bounds the job (profiles/r06_notes.md
-// section 6).  Anything this decoder does not cover -- progressive / arithmetic / lossless / 12-bit files, CMYK, several scans,
-// other sampling factors, and ANY irregularity of the entropy-coded data (a marker inside the scan, a missing EOI, an invalid
+// section 6).  Anything this decoder does not cover -- arithmetic / lossless / 12-bit files, CMYK, sequential files in several scans,
+// incomplete or irregular progressions, other sampling factors, and ANY irregularity of the entropy-coded data (a marker inside the scan, a missing EOI, an invalid
 // code) -- is declined (MQ_EUNSUPPORTED / MQ_EINVAL) and the caller decodes that file with Pillow as before, so errors and
 // warnings stay the reference's.  Oracle: oracle/jpeg.py, pinned against Pillow (tests/test_jpeg_oracle_cpu.py).
 #include <hip/hip_runtime.h>
@@ -148,28 +149,71 @@ struct Parsed {
     bool have_qt[4];
     Huff dc[4], ac[4];
     int restart;
-    int td[3], ta[3];
-    const uint8_t* scan;  // first entropy-coded byte
+    bool progressive, jfif, have_frame, geometry_done;
+    int adobe;
+    size_t pos;           // where the next marker is expected
+    // the scan whose header was read last
+    int ns, sc[3], td[3], ta[3], ss, se, ah, al;
+    const uint8_t* scan;  // its first entropy-coded byte
 };
 
 static inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
-// -> MQ_OK with `out` filled up to the start of the scan; MQ_EUNSUPPORTED: a valid-looking file of a kind not handled here;
-//    MQ_EINVAL: not a JPEG file / damaged headers
-static int parse(const uint8_t* d, size_t nbytes, Parsed& out) {
+static int begin(const uint8_t* d, size_t nbytes, Parsed& out) {
     if (!d || nbytes < 4 || d[0] != 0xFF || d[1] != 0xD8) return MQ_EINVAL;
     memset(&out.f, 0, sizeof(out.f));
     memset(out.have_qt, 0, sizeof(out.have_qt));
     for (int i = 0; i < 4; ++i) out.dc[i].defined = out.ac[i].defined = false;
     out.restart = 0;
-    bool jfif = false, have_frame = false;
-    int adobe = -1;
-    size_t pos = 2;
+    out.progressive = out.jfif = out.have_frame = out.geometry_done = false;
+    out.adobe = -1;
+    out.pos = 2;
+    return MQ_OK;
+}
+
+// sampling, colour space and block geometry, once the first scan header arrives (every table-independent reason to decline a file)
+static int finish_frame(Parsed& out) {
+    Frame& f = out.f;
+    // colour space as jdapimin.c default_decompress_parms decides it: JFIF -> YCbCr; else Adobe's transform flag; else YCbCr unless
+    // the component ids spell "RGB"
+    if (f.ncomp == 3) {
+        if (!out.jfif && out.adobe >= 0 && out.adobe != 1) return MQ_EUNSUPPORTED;
+        if (!out.jfif && out.adobe < 0 && f.id[0] == 'R' && f.id[1] == 'G' && f.id[2] == 'B') return MQ_EUNSUPPORTED;
+    }
+    if (f.ncomp == 1) {
+        f.ch[0] = f.cv[0] = 1;   // a single-component scan is not interleaved: one block per MCU whatever the factors say
+    } else {
+        if (f.ch[1] != 1 || f.cv[1] != 1 || f.ch[2] != 1 || f.cv[2] != 1) return MQ_EUNSUPPORTED;
+        if (f.ch[0] > 2 || f.cv[0] > 2) return MQ_EUNSUPPORTED;
+    }
+    f.hmax = f.ch[0];
+    f.vmax = f.cv[0];
+    if ((int64_t)f.height * f.width > (int64_t)MQ_JPEG_MAX_PIXELS) return MQ_EUNSUPPORTED;
+    f.mcux = (f.width + 8 * f.hmax - 1) / (8 * f.hmax);
+    f.mcuy = (f.height + 8 * f.vmax - 1) / (8 * f.vmax);
+    int first = 0;
+    for (int c = 0; c < f.ncomp; ++c) {
+        f.bw[c] = f.mcux * f.ch[c];
+        f.bh[c] = f.mcuy * f.cv[c];
+        f.first[c] = first;
+        first += f.bw[c] * f.bh[c];
+    }
+    f.blocks = first;
+    out.geometry_done = true;
+    return MQ_OK;
+}
+
+// Reads segments from out.pos on.  -> MQ_OK at a start-of-scan (its header in `out`, out.scan = the first entropy-coded byte),
+// 1 at the end-of-image marker; MQ_EUNSUPPORTED: a valid-looking file of a kind not handled here; MQ_EINVAL: damaged
+static int next_scan(const uint8_t* d, size_t nbytes, Parsed& out) {
+    size_t pos = out.pos;
     for (;;) {
-        if (pos + 4 > nbytes || d[pos] != 0xFF) return MQ_EINVAL;
+        if (pos + 2 > nbytes || d[pos] != 0xFF) return MQ_EINVAL;
         const int m = d[pos + 1];
         if (m == 0xFF) { ++pos; continue; }   // fill byte
-        if (m == 0xD8 || m == 0xD9 || m == 0x01 || (m >= 0xD0 && m <= 0xD7) || m == 0x00) return MQ_EINVAL;
+        if (m == 0xD9) { out.pos = pos; return 1; }
+        if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7) || m == 0x00) return MQ_EINVAL;
+        if (pos + 4 > nbytes) return MQ_EINVAL;
         const size_t ln = (size_t)be16(d + pos + 2);
         if (ln < 2 || pos + 2 + ln > nbytes) return MQ_EINVAL;
         const uint8_t* s = d + pos + 4;
@@ -181,6 +225,7 @@ static int parse(const uint8_t* d, size_t nbytes, Parsed& out) {
                 const int pq = s[q] >> 4, t = s[q] & 15;
                 ++q;
                 if (t > 3 || pq > 1 || q + (pq ? 128u : 64u) > sl) return MQ_EINVAL;
+                if (out.have_qt[t] && out.geometry_done) return MQ_EUNSUPPORTED;   // a table replaced between scans: which blocks it applies to is Pillow's business
                 for (int i = 0; i < 64; ++i) out.qt[t][NATURAL[i]] = pq ? (uint16_t)be16(s + q + 2 * i) : s[q + i];
                 q += pq ? 128 : 64;
                 out.have_qt[t] = true;
@@ -197,8 +242,8 @@ static int parse(const uint8_t* d, size_t nbytes, Parsed& out) {
                 if (!build_huff(tc ? out.ac[th] : out.dc[th], s + q + 1, s + q + 17, ns)) return MQ_EINVAL;
                 q += 17 + (size_t)ns;
             }
-        } else if (m == 0xC0 || m == 0xC1) {
-            if (have_frame || sl < 6) return MQ_EINVAL;
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+            if (out.have_frame || sl < 6) return MQ_EINVAL;
             Frame& f = out.f;
             if (s[0] != 8) return MQ_EUNSUPPORTED;
             f.height = be16(s + 1);
@@ -214,61 +259,63 @@ static int parse(const uint8_t* d, size_t nbytes, Parsed& out) {
                 f.tq[c] = s[8 + 3 * c];
                 if (f.ch[c] < 1 || f.ch[c] > 4 || f.cv[c] < 1 || f.cv[c] > 4 || f.tq[c] > 3) return MQ_EINVAL;
             }
-            have_frame = true;
-        } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
-            return MQ_EUNSUPPORTED;   // progressive, lossless, arithmetic, differential
-        } else if (m == 0xCC) {
-            return MQ_EUNSUPPORTED;   // arithmetic conditioning
+            if (f.ncomp == 3 && (f.id[0] == f.id[1] || f.id[0] == f.id[2] || f.id[1] == f.id[2])) return MQ_EUNSUPPORTED;
+            out.have_frame = true;
+            out.progressive = m == 0xC2;
+        } else if (m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8)) {
+            return MQ_EUNSUPPORTED;   // lossless, arithmetic, differential
         } else if (m == 0xDD) {
             if (sl < 2) return MQ_EINVAL;
             out.restart = be16(s);
         } else if (m == 0xE0) {
-            if (sl >= 5 && !memcmp(s, "JFIF\0", 5)) jfif = true;
+            if (sl >= 5 && !memcmp(s, "JFIF\0", 5)) out.jfif = true;
         } else if (m == 0xEE) {
-            if (sl >= 12 && !memcmp(s, "Adobe", 5)) adobe = s[11];
+            if (sl >= 12 && !memcmp(s, "Adobe", 5)) out.adobe = s[11];
         } else if (m == 0xDA) {
-            if (!have_frame) return MQ_EINVAL;
-            Frame& f = out.f;
-            if (sl < 1 || s[0] != f.ncomp || sl < 4u + 2u * f.ncomp) return MQ_EUNSUPPORTED;   // one interleaved scan only
-            for (int c = 0; c < f.ncomp; ++c) {
-                if (s[1 + 2 * c] != f.id[c]) return MQ_EUNSUPPORTED;
-                out.td[c] = s[2 + 2 * c] >> 4;
-                out.ta[c] = s[2 + 2 * c] & 15;
-                if (out.td[c] > 3 || out.ta[c] > 3 || !out.dc[out.td[c]].defined || !out.ac[out.ta[c]].defined) return MQ_EINVAL;
-                if (!out.have_qt[f.tq[c]]) return MQ_EINVAL;
+            if (!out.have_frame) return MQ_EINVAL;
+            const Frame& f = out.f;
+            if (sl < 1) return MQ_EINVAL;
+            out.ns = s[0];
+            if (out.ns < 1 || out.ns > f.ncomp || sl < 4u + 2u * out.ns) return MQ_EINVAL;
+            for (int i = 0; i < out.ns; ++i) {
+                int c = 0;
+                while (c < f.ncomp && f.id[c] != s[1 + 2 * i]) ++c;
+                if (c == f.ncomp || (i && c <= out.sc[i - 1])) return MQ_EUNSUPPORTED;   // components of a scan come in frame order
+                out.sc[i] = c;
+                out.td[i] = s[2 + 2 * i] >> 4;
+                out.ta[i] = s[2 + 2 * i] & 15;
+                if (out.td[i] > 3 || out.ta[i] > 3) return MQ_EINVAL;
             }
-            const uint8_t* t = s + 1 + 2 * f.ncomp;
-            if (t[0] != 0 || t[1] != 63 || t[2] != 0) return MQ_EUNSUPPORTED;
-            // colour space as jdapimin.c default_decompress_parms decides it: JFIF -> YCbCr; else Adobe's transform flag; else
-            // YCbCr unless the component ids spell "RGB"
-            if (f.ncomp == 3) {
-                if (!jfif && adobe >= 0 && adobe != 1) return MQ_EUNSUPPORTED;
-                if (!jfif && adobe < 0 && f.id[0] == 'R' && f.id[1] == 'G' && f.id[2] == 'B') return MQ_EUNSUPPORTED;
+            const uint8_t* t = s + 1 + 2 * out.ns;
+            out.ss = t[0]; out.se = t[1]; out.ah = t[2] >> 4; out.al = t[2] & 15;
+            if (!out.geometry_done) {
+                const int rc = finish_frame(out);
+                if (rc != MQ_OK) return rc;
             }
-            if (f.ncomp == 1) {
-                f.ch[0] = f.cv[0] = 1;   // a single-component scan is not interleaved: one block per MCU whatever the factors say
-            } else {
-                if (f.ch[1] != 1 || f.cv[1] != 1 || f.ch[2] != 1 || f.cv[2] != 1) return MQ_EUNSUPPORTED;
-                if (f.ch[0] > 2 || f.cv[0] > 2) return MQ_EUNSUPPORTED;
-            }
-            f.hmax = f.ch[0];
-            f.vmax = f.cv[0];
-            if ((int64_t)f.height * f.width > (int64_t)MQ_JPEG_MAX_PIXELS) return MQ_EUNSUPPORTED;
-            f.mcux = (f.width + 8 * f.hmax - 1) / (8 * f.hmax);
-            f.mcuy = (f.height + 8 * f.vmax - 1) / (8 * f.vmax);
-            int first = 0;
-            for (int c = 0; c < f.ncomp; ++c) {
-                f.bw[c] = f.mcux * f.ch[c];
-                f.bh[c] = f.mcuy * f.cv[c];
-                f.first[c] = first;
-                first += f.bw[c] * f.bh[c];
-            }
-            f.blocks = first;
             out.scan = d + pos;
+            out.pos = pos;
             return MQ_OK;
         }
         // every other segment (APPn, COM, ...) is skipped
     }
+}
+
+// the headers of a file up to its first scan, and whether this library decodes that kind of file
+static int parse(const uint8_t* d, size_t nbytes, Parsed& out) {
+    int rc = begin(d, nbytes, out);
+    if (rc != MQ_OK) return rc;
+    rc = next_scan(d, nbytes, out);
+    if (rc == 1) return MQ_EINVAL;   // no scan at all
+    if (rc != MQ_OK) return rc;
+    const Frame& f = out.f;
+    if (!out.progressive) {   // one interleaved scan of everything
+        if (out.ns != f.ncomp || out.ss != 0 || out.se != 63 || out.ah != 0 || out.al != 0) return MQ_EUNSUPPORTED;
+        for (int c = 0; c < f.ncomp; ++c) {
+            if (!out.dc[out.td[c]].defined || !out.ac[out.ta[c]].defined) return MQ_EINVAL;
+            if (!out.have_qt[f.tq[c]]) return MQ_EINVAL;
+        }
+    }
+    return MQ_OK;
 }
 
 static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -292,6 +339,183 @@ static inline int extend(Bits& b, int s) {
     const int v = (int)b.peek(s);
     b.drop(s);
     return v < (1 << (s - 1)) ? v + (int)((~0u) << s) + 1 : v;
+}
+
+// one bit / s bits of the scan
+static inline int get_bit(Bits& b) { const int v = (int)b.peek(1); b.drop(1); return v; }
+
+static inline int decode_symbol(Bits& b, const Huff& t) {
+    const uint32_t e = t.tab[b.peek(LOOK)];
+    if (e & 31) { b.drop((int)(e & 31)); return (int)(((e >> 5) & 15) << 4) | (int)((e >> 9) & 15); }
+    return decode_slow(b, t);
+}
+
+// the 16-bit domain of libjpeg-turbo's vector inverse DCT (see the note in mq_jpeg_read_coefficients), on a finished block
+static bool block_in_domain(const int16_t* blk, const uint16_t* qn) {
+    unsigned colsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, big = 0;
+    for (int i = 0; i < 64; ++i) {
+        const int v = blk[i];
+        if (!v) continue;
+        const unsigned t = (unsigned)(v < 0 ? -v : v) * qn[i];
+        big = t > big ? t : big;
+        colsum[i & 7] += t;
+        if (colsum[i & 7] > 1000000u) return false;
+    }
+    return !(big > 5890 || colsum[2] > 5890 || colsum[6] > 5890 || colsum[0] + colsum[4] > 5890 || colsum[3] + colsum[7] > 5890 ||
+             colsum[1] + colsum[5] > 5890);
+}
+
+// Progressive files (jdphuff.c): every scan adds bits to the coefficient blocks (cleared by the caller) -- DC first / refinement scans
+// over one or all components, AC first / refinement scans over one component and a band Ss .. Se, successive approximation by Al.
+// The progression must be the regular one (each coefficient's first scan with Ah = 0, every later one with Ah = the Al before it,
+// down to Al = 0 for all 64 coefficients of every component: libjpeg only warns about anything else, and an INCOMPLETE progression
+// makes it smooth across blocks).  -> false: the file is Pillow's.
+static bool read_progressive(const uint8_t* file, size_t nbytes, Parsed* ps, int16_t* coef) {
+    const Frame& f = ps->f;
+    int bits_known[3][64];   // libjpeg's coef_bits: -1 = not seen yet, else the Al of the coefficient's last scan
+    for (int c = 0; c < 3; ++c)
+        for (int k = 0; k < 64; ++k) bits_known[c][k] = -1;
+    for (int scans = 0;; ++scans) {
+        if (scans > 256) return false;
+        const int ns = ps->ns, ss = ps->ss, se = ps->se, ah = ps->ah, al = ps->al;
+        if (ss > se || se > 63 || al > 13) return false;
+        if (ss == 0 ? se != 0 : ns != 1) return false;        // DC scans hold the DC only; AC scans one component
+        if (ah != 0 && al != ah - 1) return false;
+        for (int i = 0; i < ns; ++i) {
+            const int c = ps->sc[i];
+            if (ss != 0 && bits_known[c][0] < 0) return false;   // AC before the component's DC
+            for (int k = ss; k <= se; ++k) {
+                if ((bits_known[c][k] < 0 ? 0 : bits_known[c][k]) != ah) return false;
+                bits_known[c][k] = al;
+            }
+            if (ss == 0 ? (ah == 0 && !ps->dc[ps->td[i]].defined) : !ps->ac[ps->ta[i]].defined) return false;
+        }
+        Bits b{ps->scan, file + nbytes, 0, 0, 0};
+        int pred[3] = {0, 0, 0};
+        int todo = ps->restart, rst = 0;
+        unsigned eobrun = 0;
+        // the scan's MCUs: interleaved (ns > 1) = the frame's MCUs; one component = its blocks that hold image samples
+        const int c0 = ps->sc[0];
+        const int nx = ns > 1 ? f.mcux : ((f.width * f.ch[c0] + f.hmax - 1) / f.hmax + 7) / 8;
+        const int ny = ns > 1 ? f.mcuy : ((f.height * f.cv[c0] + f.vmax - 1) / f.vmax + 7) / 8;
+        const int p1 = 1 << al, m1 = (int)((~0u) << al);
+        for (int my = 0; my < ny; ++my)
+            for (int mx = 0; mx < nx; ++mx) {
+                if (ps->restart && todo == 0) {
+                    if (b.n < b.fake || b.n - b.fake >= 8) return false;
+                    if (!(b.p + 1 < b.end && b.p[0] == 0xFF && b.p[1] == 0xD0 + rst)) return false;
+                    b.p += 2;
+                    b.acc = 0; b.n = 0; b.fake = 0;
+                    rst = (rst + 1) & 7;
+                    pred[0] = pred[1] = pred[2] = 0;
+                    eobrun = 0;
+                    todo = ps->restart;
+                }
+                for (int i = 0; i < ns; ++i) {
+                    const int c = ps->sc[i];
+                    const int nby = ns > 1 ? f.cv[c] : 1, nbx = ns > 1 ? f.ch[c] : 1;
+                    for (int by = 0; by < nby; ++by)
+                        for (int bx = 0; bx < nbx; ++bx) {
+                            int16_t* blk = coef + ((size_t)f.first[c] + (size_t)(my * nby + by) * f.bw[c] + (mx * nbx + bx)) * 64;
+                            b.fill();
+                            if (ss == 0) {
+                                if (ah == 0) {   // DC, first scan
+                                    const int sz = decode_symbol(b, ps->dc[ps->td[i]]);
+                                    if (sz < 0 || sz > 11) return false;
+                                    if (sz) pred[c] += extend(b, sz);
+                                    if (pred[c] < -32768 || pred[c] > 32767) return false;
+                                    const int v = (int)((unsigned)pred[c] << al);
+                                    if (v < -32768 || v > 32767) return false;
+                                    blk[0] = (int16_t)v;
+                                } else if (get_bit(b)) blk[0] = (int16_t)(blk[0] | p1);   // DC refinement
+                                continue;
+                            }
+                            const Huff& ac = ps->ac[ps->ta[i]];
+                            if (ah == 0) {   // AC band, first scan
+                                if (eobrun > 0) { --eobrun; continue; }
+                                for (int k = ss; k <= se; ++k) {
+                                    b.fill();
+                                    const int rs = decode_symbol(b, ac);
+                                    if (rs < 0) return false;
+                                    const int r = rs >> 4, sz = rs & 15;
+                                    if (sz) {
+                                        k += r;
+                                        if (k > se) return false;
+                                        const int v = (int)((unsigned)extend(b, sz) << al);
+                                        if (v < -32768 || v > 32767) return false;
+                                        blk[NATURAL[k]] = (int16_t)v;
+                                    } else if (r == 15) k += 15;
+                                    else {
+                                        eobrun = 1u << r;
+                                        if (r) eobrun += b.peek(r), b.drop(r);
+                                        --eobrun;
+                                        break;
+                                    }
+                                }
+                                continue;
+                            }
+                            // AC band, refinement: one more bit for the coefficients already non-zero, new +-1 coefficients between them
+                            int k = ss;
+                            if (eobrun == 0) {
+                                for (; k <= se; ++k) {
+                                    b.fill();
+                                    const int rs = decode_symbol(b, ac);
+                                    if (rs < 0) return false;
+                                    int r = rs >> 4, sz = rs & 15, nv = 0;
+                                    if (sz) {
+                                        if (sz != 1) return false;
+                                        nv = get_bit(b) ? p1 : m1;
+                                    } else if (r != 15) {
+                                        eobrun = 1u << r;
+                                        if (r) eobrun += b.peek(r), b.drop(r);
+                                        break;   // the rest of the band is handled below
+                                    }
+                                    do {
+                                        int16_t* cf = blk + NATURAL[k];
+                                        if (*cf != 0) {
+                                            b.fill();
+                                            if (get_bit(b) && (*cf & p1) == 0) *cf = (int16_t)(*cf >= 0 ? *cf + p1 : *cf + m1);
+                                        } else if (--r < 0) break;
+                                        ++k;
+                                    } while (k <= se);
+                                    if (nv) {
+                                        if (k > se) return false;
+                                        blk[NATURAL[k]] = (int16_t)nv;
+                                    }
+                                }
+                            }
+                            if (eobrun > 0) {
+                                for (; k <= se; ++k) {
+                                    int16_t* cf = blk + NATURAL[k];
+                                    if (*cf != 0) {
+                                        b.fill();
+                                        if (get_bit(b) && (*cf & p1) == 0) *cf = (int16_t)(*cf >= 0 ? *cf + p1 : *cf + m1);
+                                    }
+                                }
+                                --eobrun;
+                            }
+                        }
+                }
+                --todo;
+            }
+        if (eobrun != 0) return false;   // a run of empty bands that outlives its scan
+        // nothing but the padding of the last byte may be left, and a marker follows
+        if (b.n < b.fake || b.n - b.fake >= 8) return false;
+        ps->pos = (size_t)(b.p - file);
+        const int rc = next_scan(file, nbytes, *ps);
+        if (rc == 1) break;   // end of image
+        if (rc != MQ_OK) return false;
+    }
+    for (int c = 0; c < f.ncomp; ++c) {
+        if (!ps->have_qt[f.tq[c]]) return false;
+        for (int k = 0; k < 64; ++k)
+            if (bits_known[c][k] != 0) return false;   // an incomplete progression
+        // the blocks outside the component's image area but inside the MCU grid got their DC from the interleaved scans only; all
+        // blocks must lie in the vector code's domain
+        for (int bi = 0; bi < f.bw[c] * f.bh[c]; ++bi)
+            if (!block_in_domain(coef + ((size_t)f.first[c] + bi) * 64, ps->qt[f.tq[c]])) return false;
+    }
+    return true;
 }
 
 }  // namespace
@@ -336,6 +560,15 @@ int mq_jpeg_read_coefficients(const uint8_t* file_host, size_t nbytes, void* sta
     int16_t* coef = reinterpret_cast<int16_t*>(static_cast<uint8_t*>(staging_host) + HDR);
     memset(coef, 0, (size_t)f.blocks * 128);
 
+    if (ps->progressive) {
+        const bool ok = read_progressive(file_host, nbytes, ps, coef);
+        if (ok)   // the tables may have arrived after the first scan header
+            for (int c = 0; c < f.ncomp; ++c) memcpy(q + 64 * c, ps->qt[f.tq[c]], 128);
+        delete ps;
+        if (!ok) return MQ_EINVAL;
+        hw[H_MAGIC] = MQ_JPEG_MAGIC_COEFFICIENTS;
+        return MQ_OK;
+    }
     Bits b{ps->scan, file_host + nbytes, 0, 0, 0};
     int pred[3] = {0, 0, 0};
     int todo = ps->restart, rst = 0;
