@@ -114,3 +114,29 @@ def test_progressive_files():
         files.append(buf.getvalue())
     for n, (d, g) in enumerate(zip(files, dj.decode_files(files))):
         assert np.array_equal(g.cpu().numpy(), _pillow(d)), n
+
+
+@pytest.mark.parametrize("mode", ["420", "422", "444", "grey", "420p"])
+def test_every_small_size(mode):
+    """All sizes 1 x 1 ... 34 x 34 (every position of the image edge inside a block, an MCU and the colour kernel's 8 x 2 strips;
+    row starts at all four byte alignments), one batch per sampling."""
+    from viquae_amd.image import jpeg as dj
+    rng = np.random.default_rng(len(mode))
+    base = rng.integers(0, 256, (34, 34, 3), dtype=np.uint8)
+    files = []
+    for h in range(1, 35):
+        for w in range(1, 35):
+            im = Image.fromarray(base[:h, :w].copy(), "RGB")
+            kw = dict(quality=92)
+            if mode == "grey":
+                im = im.convert("L")
+            else:
+                kw["subsampling"] = {"444": 0, "422": 1, "420": 2, "420p": 2}[mode]
+            if mode == "420p":
+                kw["progressive"] = True
+            buf = io.BytesIO()
+            im.save(buf, "JPEG", **kw)
+            files.append(buf.getvalue())
+    got = dj.decode_files(files)
+    bad = [(n // 34 + 1, n % 34 + 1) for n, (d, g) in enumerate(zip(files, got)) if not np.array_equal(g.cpu().numpy(), _pillow(d))]
+    assert not bad, bad[:10]
