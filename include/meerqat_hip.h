@@ -549,7 +549,7 @@ int mq_image_preprocess_u8(const uint8_t *src_dev, const int64_t *geom_dev, int 
  *   MQ_JPEG_MAGIC_RGB, height, width.
  * mq_jpeg_decode_rgb_u8 (GPU): items_dev int64 [n_images][2] = (byte offset of an image's header, byte offset of its RGB
  *   output) inside buf_dev (16-byte aligned offsets and buffer); max_blocks / max_strips = the largest block count and the
- *   largest ceil(height / 2) * ceil(width / 8) of the batch (the colour kernel runs one thread per 8 x 2 pixels).  The inverse DCT runs in place (the coefficient area is consumed); the H x W x 3 bytes are what
+ *   largest ceil(height / 2) * ceil(width / 16) of the batch (the colour kernel runs one thread per 16 x 2 pixels).  The inverse DCT runs in place (the coefficient area is consumed); the H x W x 3 bytes are what
  *   mq_image_preprocess_u8 / mq_warp_affine_faces_f32 read.
  * ------------------------------------------------------------------------------------------- */
 #define MQ_JPEG_INFO 6

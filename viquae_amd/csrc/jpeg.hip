@@ -12,7 +12,7 @@
 //          its 64 sample bytes);
 //          jpeg_rgb_kernel: jdsample.c's fancy chroma upsampling (h2v1, h2v2, h1v2 triangle filters with libjpeg's rounding
 //          constants and edge rules, replication when a component is no wider than two samples) + jdcolor.c's fixed-point
-//          YCbCr -> RGB, one thread per 8 x 2 pixels (a luma block's row pair, four chroma samples of a 4:2:0 file), HWC uint8 at the image's offset of the packed source buffer that
+//          YCbCr -> RGB, one thread per 16 x 2 pixels (two luma blocks' row pair, one chroma block row of a 4:2:0 file), HWC uint8 at the image's offset of the packed source buffer that
 //          mq_image_preprocess_u8 reads.
 //
 // Byte / integer work; the kernels are bound by HBM (a 4:2:0 image: 3 bytes of coefficients read + 1.5 written + 1.5 read + 3
@@ -786,61 +786,69 @@ __device__ __forceinline__ unsigned ycc_rgb(int Y, int cb, int cr) {
     return (unsigned)r | ((unsigned)g << 8) | ((unsigned)b << 16);
 }
 
-struct __attribute__((packed, aligned(4))) Words6 { unsigned w[6]; };
+struct __attribute__((packed, aligned(4))) Words12 { unsigned w[12]; };
 
-// up to eight pixels (24-bit values) of one row -> 3 n consecutive bytes at dst + at
-__device__ __forceinline__ void store_row(uint8_t* dst, size_t at, const unsigned (&p)[8], int n) {
-    if (n == 8 && !(at & 3)) {
-        Words6 o;
-        o.w[0] = p[0] | (p[1] << 24);
-        o.w[1] = (p[1] >> 8) | (p[2] << 16);
-        o.w[2] = (p[2] >> 16) | (p[3] << 8);
-        o.w[3] = p[4] | (p[5] << 24);
-        o.w[4] = (p[5] >> 8) | (p[6] << 16);
-        o.w[5] = (p[6] >> 16) | (p[7] << 8);
-        *reinterpret_cast<Words6*>(dst + at) = o;
+// up to sixteen pixels (24-bit values) of one row -> 3 n consecutive bytes at dst + at
+__device__ __forceinline__ void store_row(uint8_t* dst, size_t at, const unsigned (&p)[16], int n) {
+    if (n == 16 && !(at & 3)) {
+        Words12 o;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            o.w[3 * g] = p[4 * g] | (p[4 * g + 1] << 24);
+            o.w[3 * g + 1] = (p[4 * g + 1] >> 8) | (p[4 * g + 2] << 16);
+            o.w[3 * g + 2] = (p[4 * g + 2] >> 16) | (p[4 * g + 3] << 8);
+        }
+        *reinterpret_cast<Words12*>(dst + at) = o;
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 16; ++i)
         if (i < n) { dst[at + 3 * i] = (uint8_t)p[i]; dst[at + 3 * i + 1] = (uint8_t)(p[i] >> 8); dst[at + 3 * i + 2] = (uint8_t)(p[i] >> 16); }
 }
 
-// six chroma samples of one row around the strip's four (columns cx - 1 .. cx + 4, those beyond the component's REAL samples
-// replaced by the edge ones): one 4-byte load (the four share a block row: cx is a multiple of 4) + the two neighbours
-__device__ __forceinline__ void chroma_row(const Plane& pl, int row, int cx, int (&v)[6]) {
-    const uint8_t* rp = pl.base + ((size_t)(row >> 3) * pl.bw + (cx >> 3)) * 128 + ((row & 7) << 3) + (cx & 7);
-    const unsigned m = *reinterpret_cast<const unsigned*>(rp);
-    const int e = pl.dw - 1 - cx;   // index of the last real sample among the four (>= 0)
-    const int m0 = m & 255, m1 = (m >> 8) & 255, m2 = (m >> 16) & 255, m3 = m >> 24;
-    const int last = e >= 3 ? m3 : (e == 2 ? m2 : (e == 1 ? m1 : m0));
-    v[1] = m0;
-    v[2] = e >= 1 ? m1 : last;
-    v[3] = e >= 2 ? m2 : last;
-    v[4] = e >= 3 ? m3 : last;
-    v[0] = cx > 0 ? pl.at(row, cx - 1) : m0;
-    v[5] = e >= 4 ? pl.at(row, cx + 4) : last;
+// ten chroma samples of one row around the strip's eight (columns cx - 1 .. cx + 8, those beyond the component's REAL samples
+// replaced by the edge one): the eight are one block row = ONE 8-byte load; the two neighbours are the last / first byte of the
+// block rows the adjacent lanes just loaded (their strips are the adjacent blocks) and come over the lane crossbar -- a byte load
+// only where the adjacent lane holds something else (the wave's first / last lane)
+__device__ __forceinline__ void chroma_row(const Plane& pl, int row, int sx, bool left_lane, bool right_lane, int (&v)[10]) {
+    const int cx = 8 * sx;
+    const uint8_t* rp = pl.base + ((size_t)(row >> 3) * pl.bw + sx) * 128 + ((row & 7) << 3);
+    const uint2 m = *reinterpret_cast<const uint2*>(rp);
+    const unsigned from_left = (unsigned)__shfl_up((int)m.y, 1), from_right = (unsigned)__shfl_down((int)m.x, 1);
+    const int e = pl.dw - 1 - cx;   // index of the last real sample among the eight (>= 0)
+    int s[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s[i] = (m.x >> (8 * i)) & 255; s[4 + i] = (m.y >> (8 * i)) & 255; }
+    int last = s[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) last = i <= e ? s[i] : last;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[1 + i] = i <= e ? s[i] : last;
+    v[0] = sx == 0 ? s[0] : (left_lane ? (int)(from_left >> 24) : (int)rp[-121]);            // byte 7 of the block row to the left
+    v[9] = e < 8 ? last : (right_lane ? (int)(from_right & 255) : (int)rp[128]);              // byte 0 of the block row to the right
 }
 
-// grid (chunks of 256 strips, images), 256 threads: thread = an 8 x 2 strip of output pixels (x a multiple of 8, y even).  For
-// 4:2:0 files -- the usual case -- that is one luma block's width and four chroma samples: three rows of six chroma samples per
-// plane come in as one 4-byte + two 1-byte loads each, the vertical 3 : 1 sums are shared by all the strip's pixels, the luma is two
-// 8-byte loads, and a row of the strip leaves as ONE 24-byte store when its address is 4-byte aligned (always, when the width is
-// a multiple of 4).  32 memory instructions per 16 pixels; the first version (one thread per pixel, nine single-byte loads and three
-// single-byte stores each) took 3.8 ms per 3072-image batch, one thread per 2 x 2 pixels 2.85 ms.  Every other sampling takes
-// the general per-pixel form of the filters.
+// grid (chunks of 256 strips, images), 256 threads: thread = a 16 x 2 strip of output pixels (x a multiple of 16, y even).  For
+// 4:2:0 files -- the usual case -- that is two luma blocks' width and ONE chroma block's: three rows of ten chroma samples per plane
+// come in as one 8-byte load each plus two values from the adjacent lanes, the vertical 3 : 1 sums are shared by all the strip's
+// pixels, the luma is four 8-byte loads, and a row of the strip leaves as ONE 48-byte store when its address is 4-byte aligned
+// (always, when the width is a multiple of 4).  12 memory instructions per 32 pixels.  History, all bit-identical, per 3072-image
+// batch: one thread per pixel (nine single-byte loads, three single-byte stores each) 3.79 ms; per 2 x 2 pixels 2.85 ms; per 8 x 2
+// pixels (4-byte chroma loads + byte loads for the neighbours) 1.58 ms -- the kernel is bound by the NUMBER of narrow accesses.
+// Every other sampling takes the general per-pixel form of the filters.
 __global__ __launch_bounds__(256) void jpeg_rgb_kernel(uint8_t* __restrict__ buf, const int64_t* __restrict__ items) {
     const int img = blockIdx.y;
     const uint8_t* st = buf + items[2 * img];
     uint8_t* dst = buf + items[2 * img + 1];
     const int32_t* hw = reinterpret_cast<const int32_t*>(st);
     const int h = hw[H_HEIGHT], w = hw[H_WIDTH];
-    const int sw = (w + 7) >> 3, qh = (h + 1) >> 1;
+    const int sw = (w + 15) >> 4, qh = (h + 1) >> 1;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= sw * qh) return;
+    const int lane = threadIdx.x & 63;
     const int qy = t / sw, sx = t - qy * sw;
-    const int y = 2 * qy, x = 8 * sx;
-    const int n = w - x < 8 ? w - x : 8;   // pixels of the strip inside the image
+    const int y = 2 * qy, x = 16 * sx;
+    const int n = w - x < 16 ? w - x : 16;   // pixels of the strip inside the image
     const bool below = y + 1 < h;
     const size_t at0 = ((size_t)y * w + x) * 3, at1 = at0 + (size_t)w * 3;
     const int magic = hw[H_MAGIC];
@@ -856,41 +864,46 @@ __global__ __launch_bounds__(256) void jpeg_rgb_kernel(uint8_t* __restrict__ buf
     const uint8_t* blocks = st + HDR;
     const int ncomp = hw[H_NCOMP];
     const Plane py{blocks, hw[H_BW], hw[H_DW], hw[H_DH]};
-    // luma: the strip is one block's row, and the row below it (blocks are padded to MCUs: it exists even when the image ends)
-    const uint8_t* yp = blocks + ((size_t)(y >> 3) * py.bw + sx) * 128 + ((y & 7) << 3);
-    const uint2 ya = *reinterpret_cast<const uint2*>(yp);
-    const uint2 yb = *reinterpret_cast<const uint2*>(yp + 8);   // y is even: the next row is in the same block
-    int Y0[8], Y1[8];
+    // luma: two blocks' rows y and y + 1 (y is even: the same blocks; blocks are padded to MCUs: the row exists even when the
+    // image ends at y).  The second block may lie beyond the component when the sampling is not 2 x 2: its pixels are not stored.
+    const int b0 = 2 * sx, b1 = 2 * sx + 1 < py.bw ? 2 * sx + 1 : b0;
+    const uint8_t* yrow = blocks + (size_t)(y >> 3) * py.bw * 128 + ((y & 7) << 3);
+    const uint2 ya0 = *reinterpret_cast<const uint2*>(yrow + (size_t)b0 * 128), ya1 = *reinterpret_cast<const uint2*>(yrow + (size_t)b1 * 128);
+    const uint2 yb0 = *reinterpret_cast<const uint2*>(yrow + (size_t)b0 * 128 + 8), yb1 = *reinterpret_cast<const uint2*>(yrow + (size_t)b1 * 128 + 8);
+    int Y0[16], Y1[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        Y0[i] = (ya.x >> (8 * i)) & 255; Y0[4 + i] = (ya.y >> (8 * i)) & 255;
-        Y1[i] = (yb.x >> (8 * i)) & 255; Y1[4 + i] = (yb.y >> (8 * i)) & 255;
+        Y0[i] = (ya0.x >> (8 * i)) & 255; Y0[4 + i] = (ya0.y >> (8 * i)) & 255; Y0[8 + i] = (ya1.x >> (8 * i)) & 255; Y0[12 + i] = (ya1.y >> (8 * i)) & 255;
+        Y1[i] = (yb0.x >> (8 * i)) & 255; Y1[4 + i] = (yb0.y >> (8 * i)) & 255; Y1[8 + i] = (yb1.x >> (8 * i)) & 255; Y1[12 + i] = (yb1.y >> (8 * i)) & 255;
     }
-    unsigned p0[8], p1[8];
+    unsigned p0[16], p1[16];
     if (ncomp == 1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { p0[i] = Y0[i] * 0x010101u; p1[i] = Y1[i] * 0x010101u; }
+        for (int i = 0; i < 16; ++i) { p0[i] = Y0[i] * 0x010101u; p1[i] = Y1[i] * 0x010101u; }
     } else {
         const int hexp = hw[H_HMAX], vexp = hw[H_VMAX];   // chroma is 1 x 1: its expansion is the luma's factor
         const Plane pb{blocks + (size_t)hw[H_FIRST + 1] * 128, hw[H_BW + 1], hw[H_DW + 1], hw[H_DH + 1]};
         const Plane pr{blocks + (size_t)hw[H_FIRST + 2] * 128, hw[H_BW + 2], hw[H_DW + 2], hw[H_DH + 2]};
         if (hexp == 2 && vexp == 2 && pb.dw > 2) {
-            // h2v2_fancy_upsample: chroma row qy between its neighbours (beyond the component's REAL rows: the edge row)
-            const int cx = 4 * sx;
+            // h2v2_fancy_upsample: chroma row qy between its neighbours (beyond the component's REAL rows: the edge row).  The
+            // adjacent lane holds the adjacent strip of the same rows unless this lane is the wave's first / last one or the
+            // strip the row's (the lanes of a wave that are past the image's last strip have left: never the right neighbour of a
+            // strip with sx + 1 < sw)
+            const bool left_lane = lane > 0 && sx > 0, right_lane = lane < 63 && sx + 1 < sw;
             const int r0 = qy > 0 ? qy - 1 : 0, r2 = qy + 1 < pb.dh ? qy + 1 : qy;
-            int c0[2][8], c1[2][8];   // [Cb, Cr][pixel] of the upper / the lower row
+            int c0[2][16], c1[2][16];   // [Cb, Cr][pixel] of the upper / the lower row
 #pragma unroll
             for (int comp = 0; comp < 2; ++comp) {
                 const Plane& pl = comp ? pr : pb;
-                int a[6], m[6], d[6];
-                chroma_row(pl, r0, cx, a);
-                chroma_row(pl, qy, cx, m);
-                chroma_row(pl, r2, cx, d);
-                int tu[6], tl[6];
+                int a[10], m[10], d[10];
+                chroma_row(pl, r0, sx, left_lane, right_lane, a);
+                chroma_row(pl, qy, sx, left_lane, right_lane, m);
+                chroma_row(pl, r2, sx, left_lane, right_lane, d);
+                int tu[10], tl[10];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) { tu[i] = 3 * m[i] + a[i]; tl[i] = 3 * m[i] + d[i]; }   // the row above is the farther one for the upper output row
+                for (int i = 0; i < 10; ++i) { tu[i] = 3 * m[i] + a[i]; tl[i] = 3 * m[i] + d[i]; }   // the row above is the farther one for the upper output row
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 8; ++j) {
                     c0[comp][2 * j] = (3 * tu[j + 1] + tu[j] + 8) >> 4;
                     c0[comp][2 * j + 1] = (3 * tu[j + 1] + tu[j + 2] + 7) >> 4;
                     c1[comp][2 * j] = (3 * tl[j + 1] + tl[j] + 8) >> 4;
@@ -898,16 +911,16 @@ __global__ __launch_bounds__(256) void jpeg_rgb_kernel(uint8_t* __restrict__ buf
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { p0[i] = ycc_rgb(Y0[i], c0[0][i], c0[1][i]); p1[i] = ycc_rgb(Y1[i], c1[0][i], c1[1][i]); }
+            for (int i = 0; i < 16; ++i) { p0[i] = ycc_rgb(Y0[i], c0[0][i], c0[1][i]); p1[i] = ycc_rgb(Y1[i], c1[0][i], c1[1][i]); }
         } else {
             const int y1 = below ? y + 1 : y;
 #pragma unroll 1
-            for (int i = 0; i < 8; ++i) {   // (clamped: the values of absent pixels are not stored)
+            for (int i = 0; i < 16; ++i) {   // (clamped: the values of absent pixels are not stored)
                 const int xi = x + i < w ? x + i : w - 1;
                 const unsigned u = ycc_rgb(py.at(y, xi), upsampled(pb, hexp, vexp, y, xi), upsampled(pr, hexp, vexp, y, xi));
                 const unsigned l = ycc_rgb(py.at(y1, xi), upsampled(pb, hexp, vexp, y1, xi), upsampled(pr, hexp, vexp, y1, xi));
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
+                for (int k = 0; k < 16; ++k)
                     if (k == i) { p0[k] = u; p1[k] = l; }
             }
         }

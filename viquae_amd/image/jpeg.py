@@ -47,8 +47,8 @@ def stage_rgb(rgb, buf, off):
 
 
 def strips(h, w):
-    """8 x 2 pixel strips of an h x w image: the colour kernel's threads."""
-    return ((h + 1) // 2) * ((w + 7) // 8)
+    """16 x 2 pixel strips of an h x w image: the colour kernel's threads."""
+    return ((h + 1) // 2) * ((w + 15) // 16)
 
 
 def plan_layout(geom, totals, jpeg_rows):
