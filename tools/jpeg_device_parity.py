@@ -39,10 +39,16 @@ def main():
             buf = io.BytesIO()
             try:
                 im.save(buf, "JPEG", **kw)
-            except OSError:
+            except OSError:   # libjpeg's "Suspension not allowed here": Pillow's output buffer is too small for this picture / option set
                 kw.pop("optimize", None)
-                buf = io.BytesIO()
-                im.save(buf, "JPEG", **kw)
+                kw["quality"] = min(kw["quality"], 75)
+                try:
+                    buf = io.BytesIO()
+                    im.save(buf, "JPEG", **kw)
+                except OSError:
+                    kw.pop("progressive", None)
+                    buf = io.BytesIO()
+                    im.save(buf, "JPEG", **kw)
             files.append(buf.getvalue())
             key = ("progressive " if kw.get("progressive") else "") + ("grey" if im.mode == "L" else {0: "4:4:4", 1: "4:2:2", 2: "4:2:0"}[kw["subsampling"]])
             kinds[key] = kinds.get(key, 0) + 1
