@@ -310,3 +310,56 @@ def test_compute_face_embedding_like_the_reference(tmp_path, monkeypatch):
     assert np.array_equal(np.asarray(face), oa.align_face(imgs[1], np.array(lms[1][0], np.float32)))
     from viquae_amd import encoders
     assert encoders.ArcFaceR50 is ArcFaceR50
+
+
+def test_pipelined_face_job_equals_the_serial_one(tmp_path, monkeypatch):
+    """dataset_compute_face_embedding (meerqat/image/face_recognition.py:105-112) software-pipelined -- decode workers, JPEG scans
+    finished on the GPU, alignment of batch i + 1 behind the ArcFace forward of batch i -- against the serial
+    compute_face_embedding mapped over the same dataset: the same arrays bit for bit, None where the reference has None (no
+    landmarks), None for a file that does not decode; `max_n_faces` arriving in map_kwargs like in the shipped config."""
+    import datasets
+    from PIL import Image
+    from oracle import arcface as oa
+    from viquae_amd.arcface import ArcFaceR50
+    from viquae_amd.data import loading
+    from viquae_amd.image import face_recognition as fr
+    datasets.disable_progress_bars()
+    rng = np.random.default_rng(9)
+    img_dir = tmp_path / "img"
+    img_dir.mkdir()
+    monkeypatch.setattr(loading, "IMAGE_PATH", img_dir)
+    yy, xx = np.mgrid[0:240, 0:300]
+    names, lms = [], []
+    for i in range(23):
+        a = np.stack([128 + 90 * np.sin(xx / (7 + c + i)) * np.cos(yy / (5 + c)) + rng.normal(0, 10, xx.shape) for c in range(3)], axis=2)
+        im = Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)[: 200 + 3 * (i % 7), : 260 + 5 * (i % 5)])
+        ext, kw = (("jpg", dict(quality=88)), ("jpg", dict(quality=70, progressive=True)), ("png", {}), ("jpg", dict(subsampling=0)))[i % 4]
+        im.save(img_dir / f"f{i}.{ext}", **kw)
+        names.append(f"f{i}.{ext}")
+        n_faces = (1, 0, 3, 2, 5, 1, 0)[i % 7]
+        lms.append(None if n_faces == 0 else [((oa.SRC * (0.7 + 0.2 * f)) + np.array([30.0 + 25 * f, 20.0 + 3 * i], np.float32)).tolist() for f in range(n_faces)])
+    data = open(img_dir / "f4.jpg", "rb").read()
+    (img_dir / "cut.jpg").write_bytes(data[: len(data) // 2])     # opens, does not decode
+    names[9], lms[9] = "cut.jpg", lms[4]
+    names[13] = "missing.jpg"                                      # does not open
+    ds_path = tmp_path / "ds"
+    datasets.Dataset.from_dict({"image": names, "face_landmarks": lms}).save_to_disk(str(ds_path))
+    model = ArcFaceR50.from_state_dict(oa.seeded_state(3)).cuda()
+    monkeypatch.setattr(fr, "from_pretrained", lambda **kw: model)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MQ_EMBED_PIPELINE", flag)
+        import shutil
+        work = tmp_path / f"ds{flag}"
+        shutil.copytree(ds_path, work)
+        with pytest.warns(UserWarning):
+            out = fr.dataset_compute_face_embedding(str(work), map_kwargs={"max_n_faces": 2, "batch_size": 6})
+        assert (fr.dataset_compute_face_embedding.last_pipeline_stats is not None) == (flag == "1")
+        got[flag] = out["face_embedding"]
+    assert fr.dataset_compute_face_embedding.last_pipeline_stats is None
+    for i, (a, b) in enumerate(zip(got["1"], got["0"])):
+        if lms[i] is None or i in (9, 13):
+            assert a is None and b is None, i
+        else:
+            a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+            assert a.shape == (min(2, len(lms[i])), 512) and np.array_equal(a, b), i

@@ -194,15 +194,51 @@ def compute_face_embedding(batch, model, preprocessor, tform, max_n_faces=1, ima
 
 
 def dataset_compute_face_embedding(dataset_path, map_kwargs={}, pretrained_kwargs={}, fn_kwargs={}):
-    """:105-112 (the reference overwrites the dataset in place; recent ``datasets`` refuses that: written next to it, then swapped)."""
+    """:105-112 (the reference overwrites the dataset in place; recent ``datasets`` refuses that: written next to it, then swapped).
+    ``compute_face_embedding``'s own arguments found in ``map_kwargs`` -- the shipped experiments/face_recognition/config.json puts
+    ``max_n_faces`` there, which ``Dataset.map`` rejects -- are moved to ``fn_kwargs``.  A plain job runs software-pipelined
+    (viquae_amd.pipeline.FaceEmbedPipeline: decode workers, JPEG scans finished on the GPU, alignment of batch i + 1 behind the
+    ArcFace forward of batch i); ``MQ_EMBED_PIPELINE=0`` maps the serial ``compute_face_embedding``."""
     from datasets import load_from_disk
     from .embedding import _save
+    from .decode_pool import early_pool
+    from ..pipeline import _map_batch_size, face_pipeline_or_none
+    map_kwargs, fn_kwargs = dict(map_kwargs), dict(fn_kwargs)
+    for k in ("max_n_faces", "image_key"):
+        if k in map_kwargs:
+            fn_kwargs.setdefault(k, map_kwargs.pop(k))
     dataset = load_from_disk(dataset_path)
+    # the decode workers are forked FIRST, while this process owns no page-locked memory (decode_pool.py)
+    workers = early_pool(None, _map_batch_size(map_kwargs)) if _map_batch_size(map_kwargs) is not None else None
     model = from_pretrained(**pretrained_kwargs)
-    fn_kwargs = dict(fn_kwargs, model=model, preprocessor=get_pil_preprocessor(), tform=SimilarityTransform())
-    map_kwargs = dict(map_kwargs)
+    pipe = face_pipeline_or_none(dataset, map_kwargs, model=model, decode_pool=workers, **fn_kwargs)
+    if pipe is None and workers is not None:
+        workers.close()
     if "new_fingerprint" not in map_kwargs:  # never pickle the model for a hash
         from datasets.fingerprint import generate_random_fingerprint
         map_kwargs["new_fingerprint"] = generate_random_fingerprint()
-    dataset = dataset.map(compute_face_embedding, batched=True, fn_kwargs=fn_kwargs, **map_kwargs)
+    if pipe is not None:
+        try:
+            dataset = dataset.map(pipe.embed, batched=True, with_indices=True, **map_kwargs)
+        finally:
+            pipe.close()
+            dataset_compute_face_embedding.last_pipeline_stats = dict(pipe.stats)
+    else:
+        dataset_compute_face_embedding.last_pipeline_stats = None
+        fn_kwargs = dict(fn_kwargs, model=model, preprocessor=get_pil_preprocessor(), tform=SimilarityTransform())
+        dataset = dataset.map(compute_face_embedding, batched=True, fn_kwargs=fn_kwargs, **map_kwargs)
     return _save(dataset, dataset_path, dataset_path)
+
+
+if __name__ == "__main__":
+    import argparse
+    import json
+    ap = argparse.ArgumentParser(description="ArcFace embeddings of the faces of a dataset (python -m meerqat.image.face_recognition <dataset> [<config>] [--disable_caching])")
+    ap.add_argument("dataset")
+    ap.add_argument("config", nargs="?")
+    ap.add_argument("--disable_caching", action="store_true")
+    a = ap.parse_args()
+    if a.disable_caching:
+        import datasets
+        datasets.disable_caching()
+    dataset_compute_face_embedding(a.dataset, **(json.load(open(a.config)) if a.config else {}))

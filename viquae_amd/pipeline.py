@@ -601,3 +601,170 @@ def image_pipeline_or_none(dataset, map_kwargs, model=None, transform=None, save
         return None
     return ImageEmbedPipeline(dataset, model, transform, save_as, image_key, call, pool, _map_batch_size(map_kwargs),
                               decode_procs=decode_procs, decode_pool=decode_pool)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# faces
+# ----------------------------------------------------------------------------------------------------------------------
+class FaceEmbedPipeline:
+    """The face job (meerqat/image/face_recognition.py:72-112: per batch, load every image that has ``face_landmarks``, align its
+    first ``max_n_faces`` faces, run ArcFace) with the host stages of batch i + 1 -- file decoding by the decode workers (JPEG
+    files: Huffman scan only, viquae_amd/image/jpeg.py), the 2 x 3 alignment matrices, H2D, the rest of the JPEG decoding and the
+    alignment kernel on a side stream -- hidden behind the ArcFace forward of batch i.  Same outputs as the serial
+    ``compute_face_embedding`` (the same faces in the same order through the same kernels)."""
+
+    def __init__(self, dataset, model, max_n_faces, image_key, batch_size, decode_pool, depth=2):
+        from .image import face_recognition as fr
+        self.fr, self.model, self.max_n_faces, self.image_key, self.decode = fr, model, int(max_n_faces), image_key, decode_pool
+        self.names = _arrow_strings(dataset, image_key)
+        self.landmarks = dataset.data.column("face_landmarks")
+        n = len(dataset)
+        self.bounds = [(s, min(s + batch_size, n)) for s in range(0, n, batch_size)]
+        first = next(iter(model.parameters()), None)
+        self.device = (first if first is not None else next(iter(model.buffers()))).device
+        self.main = torch.cuda.current_stream(self.device)
+        self.side = torch.cuda.Stream(device=self.device)
+        self.out_ring = _PinnedRing(3)
+        self._slot_busy = {}
+        self.tform = fr.SimilarityTransform()
+        self.stats = {"batches": 0, "decode_s": 0.0, "prepare_s": 0.0, "launch_s": 0.0, "wait_result_s": 0.0, "faces": 0,
+                      "decode": f"{len(decode_pool.procs)} processes -> shared pinned staging"}
+        self.look = Lookahead(len(self.bounds), self._prepare, self._launch, depth=depth)
+
+    def _prepare(self, j):
+        from .data import loading
+        from .image import jpeg as dj
+        from . import _lib
+        t0 = time.perf_counter()
+        s, e = self.bounds[j]
+        names = self.names.slice(s, e - s).to_pylist()
+        marks = self.landmarks.slice(s, e - s).to_pylist()
+        wanted = [i for i, lm in enumerate(marks) if lm is not None]      # only images with detected faces are loaded (:81-83)
+        empty = {"names": names, "rows": len(names), "images": [], "counts": [], "inputs": None, "event": None}
+        if not wanted:
+            return empty
+        sizes = self.decode.sizes([str(loading.IMAGE_PATH / names[i]) for i in wanted])
+        kept = [k for k, sz in enumerate(sizes) if sz is not None]         # positions in `wanted` of the readable files
+        if not kept:
+            return empty
+        geom = np.zeros((len(kept), 3), dtype=np.int64)                    # (offset, height, width) like mq_image_plan's first columns
+        geom[:, 1:] = [sizes[k] for k in kept]
+        totals = np.zeros(1, dtype=np.int64)
+        jrows = {row: self.decode.last_jpeg[k] for row, k in enumerate(kept) if k in self.decode.last_jpeg}
+        layout = None
+        if jrows:
+            layout = dj.plan_layout(geom, totals, jrows)
+        if not jrows or int(layout["h2d_bytes"]) > self.decode.slot_bytes:   # (coefficients can outgrow a slot the RGB bytes fit)
+            off = 0
+            for row in range(len(kept)):
+                geom[row, 0] = off
+                off += (int(geom[row, 1]) * int(geom[row, 2]) * 3 + 15) & ~15
+            totals[0] = off
+            jrows, layout = {}, None
+        h2d = int(layout["h2d_bytes"] if layout else totals[0])
+        if h2d > self.decode.slot_bytes:
+            raise RuntimeError(f"a batch of {len(kept)} images needs {h2d} bytes of staging, the slots hold {self.decode.slot_bytes}: "
+                               "raise MQ_IMAGE_SLOT_KB or set MQ_EMBED_PIPELINE=0")
+        slot = self.decode.take_slot()
+        busy = self._slot_busy.pop(slot, None)
+        if busy is not None:      # the copy that last read this slot (two batches ago) must be over before it is rewritten
+            busy[0].synchronize()
+        failed = self.decode.decode(slot, {k: int(layout["staging"][row] if row in jrows else geom[row, 0]) for row, k in enumerate(kept)},
+                                    staged={k for row, k in enumerate(kept) if row in jrows})
+        self.stats["decode_s"] += time.perf_counter() - t0
+        # faces of the images that decoded, in batch order: (row of geom, inverted 2 x 3 matrix)
+        images, counts, owner, minv = [], [], [], []
+        for row, k in enumerate(kept):
+            if k in failed:
+                continue
+            lm = np.array(marks[wanted[k]][:self.max_n_faces], dtype=np.float32)
+            images.append(wanted[k])
+            counts.append(int(lm.shape[0]))
+            for landmark in lm:
+                self.tform.estimate(landmark, self.fr.SRC)
+                owner.append(row)
+                minv.append(self.fr._invert_affine(self.tform.params[0:2, :]))
+        out = dict(empty, images=images, counts=counts)
+        if not owner:
+            return out
+        lib = _lib.load()
+        with torch.cuda.device(self.device), torch.cuda.stream(self.side):
+            dev = self.device
+            src = torch.empty(int(totals[0]), dtype=torch.uint8, device=dev)
+            src[:h2d].copy_(self.decode.tensors[slot][:h2d], non_blocking=True)
+            keep = [src]
+            if layout is not None:
+                keep.append(dj.decode_staged(src, layout["items"], layout["max_blocks"], layout["max_strips"]))
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)  # noqa: E731
+            off_d, hw_d = t(geom[:, 0]), t(geom[:, 1:].astype(np.int32).reshape(-1))
+            own_d, minv_d = t(np.array(owner, np.int32)), t(np.stack(minv).reshape(-1))
+            px = torch.empty((len(owner), 3, self.fr.IMAGE_SIZE, self.fr.IMAGE_SIZE), dtype=torch.float32, device=dev)
+            _lib.check(lib.mq_warp_affine_faces_f32(src.data_ptr(), off_d.data_ptr(), hw_d.data_ptr(), own_d.data_ptr(), minv_d.data_ptr(),
+                                                    len(owner), self.fr.IMAGE_SIZE, px.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                       "mq_warp_affine_faces_f32")
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            keep += [off_d, hw_d, own_d, minv_d]
+        self._slot_busy[slot] = (ev, keep)
+        self.stats["prepare_s"] += time.perf_counter() - t0
+        self.stats["faces"] += len(owner)
+        out.update(inputs=px, event=ev)
+        return out
+
+    def _launch(self, p):
+        t0 = time.perf_counter()
+        extra = (p["names"], p["images"], p["counts"], p["rows"])
+        if p["inputs"] is None:
+            return _Handle(None, torch.empty((0, 1)), 0, extra=extra)
+        with torch.cuda.device(self.device):
+            self.main.wait_event(p["event"])
+            p["inputs"].record_stream(self.main)
+            with torch.no_grad():
+                out = self.model(p["inputs"]).to(torch.float32).contiguous()
+            slot, buf = self.out_ring.take(out.numel() * 4)
+            pinned = buf[: out.numel() * 4].view(torch.float32).view(out.shape)
+            pinned.copy_(out, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            self.out_ring.events[slot] = ev
+        self.stats["launch_s"] += time.perf_counter() - t0
+        return _Handle(ev, pinned, out.shape[0], extra=extra)
+
+    def embed(self, batch, indices):
+        i = self.stats["batches"]
+        s, e = self.bounds[i] if i < len(self.bounds) else (-1, -1)
+        if len(indices) != e - s or int(indices[0]) != s or int(indices[-1]) != e - 1:
+            raise RuntimeError("Dataset.map handed over batches in another order than the prefetcher prepared them; set MQ_EMBED_PIPELINE=0")
+        t0 = time.perf_counter()
+        found, (names, images, counts, rows) = self.look.step(i)
+        self.stats["wait_result_s"] += time.perf_counter() - t0
+        if names != batch[self.image_key]:
+            raise RuntimeError(f"the prefetched file names of batch {i} differ from what Dataset.map decoded; set MQ_EMBED_PIPELINE=0")
+        self.stats["batches"] = i + 1
+        self.stats.setdefault("returned_at", []).append(time.perf_counter())
+        output = [None] * rows
+        j = 0
+        for at, n_faces in zip(images, counts):
+            output[at] = found[j: j + n_faces]
+            j += n_faces
+        batch["face_embedding"] = output
+        return batch
+
+    def close(self):
+        self.stats["wait_prepared_s"] = self.look.wait_prepared_s
+        self.look.close()
+        self.decode.close()
+
+
+def face_pipeline_or_none(dataset, map_kwargs, model=None, max_n_faces=1, image_key="image", decode_pool=None, **other):
+    """The pipelined face job, or None when it does not apply (then ``compute_face_embedding`` is mapped as the reference does)."""
+    if not pipeline_enabled() or other or model is None or decode_pool is None or not torch.cuda.is_available():
+        return None
+    if not _plain_dataset(dataset, map_kwargs) or _arrow_strings(dataset, image_key) is None or "face_landmarks" not in dataset.column_names:
+        return None
+    if _map_batch_size(map_kwargs) is None:
+        return None
+    first = next(iter(model.parameters()), None) if hasattr(model, "parameters") else None
+    if first is None or not first.is_cuda:
+        return None
+    return FaceEmbedPipeline(dataset, model, max_n_faces, image_key, _map_batch_size(map_kwargs), decode_pool)
