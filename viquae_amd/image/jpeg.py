@@ -52,7 +52,7 @@ def strips(h, w):
 
 
 def plan_layout(geom, totals, jpeg_rows):
-    """The packed source buffer of a batch with split-decoded JPEG files in it.  ``geom`` / ``totals`` come from
+    r"""The packed source buffer of a batch with split-decoded JPEG files in it.  ``geom`` / ``totals`` come from
     ``mq_image_plan`` (every image's RGB bytes one after the other); ``jpeg_rows`` = {row of geom: (blocks, staging bytes)}.
     Rewrites ``geom[:, 0]`` and ``totals[0]`` IN PLACE for the layout
 

@@ -765,6 +765,8 @@ def face_pipeline_or_none(dataset, map_kwargs, model=None, max_n_faces=1, image_
     if _map_batch_size(map_kwargs) is None:
         return None
     first = next(iter(model.parameters()), None) if hasattr(model, "parameters") else None
+    if first is None and hasattr(model, "buffers"):
+        first = next(iter(model.buffers()), None)
     if first is None or not first.is_cuda:
         return None
     return FaceEmbedPipeline(dataset, model, max_n_faces, image_key, _map_batch_size(map_kwargs), decode_pool)
