@@ -261,6 +261,96 @@ def image_job(n_files=256, n_refs=24 * 3072, batch=3072, workdir=None, ext="bmp"
     return out
 
 
+def face_job(n_files=256, n_refs=64 * 256, batch=256, max_n_faces=4, workdir=None):
+    """The face job as shipped (experiments/face_recognition/config.json: batch_size 256, max_n_faces 4;
+    `python -m meerqat.image.face_recognition <dataset> <config>`): JPEG files of 500 x 375 with 1-3 detected faces each
+    (landmarks as the upstream detector leaves them), ArcFace r50 with seeded weights.  Pipelined (decode workers, JPEG scans
+    finished on the GPU, alignment of batch i + 1 behind the forward of batch i) against the serial compute_face_embedding."""
+    import datasets
+    from PIL import Image
+    from oracle import arcface as oa   # (the weight layout's seeded generator only, like bench_encoders.arcface_throughput)
+    from viquae_amd.arcface import ArcFaceR50
+    from viquae_amd.data import loading
+    from viquae_amd.image import face_recognition as fr
+    datasets.disable_progress_bars()
+    rng = np.random.default_rng(3)
+    work = workdir or tempfile.mkdtemp(prefix="mq_faces_")
+    os.makedirs(os.path.join(work, "img"), exist_ok=True)
+    yy, xx = np.mgrid[0:375, 0:500]
+    for i in range(n_files):
+        f = rng.uniform(0.005, 0.05, (3, 2))
+        a = np.stack([127 + 100 * np.sin(f[c, 0] * xx + i) * np.cos(f[c, 1] * yy) for c in range(3)], axis=2)
+        Image.fromarray(np.clip(a + rng.normal(0, 6, a.shape), 0, 255).astype(np.uint8)).save(os.path.join(work, "img", f"{i}.jpg"), quality=90)
+    refs = rng.integers(0, n_files, n_refs)
+    names = [f"{int(i)}.jpg" for i in refs]
+    lms = []
+    for _ in range(n_refs):
+        k = int(rng.integers(1, 4))
+        lms.append([(fr.SRC * rng.uniform(0.6, 1.4) + rng.uniform([20, 10], [330, 200])).astype(np.float32).tolist() for _ in range(k)])
+    n_faces = sum(len(l) for l in lms)
+    keep = loading.IMAGE_PATH
+    loading.IMAGE_PATH = type(keep)(os.path.join(work, "img"))
+    out = {"workload": f"{n_refs} references to {n_files} synthetic 500x375 JPG files, {n_faces} faces (1-3 per image, max_n_faces {max_n_faces}), "
+                       f"batch {batch} (experiments/face_recognition/config.json), ArcFace r50"}
+    model_holder = {}
+
+    def pretrained(**kw):
+        if "m" not in model_holder:
+            model_holder["m"] = ArcFaceR50.from_state_dict(oa.seeded_state(0)).to("cuda").eval()
+        return model_holder["m"]
+    fr_from = fr.from_pretrained
+    fr.from_pretrained = pretrained
+    try:
+        res = {}
+        for flag, name, rows in (("1", "end_to_end", n_refs), ("0", "end_to_end_serial", 4 * batch)):
+            os.environ["MQ_EMBED_PIPELINE"] = flag
+            path = os.path.join(work, f"ds{flag}")
+            datasets.Dataset.from_dict({"image": names[:rows], "face_landmarks": lms[:rows]}).save_to_disk(path)
+            t0 = time.perf_counter()
+            got = fr.dataset_compute_face_embedding(path, map_kwargs={"max_n_faces": max_n_faces, "batch_size": batch})
+            _sync(); t = time.perf_counter() - t0
+            faces = sum(len(l) for l in lms[:rows])
+            res[name] = {"images": rows, "faces": faces, "seconds": round(t, 2), "images_per_s": round(rows / t, 1), "faces_per_s": round(faces / t, 1)}
+            st = fr.dataset_compute_face_embedding.last_pipeline_stats
+            if st:
+                nb = max(1, rows // batch)
+                stamps = st.get("returned_at", [])
+                if len(stamps) > 8:
+                    res[name]["steady_state_images_per_s"] = round((len(stamps) - 1 - 4) * batch / (stamps[-1] - stamps[4]), 1)
+                res[name]["pipeline"] = {"worker_prepare_ms_per_batch": round(st["prepare_s"] / nb * 1e3, 1),
+                                         "of_which_decode_ms": round(st["decode_s"] / nb * 1e3, 1),
+                                         "main_waited_for_worker_ms_per_batch": round(st["wait_prepared_s"] / nb * 1e3, 1),
+                                         "main_launch_ms_per_batch": round(st["launch_s"] / nb * 1e3, 1), "decode": st.get("decode")}
+        os.environ["MQ_EMBED_PIPELINE"] = "1"
+        # the forward alone at the job's batch composition (~2 faces per image)
+        m = pretrained()
+        px = torch.rand((n_faces * batch // n_refs, 3, 112, 112), device="cuda") * 2 - 1
+        m(px); _sync(); t0 = time.perf_counter()
+        for _ in range(3):
+            m(px)
+        _sync(); tf = (time.perf_counter() - t0) / 3
+        res["forward_only"] = {"faces_per_batch": int(px.shape[0]), "ms_per_batch": round(tf * 1e3, 2), "faces_per_s": round(px.shape[0] / tf, 1),
+                               "images_per_s": round(batch / tf, 1)}
+        res["end_to_end"]["x_forward_only"] = round(res["end_to_end"]["images_per_s"] / (batch / tf), 3)
+        res["end_to_end"]["x_serial"] = round(res["end_to_end"]["images_per_s"] / res["end_to_end_serial"]["images_per_s"], 1)
+        out.update(res)
+    finally:
+        fr.from_pretrained = fr_from
+        loading.IMAGE_PATH = keep
+        if workdir is None:
+            shutil.rmtree(work, ignore_errors=True)
+    return out
+
+
+def face_job_in_a_fresh_process():
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--faces"], capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": f"rc {p.returncode}", "stderr": p.stderr[-600:]}
+    return json.loads(lines[-1])
+
+
 def image_job_in_a_fresh_process(ext):
     """The image job as the reference runs it -- its own `python -m ...image.embedding` process.  (Inside the long-lived
     benchmark process the decode workers would be forked from a process that already holds gigabytes of page-locked memory,
@@ -279,7 +369,8 @@ def main(n_passages=65536):
     for name, fn in (("text", lambda: text_job(n_passages)),
                      ("text_questions", lambda: text_job(32768, mean_words=11, sd_words=4, serial_batches=2, what="questions")),
                      ("image", lambda: image_job_in_a_fresh_process("bmp")),
-                     ("image_jpeg", lambda: image_job_in_a_fresh_process("jpg"))):
+                     ("image_jpeg", lambda: image_job_in_a_fresh_process("jpg")),
+                     ("faces", face_job_in_a_fresh_process)):
         try:
             out[name] = fn()
         except Exception as e:  # noqa: BLE001 - a measurement, never a reason to lose the bench line
@@ -290,7 +381,9 @@ def main(n_passages=65536):
 
 if __name__ == "__main__":
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    if len(sys.argv) > 2 and sys.argv[1] == "--image":
+    if len(sys.argv) > 1 and sys.argv[1] == "--faces":
+        print(json.dumps(face_job()))
+    elif len(sys.argv) > 2 and sys.argv[1] == "--image":
         print(json.dumps(image_job(ext=sys.argv[2], n_refs=int(sys.argv[3]) * 3072 if len(sys.argv) > 3 else 24 * 3072)))
     else:
         n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
