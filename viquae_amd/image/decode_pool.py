@@ -197,9 +197,16 @@ class DecodePool:
         """offsets: {index in the batch: byte offset in `slot`} for the images to decode (RGB bytes, or the staging area of a
         ``last_jpeg`` file) -> set of indices that failed.  ``staged``: the indices whose offset IS a staging area (default: every
         ``last_jpeg`` file); a ``last_jpeg`` file outside it is decoded by Pillow to RGB bytes like any other file."""
+        self.decode_start(slot, offsets, staged)
+        return self.decode_finish()
+
+    def decode_start(self, slot, offsets, staged=None):
+        """The first half of :meth:`decode`: the workers get their items and start; the caller does something else meanwhile."""
         staged = set(self.last_jpeg) if staged is None else staged
         for c, lo, hi in self._chunks:
             self.conns[c].send(("decode", slot, [(i, int(offsets[i]), i in staged) for i in range(lo, hi) if i in offsets]))
+
+    def decode_finish(self):
         failed = set()
         for c, lo, hi in self._chunks:
             for idx, err in self._recv(self.conns[c], "decode"):

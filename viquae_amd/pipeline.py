@@ -669,21 +669,29 @@ class FaceEmbedPipeline:
         busy = self._slot_busy.pop(slot, None)
         if busy is not None:      # the copy that last read this slot (two batches ago) must be over before it is rewritten
             busy[0].synchronize()
-        failed = self.decode.decode(slot, {k: int(layout["staging"][row] if row in jrows else geom[row, 0]) for row, k in enumerate(kept)},
-                                    staged={k for row, k in enumerate(kept) if row in jrows})
+        self.decode.decode_start(slot, {k: int(layout["staging"][row] if row in jrows else geom[row, 0]) for row, k in enumerate(kept)},
+                                 staged={k for row, k in enumerate(kept) if row in jrows})
+        # while the workers decode: the faces' alignment matrices (Umeyama's estimate per face, ~40 us of numpy calls each)
+        per_image = []
+        for row, k in enumerate(kept):
+            lm = np.array(marks[wanted[k]][:self.max_n_faces], dtype=np.float32)
+            mats = []
+            for landmark in lm:
+                self.tform.estimate(landmark, self.fr.SRC)
+                mats.append(self.fr._invert_affine(self.tform.params[0:2, :]))
+            per_image.append((int(lm.shape[0]), mats))
+        failed = self.decode.decode_finish()
         self.stats["decode_s"] += time.perf_counter() - t0
         # faces of the images that decoded, in batch order: (row of geom, inverted 2 x 3 matrix)
         images, counts, owner, minv = [], [], [], []
         for row, k in enumerate(kept):
             if k in failed:
                 continue
-            lm = np.array(marks[wanted[k]][:self.max_n_faces], dtype=np.float32)
             images.append(wanted[k])
-            counts.append(int(lm.shape[0]))
-            for landmark in lm:
-                self.tform.estimate(landmark, self.fr.SRC)
+            counts.append(per_image[row][0])
+            for m in per_image[row][1]:
                 owner.append(row)
-                minv.append(self.fr._invert_affine(self.tform.params[0:2, :]))
+                minv.append(m)
         out = dict(empty, images=images, counts=counts)
         if not owner:
             return out
