@@ -347,3 +347,38 @@ def test_job_fingerprint_follows_the_code_that_computes_the_embeddings(monkeypat
     assert "meerqat_hip" in utils.code_fingerprint()
     monkeypatch.setattr(utils, "_CODE_FINGERPRINT", "meerqat_hip 9.9 (gfx950):0123456789abcdef")
     assert utils.job_fingerprint(DS(), "job", key="passage") != a
+
+
+def test_decode_pool_runs_small_host_functions_in_the_workers(tmp_path):
+    """DecodePool.call_start / call_finish: a named function over per-image arguments, spread over the workers like the files
+    (the face job's alignment matrices); replies in request order with a decode in flight; a failure is raised in the parent."""
+    from PIL import Image
+    from viquae_amd.image import face_recognition as fr
+    from viquae_amd.image.decode_pool import DecodePool
+    rng = np.random.default_rng(0)
+    paths = []
+    for i in range(7):
+        p = str(tmp_path / f"{i}.png")
+        Image.fromarray(rng.integers(0, 256, (20 + i, 30, 3), dtype=np.uint8)).save(p)
+        paths.append(p)
+    lms = [[(fr.SRC * (0.8 + 0.1 * f) + np.array([10.0 * i, 5.0 * f], np.float32)).tolist() for f in range(1 + i % 3)] for i in range(7)]
+    pool = DecodePool(3, 1 << 20, n_slots=2)
+    try:
+        sizes = pool.sizes(paths)
+        pool.call_start("viquae_amd.image.face_recognition", "face_matrices", {i: (lms[i], 2) for i in range(7) if i != 3})
+        offs, o = {}, 0
+        for i, (h, w) in enumerate(sizes):
+            offs[i] = o
+            o += -(-(h * w * 3) // 16) * 16
+        pool.decode_start(pool.take_slot(), offs)
+        got = pool.call_finish()
+        assert pool.decode_finish() == set() and sorted(got) == [0, 1, 2, 4, 5, 6]
+        for i, (n, mats) in got.items():
+            want = fr.face_matrices((lms[i], 2))
+            assert n == want[0] == min(2, len(lms[i])) and all(np.array_equal(a, b) for a, b in zip(mats, want[1]))
+        pool.sizes(paths)
+        pool.call_start("viquae_amd.image.face_recognition", "no_such_function", {0: 1})
+        with pytest.raises(RuntimeError, match="no_such_function"):
+            pool.call_finish()
+    finally:
+        pool.close()

@@ -95,6 +95,16 @@ def _worker(conn, slots):
                 except Exception as e:  # noqa: BLE001 - load_image catches everything too
                     out.append((None, f"Caught exception '{e}' with image '{path}'", None))
             conn.send(out)
+        elif kind == "call":
+            # a small per-image host computation spread over the workers (e.g. the faces' alignment matrices): the named function
+            # is applied to every item's argument; an exception travels back and is raised in the parent
+            _, module, function, items = msg
+            try:
+                import importlib
+                fn = getattr(importlib.import_module(module), function)
+                conn.send([(i, fn(arg)) for i, arg in items])
+            except Exception as e:  # noqa: BLE001
+                conn.send(RuntimeError(f"{module}.{function} failed in a decode worker: {e!r}"))
         elif kind == "decode":
             _, slot, items = msg   # items: (index in the batch, byte offset in the slot, offset is a JPEG staging area)
             buf = np.frombuffer(slots[slot], dtype=np.uint8)
@@ -205,6 +215,22 @@ class DecodePool:
         staged = set(self.last_jpeg) if staged is None else staged
         for c, lo, hi in self._chunks:
             self.conns[c].send(("decode", slot, [(i, int(offsets[i]), i in staged) for i in range(lo, hi) if i in offsets]))
+
+    def call_start(self, module, function, items):
+        """``items``: {index in the batch (of the last :meth:`sizes`): argument}.  Every worker applies ``module.function`` to the
+        arguments of its share of the batch; collect with :meth:`call_finish` (replies come in the order the requests were sent:
+        a ``call_start`` before a ``decode_start`` is finished before it)."""
+        for c, lo, hi in self._chunks:
+            self.conns[c].send(("call", module, function, [(i, items[i]) for i in range(lo, hi) if i in items]))
+
+    def call_finish(self):
+        out = {}
+        for c, lo, hi in self._chunks:
+            got = self._recv(self.conns[c], "call")
+            if isinstance(got, Exception):
+                raise got
+            out.update(got)
+        return out
 
     def decode_finish(self):
         failed = set()

@@ -92,6 +92,20 @@ def _invert_affine(M):
     return M
 
 
+def face_matrices(arg):
+    """(landmarks of one image, max_n_faces) -> (number of faces kept, [the inverted 2 x 3 matrix of each face as cv::warpAffine
+    uses it]): ``tform.estimate(landmark, SRC)`` + the inversion, per face like ``compute_face_embedding`` does it -- the same numpy
+    calls, so the same bits.  The pipelined job runs it in the decode workers (~50 us of small numpy calls per face)."""
+    landmarks, max_n_faces = arg
+    lm = np.array(landmarks[:max_n_faces], dtype=np.float32)
+    tform = SimilarityTransform()
+    mats = []
+    for landmark in lm:
+        tform.estimate(landmark, SRC)
+        mats.append(_invert_affine(tform.params[0:2, :]))
+    return int(lm.shape[0]), mats
+
+
 def align_faces_device(images, faces, device, image_size=IMAGE_SIZE):
     """``images``: list of uint8 [H, W, 3] arrays; ``faces``: list of (image index, 2 x 3 matrix M as tform.params[0:2]).
     -> fp32 CUDA tensor [len(faces), 3, size, size]: warpAffine + ToTensor + Normalize(0.5, 0.5) of every face, one kernel."""

@@ -669,17 +669,12 @@ class FaceEmbedPipeline:
         busy = self._slot_busy.pop(slot, None)
         if busy is not None:      # the copy that last read this slot (two batches ago) must be over before it is rewritten
             busy[0].synchronize()
+        # the faces' alignment matrices (Umeyama's estimate per face: ~50 us of small numpy calls each) are the workers' job too
+        self.decode.call_start("viquae_amd.image.face_recognition", "face_matrices", {k: (marks[wanted[k]], self.max_n_faces) for k in kept})
         self.decode.decode_start(slot, {k: int(layout["staging"][row] if row in jrows else geom[row, 0]) for row, k in enumerate(kept)},
                                  staged={k for row, k in enumerate(kept) if row in jrows})
-        # while the workers decode: the faces' alignment matrices (Umeyama's estimate per face, ~40 us of numpy calls each)
-        per_image = []
-        for row, k in enumerate(kept):
-            lm = np.array(marks[wanted[k]][:self.max_n_faces], dtype=np.float32)
-            mats = []
-            for landmark in lm:
-                self.tform.estimate(landmark, self.fr.SRC)
-                mats.append(self.fr._invert_affine(self.tform.params[0:2, :]))
-            per_image.append((int(lm.shape[0]), mats))
+        mats = self.decode.call_finish()
+        per_image = [mats[k] for k in kept]
         failed = self.decode.decode_finish()
         self.stats["decode_s"] += time.perf_counter() - t0
         # faces of the images that decoded, in batch order: (row of geom, inverted 2 x 3 matrix)
