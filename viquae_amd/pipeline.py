@@ -747,9 +747,10 @@ class FaceEmbedPipeline:
         self.stats.setdefault("returned_at", []).append(time.perf_counter())
         output = [None] * rows
         j = 0
-        for at, n_faces in zip(images, counts):
-            output[at] = found[j: j + n_faces]
-            j += n_faces
+        if sum(counts):   # (a batch without a single face: every entry None, like the reference's early return)
+            for at, n_faces in zip(images, counts):
+                output[at] = found[j: j + n_faces]
+                j += n_faces
         batch["face_embedding"] = output
         return batch
 
