@@ -268,7 +268,7 @@ def face_job(n_files=256, n_refs=64 * 256, batch=256, max_n_faces=4, workdir=Non
     finished on the GPU, alignment of batch i + 1 behind the forward of batch i) against the serial compute_face_embedding."""
     import datasets
     from PIL import Image
-    from oracle import arcface as oa   # (the weight layout's seeded generator only, like bench_encoders.arcface_throughput)
+    from bench_encoders import random_arcface_state
     from viquae_amd.arcface import ArcFaceR50
     from viquae_amd.data import loading
     from viquae_amd.image import face_recognition as fr
@@ -296,7 +296,7 @@ def face_job(n_files=256, n_refs=64 * 256, batch=256, max_n_faces=4, workdir=Non
 
     def pretrained(**kw):
         if "m" not in model_holder:
-            model_holder["m"] = ArcFaceR50.from_state_dict(oa.seeded_state(0)).to("cuda").eval()
+            model_holder["m"] = ArcFaceR50.from_state_dict(random_arcface_state(0)).to("cuda").eval()
         return model_holder["m"]
     fr_from = fr.from_pretrained
     fr.from_pretrained = pretrained

@@ -142,14 +142,52 @@ def clip_throughput(B=3072, steps=2, device="cuda"):
     return {"images_per_s": B / t, "ms_per_batch": t * 1e3, "batch": B, "tflops": 8.82e9 * B / t / 1e12}
 
 
+def random_arcface_state(seed=0, layers=(3, 4, 14, 3), planes=(64, 128, 256, 512), num_features=512):
+    """A synthetic IResNet-50 checkpoint in arcface_torch's layout (fp32 numpy): random weights scaled so that activations stay
+    O(1) through the 50 layers (benchmarks only; the tests' seeded checkpoints come from oracle/arcface.py)."""
+    rng = np.random.default_rng(seed)
+    st = {}
+
+    def conv(name, cout, cin, k):
+        st[name + ".weight"] = (rng.standard_normal((cout, cin, k, k)) * np.sqrt(1.0 / (cin * k * k))).astype(np.float32)
+
+    def bn(name, c, lo=0.6, hi=1.4):
+        st[name + ".weight"] = rng.uniform(lo, hi, c).astype(np.float32)
+        st[name + ".bias"] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        st[name + ".running_mean"] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        st[name + ".running_var"] = rng.uniform(0.6, 1.4, c).astype(np.float32)
+
+    conv("conv1", 64, 3, 3)
+    bn("bn1", 64)
+    st["prelu.weight"] = rng.uniform(0.1, 0.4, 64).astype(np.float32)
+    inplanes = 64
+    for s_, (n, pl) in enumerate(zip(layers, planes), start=1):
+        for i in range(n):
+            p = f"layer{s_}.{i}"
+            bn(p + ".bn1", inplanes)
+            conv(p + ".conv1", pl, inplanes, 3)
+            bn(p + ".bn2", pl)
+            st[p + ".prelu.weight"] = rng.uniform(0.1, 0.4, pl).astype(np.float32)
+            conv(p + ".conv2", pl, pl, 3)
+            bn(p + ".bn3", pl, 0.15, 0.35)
+            if i == 0:
+                conv(p + ".downsample.0", pl, inplanes, 1)
+                bn(p + ".downsample.1", pl)
+            inplanes = pl
+    bn("bn2", 512)
+    st["fc.weight"] = (rng.standard_normal((num_features, 512 * 49)) * np.sqrt(1.0 / (512 * 49))).astype(np.float32)
+    st["fc.bias"] = (0.1 * rng.standard_normal(num_features)).astype(np.float32)
+    bn("features", num_features)
+    return st
+
+
 def arcface_throughput(B=656, steps=3, device="cuda"):
-    """ArcFace r50 (meerqat/image/face_recognition.py:55-61) on aligned 112 x 112 faces: seeded weights (oracle/arcface.py's
-    layout), fp32-class arithmetic.  Algorithmic work: 12.63 GFLOP per face (6.31 G multiply-adds: the 50 convolutions + fc)."""
+    """ArcFace r50 (meerqat/image/face_recognition.py:55-61) on aligned 112 x 112 faces: random weights in the checkpoint's
+    layout (random_arcface_state), fp32-class arithmetic.  Algorithmic work: 12.63 GFLOP per face (6.31 G multiply-adds: the 50 convolutions + fc)."""
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from oracle import arcface as oa
     from viquae_amd.arcface import ArcFaceR50
-    model = ArcFaceR50.from_state_dict(oa.seeded_state(0)).to(device).eval()
+    model = ArcFaceR50.from_state_dict(random_arcface_state(0)).to(device).eval()
     g = torch.Generator(device=device).manual_seed(4)
     px = torch.rand((B, 3, 112, 112), generator=g, device=device) * 2 - 1
     t = time_it(lambda: model(px), steps)
