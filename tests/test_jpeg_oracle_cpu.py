@@ -191,3 +191,19 @@ def test_progressive_files_through_the_host_decoder():
     p = dj.probe(cut)
     st = np.zeros(p[4], dtype=np.uint8)
     assert _pillow(cut).shape == _pillow(data).shape and not dj.stage(cut, st.ctypes.data, st.size)
+
+
+def test_grey_file_with_sampling_factors_other_than_one():
+    """A one-component frame is never interleaved: its scan codes ceil(W / 8) x ceil(H / 8) blocks whatever sampling factors the
+    header gives the component (libjpeg; made here by rewriting the factors of a grey file to 2 x 2)."""
+    rng = np.random.default_rng(0)
+    for h, w in ((37, 53), (64, 64), (9, 100)):
+        buf = io.BytesIO()
+        jp.picture(rng, h, w, grey=True).save(buf, "JPEG", quality=80)
+        d = bytearray(buf.getvalue())
+        at = d.find(b"\xff\xc0")
+        assert d[at + 9] == 1 and d[at + 11] == 0x11
+        d[at + 11] = 0x22
+        d = bytes(d)
+        _, st = _staged(d)
+        assert np.array_equal(oj.decode_staging(st), _pillow(d)) and np.array_equal(oj.decode(d), _pillow(d))
