@@ -207,3 +207,18 @@ def test_grey_file_with_sampling_factors_other_than_one():
         d = bytes(d)
         _, st = _staged(d)
         assert np.array_equal(oj.decode_staging(st), _pillow(d)) and np.array_equal(oj.decode(d), _pillow(d))
+
+
+def test_fill_bytes_in_front_of_markers_are_legal():
+    """Any number of 0xFF fill bytes may precede a marker (the restart markers inside a scan, the end-of-image marker): still a
+    regular file, decoded here, same pixels."""
+    from viquae_amd.image import jpeg as dj
+    buf = io.BytesIO()
+    jp.picture(np.random.default_rng(0), 50, 70).save(buf, "JPEG", quality=80, restart_marker_blocks=3)
+    d = buf.getvalue()
+    d2 = d[:-2] + b"\xff\xff\xff" + d[-2:]
+    for k in range(8):
+        d2 = d2.replace(bytes([0xFF, 0xD0 + k]), b"\xff\xff" + bytes([0xFF, 0xD0 + k]))
+    assert len(d2) > len(d) + 6
+    _, st = _staged(d2)
+    assert np.array_equal(oj.decode_staging(st), _pillow(d2)) and np.array_equal(_pillow(d2), _pillow(d))

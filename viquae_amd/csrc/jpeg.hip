@@ -135,6 +135,11 @@ struct Bits {
         }
     }
     inline unsigned peek(int k) const { return (unsigned)(acc >> (n - k)) & ((1u << k) - 1); }
+    // at the end of a scan or a restart interval: is marker `m` next?  (any number of 0xFF fill bytes may precede a marker)
+    inline bool at_marker(int m) {
+        while (p + 2 < end && p[0] == 0xFF && p[1] == 0xFF) ++p;
+        return p + 1 < end && p[0] == 0xFF && p[1] == m;
+    }
     inline void drop(int k) { n -= k; }
 };
 
@@ -403,7 +408,7 @@ static bool read_progressive(const uint8_t* file, size_t nbytes, Parsed* ps, int
             for (int mx = 0; mx < nx; ++mx) {
                 if (ps->restart && todo == 0) {
                     if (b.n < b.fake || b.n - b.fake >= 8) return false;
-                    if (!(b.p + 1 < b.end && b.p[0] == 0xFF && b.p[1] == 0xD0 + rst)) return false;
+                    if (!b.at_marker(0xD0 + rst)) return false;
                     b.p += 2;
                     b.acc = 0; b.n = 0; b.fake = 0;
                     rst = (rst + 1) & 7;
@@ -578,7 +583,7 @@ int mq_jpeg_read_coefficients(const uint8_t* file_host, size_t nbytes, void* sta
             if (ps->restart && todo == 0) {
                 // the interval's bits are used up: whatever is left of the last byte is padding; the marker must follow at once
                 if (b.n < b.fake || b.n - b.fake >= 8) { bad = true; break; }
-                if (!(b.p + 1 < b.end && b.p[0] == 0xFF && b.p[1] == 0xD0 + rst)) { bad = true; break; }
+                if (!b.at_marker(0xD0 + rst)) { bad = true; break; }
                 b.p += 2;
                 b.acc = 0; b.n = 0; b.fake = 0;
                 rst = (rst + 1) & 7;
@@ -664,7 +669,7 @@ int mq_jpeg_read_coefficients(const uint8_t* file_host, size_t nbytes, void* sta
 done:
     // nothing but the padding of the last byte may be left, and the next thing in the file is the end-of-image marker
     if (!bad && (b.n < b.fake || b.n - b.fake >= 8)) bad = true;
-    if (!bad && !(b.p + 1 < b.end && b.p[0] == 0xFF && b.p[1] == 0xD9)) bad = true;
+    if (!bad && !b.at_marker(0xD9)) bad = true;
     delete ps;
     if (bad) return MQ_EINVAL;
     hw[H_MAGIC] = MQ_JPEG_MAGIC_COEFFICIENTS;
